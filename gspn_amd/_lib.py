@@ -1,0 +1,113 @@
+"""ctypes binding of libgspn_hip.so (C ABI in include/gspn_hip.h).
+
+The product path has NO CPU fallback: if the HIP library is missing or a tensor is not on a
+ROCm device the call raises.  PyTorch is used only for device memory and streams.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgspn_hip.so")
+
+_c = ctypes
+_P = _c.c_void_p
+_I = _c.c_int
+_L = _c.c_long
+_F = _c.c_float
+
+
+class BnBwdArgs(_c.Structure):
+    """mirror of struct gspn_bn_bwd_args (include/gspn_hip.h)"""
+    _fields_ = [("Y", _P), ("ldy", _I), ("dZ", _P), ("ldz", _I), ("dPool", _P), ("pool_arg", _P), ("ns", _I),
+                ("mean", _P), ("var", _P), ("gamma", _P), ("beta", _P), ("eps", _F), ("red", _P),
+                ("use_bn", _I), ("is_training", _I)]
+
+
+# symbol -> argtypes; every entry point of include/gspn_hip.h (tests check the list against the header)
+SIGNATURES = {
+    "gspn_dist_policy": [],
+    "gspn_abi_version": [],
+    "gspn_farthestpointsampling": [_I, _I, _I, _P, _P, _P, _P],
+    "gspn_gatherpoint": [_I, _I, _I, _P, _P, _P, _P],
+    "gspn_scatteraddpoint": [_I, _I, _I, _P, _P, _P, _P],
+    "gspn_probsample": [_I, _I, _I, _P, _P, _P, _P, _P],
+    "gspn_queryballpoint": [_I, _I, _I, _F, _I, _P, _P, _P, _P, _P],
+    "gspn_selectionsort": [_I, _I, _I, _I, _P, _P, _P, _P],
+    "gspn_grouppoint": [_I, _I, _I, _I, _I, _P, _P, _P, _P],
+    "gspn_grouppoint_grad": [_I, _I, _I, _I, _I, _P, _P, _P, _P],
+    "gspn_groupmaxpool": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
+    "gspn_groupmaxpool_grad": [_I, _I, _I, _I, _P, _P, _P, _P],
+    "gspn_threenn": [_I, _I, _I, _P, _P, _P, _P, _P],
+    "gspn_threeinterpolate": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
+    "gspn_threeinterpolate_grad": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
+    "gspn_nmdistance": [_I, _I, _P, _I, _P, _P, _P, _P, _P, _P],
+    "gspn_nmdistance_grad": [_I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P],
+    "gspn_sa_group_concat": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P],
+    "gspn_sa_group_concat_grad": [_I, _I, _I, _I, _I, _P, _I, _I, _P, _P, _P],
+}
+# MLP entry points: bound once mlp.hip lands
+PENDING = {
+    "gspn_mlp_fwd": [_L, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P],
+    "gspn_bn_finalize": [_L, _I, _P, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P],
+    "gspn_bnrelu_maxpool": [_L, _I, _I, _P, _I, _P, _P, _P, _P, _P],
+    "gspn_bnrelu_apply": [_L, _I, _P, _I, _P, _P, _P, _I, _P],
+    "gspn_bn_bwd_reduce": [_L, _I, _c.POINTER(BnBwdArgs), _P, _P, _P, _P],
+    "gspn_mlp_bwd_data": [_L, _I, _I, _c.POINTER(BnBwdArgs), _P, _P, _I, _P],
+    "gspn_mlp_bwd_weight": [_L, _I, _I, _c.POINTER(BnBwdArgs), _P, _I, _P, _P, _P, _P, _P],
+}
+SIGNATURES["gspn_fill_zero"] = [_P, _L, _P]
+
+_lib = None
+
+
+class GspnHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libgspn_hip.so (built by gspn_amd.build); raises loudly if it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GspnHipError(
+                "libgspn_hip.so not found at %s -- run `python -m gspn_amd.build` (there is no CPU fallback)" % LIB_PATH)
+        h = ctypes.CDLL(LIB_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(h, name)          # AttributeError if the ABI and the binding drift apart
+            fn.argtypes = args
+            fn.restype = _I
+        _lib = h
+    return _lib
+
+
+def check(rc, what):
+    if rc == 0:
+        return
+    if rc == -1:
+        raise ValueError("%s: invalid argument (rejected like the reference's OP_REQUIRES)" % what)
+    if rc == -2:
+        raise NotImplementedError("%s: input outside the supported range of this build" % what)
+    raise GspnHipError("%s: HIP error %d" % (what, rc))
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def need(t, dtype, ndim, name):
+    """shape/dtype/device validation shared by the op wrappers (ValueError like TF's InvalidArgument)"""
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a torch.Tensor" % name)
+    if t.dtype != dtype:
+        raise ValueError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if ndim is not None and t.dim() != ndim:
+        raise ValueError("%s must be %d-D, got shape %s" % (name, ndim, tuple(t.shape)))
+    if not t.is_cuda:
+        raise GspnHipError("%s is on %s: gspn_amd runs on ROCm devices only (no CPU fallback)" % (name, t.device))
+    return t.contiguous()

@@ -1,0 +1,332 @@
+// grouping.hip -- tf_ops/grouping on gfx950: ball query, group_point (+grad), group_maxpool
+// (+grad), selection sort, and the fused sample_and_group tail used by pointnet_util.
+// Reference semantics: tf_ops/grouping/tf_grouping_g.cu (cited per kernel).
+#include <math.h>
+
+#include "common.h"
+
+// ============================================================================================
+// Ball query (reference: tf_grouping_g.cu:6-39)
+//
+// Reference: one THREAD per query scanning k = 0..n-1 serially with a divergent early break;
+// b*256 threads in flight.  Here: one WAVE per query.  The 64 lanes test 64 consecutive data
+// points at once, a ballot gives the hit mask, mbcnt gives each hit its slot so hits are written
+// in ascending k exactly as the serial scan would, and the wave stops as soon as nsample hits
+// exist.  Four 64-point chunks are in flight per iteration to hide the L2 latency of the AoS
+// point loads.  The scene (<= 384 KiB) stays L2 resident; the block -> scene map keeps one scene
+// on one XCD's L2 (block b runs on XCD b % 8).
+//
+// Hit test: the reference evaluates  max(sqrtf(s), 1e-20f) < radius  (:27-28).  sqrtf is
+// correctly rounded and monotone, so this equals  s < T  with T = the smallest float whose
+// sqrtf is >= radius (and "no hit at all" when radius <= 1e-20f).  T is found on the host with
+// IEEE sqrtf; the kernel needs no square root and stays bit-exact.
+// ============================================================================================
+#define BQ_WAVES 4
+#define BQ_UNROLL 4
+
+__global__ __launch_bounds__(BQ_WAVES * 64) void ball_query_kernel(int b, int n, int m, float thresh, int nsample,
+                                                                  const float* __restrict__ xyz1, const float* __restrict__ xyz2,
+                                                                  int* __restrict__ idx, int* __restrict__ pts_cnt) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int scene = blockIdx.x % b;            // scene <-> XCD affinity
+    const int chunk = blockIdx.x / b;
+    const int j = chunk * BQ_WAVES + wave;
+    if (j >= m) return;
+    const float* data = xyz1 + (size_t)scene * n * 3;
+    const float* qp = xyz2 + ((size_t)scene * m + j) * 3;
+    int* row = idx + ((size_t)scene * m + j) * nsample;
+    const float qx = qp[0], qy = qp[1], qz = qp[2];
+
+    int cnt = 0, first = 0;
+    for (int base = 0; base < n && cnt < nsample; base += 64 * BQ_UNROLL) {
+        float s[BQ_UNROLL];
+#pragma unroll
+        for (int u = 0; u < BQ_UNROLL; ++u) {
+            const int k = base + u * 64 + lane;
+            float px = 0.f, py = 0.f, pz = 0.f;
+            if (k < n) {
+                px = data[k * 3 + 0];
+                py = data[k * 3 + 1];
+                pz = data[k * 3 + 2];
+            }
+            s[u] = dist2_cuda(qx - px, qy - py, qz - pz);      // (x2-x1): query minus data, :27
+        }
+#pragma unroll
+        for (int u = 0; u < BQ_UNROLL; ++u) {
+            const int k = base + u * 64 + lane;
+            const bool hit = (k < n) && (s[u] < thresh);
+            const unsigned long long mask = __ballot(hit);
+            if (mask != 0ull && cnt < nsample) {
+                if (cnt == 0) first = base + u * 64 + __builtin_ctzll(mask);
+                const int pos = cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                if (hit && pos < nsample) row[pos] = k;          // :33
+                cnt += __builtin_popcountll(mask);
+            }
+        }
+    }
+    cnt = cnt < nsample ? cnt : nsample;
+    // :29-32 -- unfilled slots repeat the first hit; rows without a hit are zero-filled
+    for (int l = cnt + lane; l < nsample; l += 64) row[l] = first;
+    if (lane == 0) pts_cnt[(size_t)scene * m + j] = cnt;         // :37
+}
+
+static float ball_threshold(float radius) {
+    // smallest float T with sqrtf(T) >= radius
+    if (!(radius > 1e-20f)) return 0.0f;                  // max(d,1e-20f) < radius is never true
+    if (isinf(radius)) return INFINITY;
+    float t = radius * radius;
+    if (isinf(t)) t = 3.402823466e+38f;
+    while (t > 0.0f && sqrtf(t) >= radius) t = nextafterf(t, 0.0f);
+    while (sqrtf(t) < radius) t = nextafterf(t, INFINITY);
+    return t;
+}
+
+extern "C" int gspn_queryballpoint(int b, int n, int m, float radius, int nsample, const float* xyz1, const float* xyz2,
+                                   int* idx, int* pts_cnt, void* stream) {
+    if (!(radius > 0.0f) || nsample <= 0) return GSPN_ERR_ARG;        // tf_grouping.cpp:101,104
+    if (b < 0 || n <= 0 || m < 0) return GSPN_ERR_ARG;
+    if (b == 0 || m == 0) return 0;
+    const long long blocks = (long long)b * ((m + BQ_WAVES - 1) / BQ_WAVES);
+    if (blocks > 0x7FFFFFFFll || (long long)n * 3 > 0x7FFFFFFFll) return GSPN_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(ball_query_kernel, dim3((unsigned)blocks), dim3(BQ_WAVES * 64), 0, (hipStream_t)stream,
+                       b, n, m, ball_threshold(radius), nsample, xyz1, xyz2, idx, pts_cnt);
+    return gspn_launch_status();
+}
+
+// ============================================================================================
+// group_point / group_point_grad  (tf_grouping_g.cu:43-83)
+// The reference gives each query to one thread (stride-ns*c stores between lanes).  Here one
+// thread per OUTPUT element, so stores (and the grad loads) are fully coalesced; the gathered
+// source rows are c contiguous floats each.
+// ============================================================================================
+template <int VEC>
+__global__ void group_point_kernel(long total, int n, int c, int m_ns, const float* __restrict__ points, const int* __restrict__ idx, float* __restrict__ out) {
+    // total = b*m*ns*(c/VEC) work items; item -> (row, chunk)
+    const int cv = c / VEC;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long row = i / cv;
+        const int ch = (int)(i - row * cv) * VEC;
+        const long bi = row / m_ns;
+        const int ii = idx[row];
+        const float* src = points + ((size_t)bi * n + ii) * c + ch;
+        float* dst = out + (size_t)row * c + ch;
+        if (VEC == 4) *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(src);
+        else dst[0] = src[0];
+    }
+}
+template <int VEC>
+__global__ void group_point_grad_kernel(long total, int n, int c, int m_ns, const float* __restrict__ grad_out, const int* __restrict__ idx, float* __restrict__ grad_points) {
+    const int cv = c / VEC;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long row = i / cv;
+        const int ch = (int)(i - row * cv) * VEC;
+        const long bi = row / m_ns;
+        const int ii = idx[row];
+        float* dst = grad_points + ((size_t)bi * n + ii) * c + ch;
+        const float* src = grad_out + (size_t)row * c + ch;
+        if (VEC == 4) {
+            const float4 v = *reinterpret_cast<const float4*>(src);
+            atomicAdd(dst + 0, v.x); atomicAdd(dst + 1, v.y); atomicAdd(dst + 2, v.z); atomicAdd(dst + 3, v.w);
+        } else {
+            atomicAdd(dst, src[0]);
+        }
+    }
+}
+extern "C" int gspn_grouppoint(int b, int n, int c, int m, int nsample, const float* points, const int* idx, float* out, void* stream) {
+    if (b < 0 || n <= 0 || c <= 0 || m < 0 || nsample < 0) return GSPN_ERR_ARG;
+    const long rows = (long)b * m * nsample;
+    if (rows == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const bool v4 = (c % 4 == 0) && (((uintptr_t)points | (uintptr_t)out) % 16 == 0);
+    if (v4) {
+        const long total = rows * (c / 4);
+        hipLaunchKernelGGL(group_point_kernel<4>, dim3(grid_for(total, 256)), dim3(256), 0, st, total, n, c, m * nsample, points, idx, out);
+    } else {
+        const long total = rows * c;
+        hipLaunchKernelGGL(group_point_kernel<1>, dim3(grid_for(total, 256)), dim3(256), 0, st, total, n, c, m * nsample, points, idx, out);
+    }
+    return gspn_launch_status();
+}
+extern "C" int gspn_grouppoint_grad(int b, int n, int c, int m, int nsample, const float* grad_out, const int* idx, float* grad_points, void* stream) {
+    if (b < 0 || n <= 0 || c <= 0 || m < 0 || nsample < 0) return GSPN_ERR_ARG;
+    if (b == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(grad_points, 0, sizeof(float) * (size_t)b * n * c, st);     // tf_grouping.cpp:234
+    if (e != hipSuccess) return (int)e;
+    const long rows = (long)b * m * nsample;
+    if (rows == 0) return 0;
+    const bool v4 = (c % 4 == 0) && (((uintptr_t)grad_out) % 16 == 0);
+    if (v4) {
+        const long total = rows * (c / 4);
+        hipLaunchKernelGGL(group_point_grad_kernel<4>, dim3(grid_for(total, 256)), dim3(256), 0, st, total, n, c, m * nsample, grad_out, idx, grad_points);
+    } else {
+        const long total = rows * c;
+        hipLaunchKernelGGL(group_point_grad_kernel<1>, dim3(grid_for(total, 256)), dim3(256), 0, st, total, n, c, m * nsample, grad_out, idx, grad_points);
+    }
+    return gspn_launch_status();
+}
+
+// ============================================================================================
+// Fused tail of sample_and_group (utils/pointnet_util.py:41-52):
+//   out[row, :]  = [ xyz[idx]-new_xyz | points[idx] ]   (xyz_first)   or  [ points[idx] | xyz[idx]-new_xyz ]
+// written once, with row pitch ld_out (pad columns zeroed) so the MLP GEMM can read it directly.
+// The reference materialises grouped_xyz, a tiled new_xyz, grouped_points and the concat.
+// ============================================================================================
+__global__ void sa_group_concat_kernel(long total, int n, int c, int m, int nsample, const float* __restrict__ xyz, const float* __restrict__ new_xyz,
+                                       const float* __restrict__ points, const int* __restrict__ idx, int xyz_first, int ld, float* __restrict__ out) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long row = i / ld;
+        const int col = (int)(i - row * ld);
+        const long q = row / nsample;              // b*m + j
+        const long bi = q / m;
+        const int ii = idx[row];
+        float v = 0.f;
+        const int xc = xyz_first ? col : col - c;          // column inside the xyz part
+        const int fc = xyz_first ? col - 3 : col;          // column inside the feature part
+        if (xc >= 0 && xc < 3) v = xyz[((size_t)bi * n + ii) * 3 + xc] - new_xyz[q * 3 + xc];   // :41-42
+        else if (fc >= 0 && fc < c) v = points[((size_t)bi * n + ii) * c + fc];                  // :46
+        out[i] = v;
+    }
+}
+__global__ void sa_group_concat_grad_kernel(long total, int n, int c, int m_ns, const int* __restrict__ idx, int xyz_first, int ld,
+                                            const float* __restrict__ grad_out, float* __restrict__ grad_points) {
+    // total = rows*c : only the feature columns carry gradient to `points`
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long row = i / c;
+        const int fc = (int)(i - row * c);
+        const long bi = row / m_ns;
+        const int ii = idx[row];
+        const float g = grad_out[(size_t)row * ld + (xyz_first ? 3 + fc : fc)];
+        atomicAdd(grad_points + ((size_t)bi * n + ii) * c + fc, g);
+    }
+}
+extern "C" int gspn_sa_group_concat(int b, int n, int c, int m, int nsample, const float* xyz, const float* new_xyz, const float* points,
+                                    const int* idx, int xyz_first, int ld_out, float* out, void* stream) {
+    if (b < 0 || n <= 0 || c < 0 || m < 0 || nsample < 0 || ld_out < 3 + c) return GSPN_ERR_ARG;
+    if (c > 0 && !points) return GSPN_ERR_ARG;
+    const long total = (long)b * m * nsample * ld_out;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(sa_group_concat_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       total, n, c, m, nsample, xyz, new_xyz, points, idx, xyz_first, ld_out, out);
+    return gspn_launch_status();
+}
+extern "C" int gspn_sa_group_concat_grad(int b, int n, int c, int m, int nsample, const int* idx, int xyz_first, int ld_out,
+                                         const float* grad_out, float* grad_points, void* stream) {
+    if (b < 0 || n <= 0 || c <= 0 || m < 0 || nsample < 0 || ld_out < 3 + c) return GSPN_ERR_ARG;
+    if (b == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(grad_points, 0, sizeof(float) * (size_t)b * n * c, st);
+    if (e != hipSuccess) return (int)e;
+    const long total = (long)b * m * nsample * c;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(sa_group_concat_grad_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, total, n, c, m * nsample, idx, xyz_first, ld_out, grad_out, grad_points);
+    return gspn_launch_status();
+}
+
+// ============================================================================================
+// group_maxpool / grad  (tf_grouping_g.cu:88-134): fused gather + max over nsample.
+// init -10000, strict '>' (first maximum wins).  One thread per (query, channel): consecutive
+// lanes read consecutive channels of the same gathered row.
+// When no element exceeds -10000 the reference stores a stale index; this build stores the
+// first index of the group instead (documented divergence on an input the model never produces).
+// ============================================================================================
+__global__ void group_maxpool_kernel(long total, int n, int c, int m, int nsample, const float* __restrict__ points, const int* __restrict__ idx,
+                                     float* __restrict__ out, int* __restrict__ max_idx) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long q = i / c;                      // b*m + j
+        const int l = (int)(i - q * c);
+        const long bi = q / m;
+        const int* row = idx + q * nsample;
+        const float* P = points + (size_t)bi * n * c;
+        float best = -10000.0f;
+        int besti = row[0];
+        for (int k = 0; k < nsample; ++k) {
+            const int ii = row[k];
+            const float t = P[(size_t)ii * c + l];
+            if (t > best) { best = t; besti = ii; }
+        }
+        out[i] = best;
+        max_idx[i] = besti;
+    }
+}
+__global__ void group_maxpool_grad_kernel(long total, int n, int c, int m, const float* __restrict__ grad_out, const int* __restrict__ max_idx, float* __restrict__ grad_points) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long q = i / c;
+        const int l = (int)(i - q * c);
+        const long bi = q / m;
+        atomicAdd(grad_points + ((size_t)bi * n + max_idx[i]) * c + l, grad_out[i]);
+    }
+}
+extern "C" int gspn_groupmaxpool(int b, int n, int c, int m, int nsample, const float* points, const int* idx, float* out, int* max_idx, void* stream) {
+    if (b < 0 || n <= 0 || c <= 0 || m < 0 || nsample <= 0) return GSPN_ERR_ARG;
+    const long total = (long)b * m * c;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(group_maxpool_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, total, n, c, m, nsample, points, idx, out, max_idx);
+    return gspn_launch_status();
+}
+extern "C" int gspn_groupmaxpool_grad(int b, int n, int c, int m, const float* grad_out, const int* max_idx, float* grad_points, void* stream) {
+    if (b < 0 || n <= 0 || c <= 0 || m < 0) return GSPN_ERR_ARG;
+    if (b == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(grad_points, 0, sizeof(float) * (size_t)b * n * c, st);     // tf_grouping.cpp:307
+    if (e != hipSuccess) return (int)e;
+    const long total = (long)b * m * c;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(group_maxpool_grad_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, total, n, c, m, grad_out, max_idx, grad_points);
+    return gspn_launch_status();
+}
+
+// ============================================================================================
+// selection_sort (tf_grouping_g.cu:144-184): copy each (b,m) row of n distances, then a partial
+// selection sort of its first k slots, swapping values and indices; strict '<' so the lowest
+// POSITION wins ties (positions, not original indices: earlier swaps move elements).
+// The reference runs one thread per row; here one wave per row: the arg-min over the tail is a
+// strided scan + DPP/shuffle reduction on (value, position) keys, the swap is done by lane 0.
+// ============================================================================================
+__global__ __launch_bounds__(256) void selection_sort_kernel(long rows, int n, int k, const float* __restrict__ dist, int* __restrict__ outi, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const long r = blockIdx.x * 4L + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const float* src = dist + r * n;
+    float* p = out + r * n;
+    int* pi = outi + r * n;
+    for (int s = lane; s < n; s += 64) { p[s] = src[s]; pi[s] = s; }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    const int kk = k < n ? k : n;
+    for (int s = 0; s < kk; ++s) {
+        // arg-min over positions s..n-1, lowest position on ties (== the serial strict-'<' scan
+        // that starts with min=s)
+        float bv = INFINITY;
+        int bp = 0x7FFFFFFF;
+        bool have = false;
+        for (int t = s + lane; t < n; t += 64) {
+            const float v = p[t];
+            if (!have || v < bv) { bv = v; bp = t; have = true; }
+        }
+        // reduce (value, position); NaNs are not ordered by '<' in the reference either
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) {
+            const float ov = __shfl_xor(bv, sft, 64);
+            const int op = __shfl_xor(bp, sft, 64);
+            const int oh = __shfl_xor((int)have, sft, 64);
+            const bool take = oh && (!have || ov < bv || (ov == bv && op < bp));
+            if (take) { bv = ov; bp = op; have = true; }
+        }
+        if (lane == 0 && bp != s) {
+            const float tv = p[bp]; p[bp] = p[s]; p[s] = tv;
+            const int ti = pi[bp]; pi[bp] = pi[s]; pi[s] = ti;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+extern "C" int gspn_selectionsort(int b, int n, int m, int k, const float* dist, int* outi, float* out, void* stream) {
+    if (k <= 0) return GSPN_ERR_ARG;                                     // tf_grouping.cpp:143
+    if (b < 0 || n <= 0 || m < 0) return GSPN_ERR_ARG;
+    const long rows = (long)b * m;
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(selection_sort_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, rows, n, k, dist, outi, out);
+    return gspn_launch_status();
+}

@@ -1,0 +1,122 @@
+// interpolate.hip -- tf_ops/3d_interpolation on gfx950: three_nn, three_interpolate (+grad).
+// The reference has CPU kernels only (tf_interpolate.cpp:60-153; ops registered DEVICE_CPU
+// :187,222,262), so every FP module round-trips through the host.  These kernels keep the data
+// on the device and reproduce the host arithmetic: unfused fp32, left to right.
+#include <math.h>
+
+#include "common.h"
+
+// ============================================================================================
+// three_nn (tf_interpolate.cpp:60-103): for each dense point j the 3 smallest squared distances
+// to the m sparse points, strict '<' insertion cascade (ties keep ascending k), squared
+// distances returned.  One thread per dense point; the sparse cloud is staged through LDS in
+// tiles of float4 {x,y,z,-} so one ds_read_b128 (broadcast, conflict free) feeds a whole wave.
+// ============================================================================================
+#define NN_TILE 1024
+#define NN_BLOCK 256
+
+__global__ __launch_bounds__(NN_BLOCK) void three_nn_kernel(int b, int n, int m, const float* __restrict__ xyz1, const float* __restrict__ xyz2,
+                                                            float* __restrict__ dist, int* __restrict__ idx) {
+    __shared__ float4 tile[NN_TILE];
+    const int scene = blockIdx.x % b;               // scene <-> XCD affinity for the sparse cloud
+    const int j = (blockIdx.x / b) * NN_BLOCK + threadIdx.x;
+    const bool live = j < n;
+    float x1 = 0.f, y1 = 0.f, z1 = 0.f;
+    if (live) {
+        const float* q = xyz1 + ((size_t)scene * n + j) * 3;
+        x1 = q[0]; y1 = q[1]; z1 = q[2];
+    }
+    // double best=1e40 in the reference (:66): any finite float is smaller, +inf/NaN are not ->
+    // identical to a float +inf initialiser; (float)1e40 == +inf on output (:91-96)
+    float b1 = INFINITY, b2 = INFINITY, b3 = INFINITY;
+    int i1 = 0, i2 = 0, i3 = 0;
+    const float* sp = xyz2 + (size_t)scene * m * 3;
+    for (int k0 = 0; k0 < m; k0 += NN_TILE) {
+        const int cnt = min(NN_TILE, m - k0);
+        __syncthreads();
+        for (int t = threadIdx.x; t < cnt; t += NN_BLOCK)
+            tile[t] = make_float4(sp[(size_t)(k0 + t) * 3 + 0], sp[(size_t)(k0 + t) * 3 + 1], sp[(size_t)(k0 + t) * 3 + 2], 0.f);
+        __syncthreads();
+#pragma unroll 4
+        for (int k = 0; k < cnt; ++k) {
+            const float4 p = tile[k];
+            const float d = dist2_host(p.x - x1, p.y - y1, p.z - z1);        // :74
+            if (d < b3) {                                                   // rare after warm-up
+                const int kk = k0 + k;
+                if (d < b1) { b3 = b2; i3 = i2; b2 = b1; i2 = i1; b1 = d; i1 = kk; }
+                else if (d < b2) { b3 = b2; i3 = i2; b2 = d; i2 = kk; }
+                else { b3 = d; i3 = kk; }
+            }
+        }
+    }
+    if (live) {
+        float* od = dist + ((size_t)scene * n + j) * 3;
+        int* oi = idx + ((size_t)scene * n + j) * 3;
+        od[0] = b1; od[1] = b2; od[2] = b3;
+        oi[0] = i1; oi[1] = i2; oi[2] = i3;
+    }
+}
+extern "C" int gspn_threenn(int b, int n, int m, const float* xyz1, const float* xyz2, float* dist, int* idx, void* stream) {
+    if (b < 0 || n < 0 || m < 0) return GSPN_ERR_ARG;
+    if (b == 0 || n == 0) return 0;
+    const long long blocks = (long long)b * ((n + NN_BLOCK - 1) / NN_BLOCK);
+    if (blocks > 0x7FFFFFFFll) return GSPN_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(three_nn_kernel, dim3((unsigned)blocks), dim3(NN_BLOCK), 0, (hipStream_t)stream, b, n, m, xyz1, xyz2, dist, idx);
+    return gspn_launch_status();
+}
+
+// ============================================================================================
+// three_interpolate (tf_interpolate.cpp:107-127):  out[j,l] = p[i1,l]*w1 + p[i2,l]*w2 + p[i3,l]*w3
+// (each product rounded, summed left to right).  One thread per output element.
+// ============================================================================================
+__global__ void three_interpolate_kernel(long total, int m, int c, int n, const float* __restrict__ points, const int* __restrict__ idx,
+                                         const float* __restrict__ weight, float* __restrict__ out) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long row = i / c;                 // b*n + j
+        const int l = (int)(i - row * c);
+        const long bi = row / n;
+        const int* ii = idx + row * 3;
+        const float* w = weight + row * 3;
+        const float* P = points + (size_t)bi * m * c + l;
+        const float a = P[(size_t)ii[0] * c] * w[0];
+        const float bb = P[(size_t)ii[1] * c] * w[1];
+        const float cc = P[(size_t)ii[2] * c] * w[2];
+        out[i] = (a + bb) + cc;
+    }
+}
+// three_interpolate_grad (tf_interpolate.cpp:131-153): grad_points[i_t,l] += grad_out[j,l]*w_t.
+// The reference is a sequential CPU loop (deterministic order); this is a hardware-atomic scatter,
+// so sums agree to rounding, not bitwise.
+__global__ void three_interpolate_grad_kernel(long total, int n, int c, int m, const float* __restrict__ grad_out, const int* __restrict__ idx,
+                                              const float* __restrict__ weight, float* __restrict__ grad_points) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long row = i / c;
+        const int l = (int)(i - row * c);
+        const long bi = row / n;
+        const int* ii = idx + row * 3;
+        const float* w = weight + row * 3;
+        const float g = grad_out[i];
+        float* G = grad_points + (size_t)bi * m * c + l;
+        atomicAdd(G + (size_t)ii[0] * c, g * w[0]);
+        atomicAdd(G + (size_t)ii[1] * c, g * w[1]);
+        atomicAdd(G + (size_t)ii[2] * c, g * w[2]);
+    }
+}
+extern "C" int gspn_threeinterpolate(int b, int m, int c, int n, const float* points, const int* idx, const float* weight, float* out, void* stream) {
+    if (b < 0 || m <= 0 || c <= 0 || n < 0) return GSPN_ERR_ARG;
+    const long total = (long)b * n * c;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(three_interpolate_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, total, m, c, n, points, idx, weight, out);
+    return gspn_launch_status();
+}
+extern "C" int gspn_threeinterpolate_grad(int b, int n, int c, int m, const float* grad_out, const int* idx, const float* weight, float* grad_points, void* stream) {
+    if (b < 0 || m <= 0 || c <= 0 || n < 0) return GSPN_ERR_ARG;
+    if (b == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(grad_points, 0, sizeof(float) * (size_t)b * m * c, st);      // tf_interpolate.cpp:258
+    if (e != hipSuccess) return (int)e;
+    const long total = (long)b * n * c;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(three_interpolate_grad_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, total, n, c, m, grad_out, idx, weight, grad_points);
+    return gspn_launch_status();
+}

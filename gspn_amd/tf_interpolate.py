@@ -1,0 +1,61 @@
+"""Drop-in for tf_ops/3d_interpolation/tf_interpolate.py (CPU-only ops in the reference; on-device here)."""
+import torch
+
+from . import _lib as L
+
+
+def three_nn(xyz1, xyz2):
+    """tf_interpolate.py:8-18 -- xyz1 (b,n,3) unknown, xyz2 (b,m,3) known ->
+    dist (b,n,3) SQUARED distances, idx (b,n,3) int32.  Non-differentiable."""
+    xyz1 = L.need(xyz1.detach(), torch.float32, 3, "xyz1")
+    xyz2 = L.need(xyz2.detach(), torch.float32, 3, "xyz2")
+    if xyz1.shape[2] != 3:
+        raise ValueError("ThreeNN expects (b,n,3) xyz1 shape")                              # tf_interpolate.cpp:163
+    if xyz2.shape[2] != 3 or xyz2.shape[0] != xyz1.shape[0]:
+        raise ValueError("ThreeNN expects (b,m,3) xyz2 shape")                              # tf_interpolate.cpp:168
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    dist = torch.empty((b, n, 3), dtype=torch.float32, device=xyz1.device)
+    idx = torch.empty((b, n, 3), dtype=torch.int32, device=xyz1.device)
+    with torch.cuda.device(xyz1.device):
+        L.check(L.lib().gspn_threenn(b, n, m, L.ptr(xyz1), L.ptr(xyz2), L.ptr(dist), L.ptr(idx), L.stream()), "three_nn")
+    return dist, idx
+
+
+class _ThreeInterpolate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, points, idx, weight):
+        b, m, c = points.shape
+        n = idx.shape[1]
+        out = torch.empty((b, n, c), dtype=torch.float32, device=points.device)
+        with torch.cuda.device(points.device):
+            L.check(L.lib().gspn_threeinterpolate(b, m, c, n, L.ptr(points), L.ptr(idx), L.ptr(weight), L.ptr(out), L.stream()), "three_interpolate")
+        ctx.save_for_backward(idx, weight)
+        ctx.m = m
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        # tf_interpolate.py:29-34 -> [three_interpolate_grad(points, idx, weight, grad_out), None, None]
+        idx, weight = ctx.saved_tensors
+        grad_out = grad_out.contiguous()
+        b, n, c = grad_out.shape
+        g = torch.empty((b, ctx.m, c), dtype=torch.float32, device=grad_out.device)
+        with torch.cuda.device(grad_out.device):
+            L.check(L.lib().gspn_threeinterpolate_grad(b, n, c, ctx.m, L.ptr(grad_out), L.ptr(idx), L.ptr(weight), L.ptr(g), L.stream()),
+                    "three_interpolate_grad")
+        return g, None, None
+
+
+def three_interpolate(points, idx, weight):
+    """tf_interpolate.py:19-28 -- points (b,m,c), idx (b,n,3) int32, weight (b,n,3) -> (b,n,c).
+    Gradient flows to `points` only (no gradient to idx/weight, as in the reference)."""
+    points = L.need(points, torch.float32, 3, "points")
+    idx = L.need(idx, torch.int32, 3, "idx")
+    weight = L.need(weight.detach(), torch.float32, 3, "weight")
+    b = points.shape[0]
+    if idx.shape[0] != b or idx.shape[2] != 3:
+        raise ValueError("ThreeInterpolate expects (b,n,3) idx shape")                      # tf_interpolate.cpp:199
+    if tuple(weight.shape) != tuple(idx.shape):
+        raise ValueError("ThreeInterpolate expects (b,n,3) weight shape")                   # tf_interpolate.cpp:203
+    return _ThreeInterpolate.apply(points, idx, weight)

@@ -1,0 +1,184 @@
+/*
+ * gspn_hip.h -- C ABI of libgspn_hip.so: the MI355X (gfx950) implementation of the GSPN /
+ * PointNet++ set-abstraction hot path.
+ *
+ * Drop-in boundary.  Every entry point below replaces one C launcher (or CPU loop) that the
+ * reference's TensorFlow OpKernels call; the scalar and pointer order is the reference
+ * launcher's, followed by one extra `void* stream` (a hipStream_t; NULL = the null stream).
+ * The reference launchers go to the legacy default stream and return void
+ * (tf_ops/sampling/tf_sampling_g.cu:194-211); here every call is stream-ordered and returns
+ *      0                      success
+ *      GSPN_ERR_ARG  (-1)     a size/attribute the reference OP_REQUIRES would reject
+ *      GSPN_ERR_UNSUPPORTED   (-2)  valid input outside what this build supports
+ *      > 0                    a hipError_t from the launch
+ * Nothing throws across the ABI.  No entry point allocates or frees device memory: the caller
+ * owns every buffer (as TF's allocate_output/allocate_temp do in the reference).  Gradient
+ * entry points zero their output themselves (stream-ordered), replacing the reference's
+ * cudaMemset calls (tf_sampling.cpp:174, tf_grouping.cpp:234,307, tf_nndistance_g.cu:153-154).
+ * All pointers are device pointers; tensors are dense row-major float32 / int32.
+ * Thread safety: the library holds no mutable global state.
+ */
+#ifndef GSPN_HIP_H
+#define GSPN_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSPN_ERR_ARG (-1)
+#define GSPN_ERR_UNSUPPORTED (-2)
+
+/* Build facts: squared-distance contraction policy (see oracle/gspn_oracle.c header) and ABI rev. */
+int gspn_dist_policy(void);
+int gspn_abi_version(void);
+
+/* ---------------- tf_ops/sampling ---------------------------------------------------- */
+
+/* farthestpointsamplingLauncher(b,n,m,inp,temp,out)  tf_sampling.cpp:94, tf_sampling_g.cu:203-205.
+ * inp (b,n,3) f32 -> out (b,m) i32.  temp: scratch of min(b,32)*n floats, used only when
+ * n > GSPN_FPS_RESIDENT_MAX (the on-chip kernel needs none; may be NULL below that). */
+#define GSPN_FPS_RESIDENT_MAX 32768
+int gspn_farthestpointsampling(int b, int n, int m, const float* inp, float* temp, int* out, void* stream);
+
+/* gatherpointLauncher(b,n,m,inp,idx,out)  tf_sampling.cpp:125, tf_sampling_g.cu:206-208 */
+int gspn_gatherpoint(int b, int n, int m, const float* inp, const int* idx, float* out, void* stream);
+
+/* scatteraddpointLauncher(b,n,m,out_g,idx,inp_g)  tf_sampling.cpp:150, tf_sampling_g.cu:209-211.
+ * inp_g (b,n,3) is zeroed here first. */
+int gspn_scatteraddpoint(int b, int n, int m, const float* out_g, const int* idx, float* inp_g, void* stream);
+
+/* probsampleLauncher(b,n,m,inp_p,inp_r,temp,out)  tf_sampling.cpp:65, tf_sampling_g.cu:198-201.
+ * temp: (b,n) floats (the cumulative sums). */
+int gspn_probsample(int b, int n, int m, const float* inp_p, const float* inp_r, float* temp, int* out, void* stream);
+
+/* ---------------- tf_ops/grouping ---------------------------------------------------- */
+
+/* queryBallPointLauncher(b,n,m,radius,nsample,xyz1,xyz2,idx,pts_cnt)  tf_grouping.cpp:96,
+ * tf_grouping_g.cu:186-189.  Rows without any hit are zero-filled (uninitialised in the reference). */
+int gspn_queryballpoint(int b, int n, int m, float radius, int nsample, const float* xyz1, const float* xyz2,
+                        int* idx, int* pts_cnt, void* stream);
+
+/* selectionSortLauncher(b,n,m,k,dist,outi,out)  tf_grouping.cpp:138, tf_grouping_g.cu:190-193 */
+int gspn_selectionsort(int b, int n, int m, int k, const float* dist, int* outi, float* out, void* stream);
+
+/* Direct k-NN replacing tf_grouping.py:71-96 (dense (b,m,n) matrix + selection sort):
+ * xyz1 (b,n,3) data, xyz2 (b,m,3) queries -> val (b,m,k) squared distances, idx (b,m,k); same
+ * arithmetic ((x1-x2)^2 summed x,y,z) and tie rule (lowest index first). k <= 64. */
+int gspn_knnpoint(int b, int n, int m, int k, const float* xyz1, const float* xyz2, float* val, int* idx, void* stream);
+
+/* groupPointLauncher(b,n,c,m,nsample,points,idx,out)  tf_grouping.cpp:172, tf_grouping_g.cu:194-197 */
+int gspn_grouppoint(int b, int n, int c, int m, int nsample, const float* points, const int* idx, float* out, void* stream);
+
+/* groupPointGradLauncher(b,n,c,m,nsample,grad_out,idx,grad_points)  tf_grouping.cpp:203,
+ * tf_grouping_g.cu:198-202.  grad_points (b,n,c) is zeroed here first. */
+int gspn_grouppoint_grad(int b, int n, int c, int m, int nsample, const float* grad_out, const int* idx, float* grad_points, void* stream);
+
+/* groupMaxpoolLauncher / groupMaxpoolGradLauncher  tf_grouping.cpp:241,277, tf_grouping_g.cu:203-210 */
+int gspn_groupmaxpool(int b, int n, int c, int m, int nsample, const float* points, const int* idx, float* out, int* max_idx, void* stream);
+int gspn_groupmaxpool_grad(int b, int n, int c, int m, const float* grad_out, const int* max_idx, float* grad_points, void* stream);
+
+/* ---------------- tf_ops/3d_interpolation (CPU-only in the reference) ----------------- */
+
+/* threenn_cpu(b,n,m,xyz1,xyz2,dist,idx)  tf_interpolate.cpp:60-103 */
+int gspn_threenn(int b, int n, int m, const float* xyz1, const float* xyz2, float* dist, int* idx, void* stream);
+/* threeinterpolate_cpu(b,m,c,n,points,idx,weight,out)  tf_interpolate.cpp:107-127 */
+int gspn_threeinterpolate(int b, int m, int c, int n, const float* points, const int* idx, const float* weight, float* out, void* stream);
+/* threeinterpolate_grad_cpu(b,n,c,m,grad_out,idx,weight,grad_points)  tf_interpolate.cpp:131-153;
+ * grad_points (b,m,c) is zeroed here first. */
+int gspn_threeinterpolate_grad(int b, int n, int c, int m, const float* grad_out, const int* idx, const float* weight, float* grad_points, void* stream);
+
+/* ---------------- tf_ops/nn_distance -------------------------------------------------- */
+
+/* NmDistanceKernelLauncher(b,n,xyz,m,xyz2,result,result_i,result2,result2_i)  tf_nndistance.cpp:168,
+ * tf_nndistance_g.cu:128-131 */
+int gspn_nmdistance(int b, int n, const float* xyz, int m, const float* xyz2, float* result, int* result_i,
+                    float* result2, int* result2_i, void* stream);
+/* NmDistanceGradKernelLauncher(...)  tf_nndistance.cpp:208, tf_nndistance_g.cu:152-157;
+ * both gradients are zeroed here first. */
+int gspn_nmdistance_grad(int b, int n, const float* xyz1, int m, const float* xyz2, const float* grad_dist1, const int* idx1,
+                         const float* grad_dist2, const int* idx2, float* grad_xyz1, float* grad_xyz2, void* stream);
+
+/* ---------------- utils/pointnet_util.py composition helpers --------------------------- */
+
+/* sample_and_group's tail in one pass (pointnet_util.py:41-52): out (b,m,ns,cx+c) where the cx=3
+ * xyz channels are xyz[idx]-new_xyz (:41-42) and the c feature channels are points[idx] (:46);
+ * xyz_first=1 gives concat([grouped_xyz, grouped_points]) (:48), 0 gives the features-first order
+ * of models/model_rpointnet.py:61.  points may be NULL (c=0).  ld_out >= 3+c is the row pitch
+ * of out in floats (rows may be padded for the MLP kernels; pad columns are written as 0). */
+int gspn_sa_group_concat(int b, int n, int c, int m, int nsample, const float* xyz, const float* new_xyz, const float* points,
+                         const int* idx, int xyz_first, int ld_out, float* out, void* stream);
+/* gradient of the above w.r.t. points: grad_points (b,n,c) += grad_out[..., feature channels];
+ * zeroed here first. */
+int gspn_sa_group_concat_grad(int b, int n, int c, int m, int nsample, const int* idx, int xyz_first, int ld_out,
+                              const float* grad_out, float* grad_points, void* stream);
+
+/* ---------------- utils/tf_util.py conv2d 1x1 (+bias +BN +ReLU) : the shared MLP ------- */
+/* The reference delegates this arithmetic to TensorFlow (tf_util.py:120-185, 515-534).
+ * One layer is   y = x.W + bias ;  z = relu(gamma*(y-mean)*rsqrt(var+eps)+beta)
+ * over `rows` = b*m*nsample rows.  The kernels are fp32 MFMA GEMMs with the element-wise work
+ * fused into the operand load (prologue) / the accumulator store (epilogue).
+ *
+ * gspn_mlp_fwd:  Y(rows,ldy) = act(X)(rows,ldx)[:, :cin] . W(cin,cout) + bias
+ *   act(X) = X                           if in_scale == NULL
+ *          = relu(X*in_scale+in_shift)   otherwise (per input channel; the previous layer's BN+ReLU)
+ *   stats (2*cout floats, may be NULL): column sums of Y and Y^2 are ATOMICALLY ADDED; the caller
+ *   zeroes it (gspn_fill_zero) -- they feed training-mode BN.
+ */
+int gspn_mlp_fwd(long rows, int cin, int cout, const float* X, int ldx, const float* in_scale, const float* in_shift,
+                 const float* W, const float* bias, float* Y, int ldy, float* stats, void* stream);
+
+/* BN finalize: from stats (sum, sumsq) over `rows` rows produce scale/shift (2*c each), the batch
+ * mean / biased variance (saved for backward) and update the moving averages in place
+ * (moving = moving*decay + batch*(1-decay), tf.contrib.layers.batch_norm semantics; the moving
+ * variance uses the biased batch variance).  When is_training==0, scale/shift come from the
+ * moving statistics and nothing is updated. */
+int gspn_bn_finalize(long rows, int c, const float* stats, const float* gamma, const float* beta, float eps, float decay,
+                     int is_training, float* moving_mean, float* moving_var, float* mean, float* var,
+                     float* scale, float* shift, void* stream);
+
+/* out(groups,c) = max over the ns rows of each group of relu(Y*scale+shift); arg (groups,c) gets the
+ * row offset (0..ns-1) of the first maximum.  scale==NULL: plain max of Y. */
+int gspn_bnrelu_maxpool(long groups, int ns, int c, const float* Y, int ldy, const float* scale, const float* shift,
+                        float* out, int* arg, void* stream);
+/* z = relu(Y*scale+shift) materialised (used after the last layer of an FP module) */
+int gspn_bnrelu_apply(long rows, int c, const float* Y, int ldy, const float* scale, const float* shift, float* out, int ldo, void* stream);
+
+/* Backward of one layer.  Given dZ (the gradient w.r.t. z = relu(bn(y))) this computes
+ *   dY = BN-backward(relu-backward(dZ))          (training-mode batch statistics)
+ * in two passes.  Pass 1 (gspn_bn_bwd_reduce) accumulates per channel
+ *   red[0:c]  = sum(dZ*[z>0]),  red[c:2c] = sum(dZ*[z>0]*xhat)      (atomically; caller zeroes)
+ * where dZ is either a dense (rows,ldz) tensor or, when pool_arg != NULL, the scatter of a
+ * pooled gradient dPool(groups,c) to its arg-max rows.  Pass 2 is fused into the two GEMMs:
+ *   gspn_mlp_bwd_data :  dX(rows,ldx)[:, :cin] = dY . W^T
+ *   gspn_mlp_bwd_weight: dW(cin,cout) += act(X)^T . dY ,  dbias += colsum(dY)   (atomic; caller zeroes)
+ * both of which recompute dY on the fly from (Y, dZ|dPool+arg, mean, var, gamma, red).
+ */
+typedef struct gspn_bn_bwd_args {
+    const float* Y;        /* (rows, ldy) pre-BN output of this layer (saved from forward) */
+    int ldy;
+    const float* dZ;       /* dense upstream gradient (rows, ldz), or NULL when pooled */
+    int ldz;
+    const float* dPool;    /* pooled upstream gradient (rows/ns, c), or NULL */
+    const int* pool_arg;   /* (rows/ns, c) arg-max row offsets from gspn_bnrelu_maxpool */
+    int ns;
+    const float* mean;     /* c : batch mean */
+    const float* var;      /* c : biased batch variance */
+    const float* gamma;    /* c */
+    const float* beta;     /* c */
+    float eps;
+    const float* red;      /* 2c: output of gspn_bn_bwd_reduce */
+    int use_bn;            /* 0: layer without BN (y -> relu only); mean/var/gamma/red ignored */
+    int is_training;       /* 0: BN used moving statistics (constant w.r.t. the batch) */
+} gspn_bn_bwd_args;
+
+int gspn_bn_bwd_reduce(long rows, int c, const gspn_bn_bwd_args* a, float* red, float* dgamma, float* dbeta, void* stream);
+int gspn_mlp_bwd_data(long rows, int cin, int cout, const gspn_bn_bwd_args* a, const float* W, float* dX, int ldx, void* stream);
+int gspn_mlp_bwd_weight(long rows, int cin, int cout, const gspn_bn_bwd_args* a, const float* X, int ldx,
+                        const float* in_scale, const float* in_shift, float* dW, float* dbias, void* stream);
+
+int gspn_fill_zero(void* ptr, long bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

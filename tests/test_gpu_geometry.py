@@ -1,0 +1,207 @@
+"""GPU parity: HIP kernels (through the C ABI) vs the CPU oracle on identical seeded inputs.
+Index outputs must match bit-exactly; scatter-add gradients within fp32 rounding."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from tests import data as D
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("kind,b,n,m", [
+    ("U", 1, 4096, 512),      # BASELINE config 1
+    ("U", 3, 512, 128), ("U", 2, 300, 64), ("U", 2, 1000, 333), ("U", 2, 2048, 512),
+    ("D", 2, 4096, 1024), ("D", 2, 8192, 256), ("U", 2, 16384, 128), ("D", 1, 20000, 300),
+    ("U", 2, 32768, 64), ("D", 1, 32768, 600), ("S", 1, 6000, 700),
+    ("U", 1, 7, 7), ("U", 1, 5, 9), ("U", 2, 1, 3), ("U", 40, 600, 16),
+])
+def test_fps_matches_oracle(kind, b, n, m):
+    from gspn_amd.tf_sampling import farthest_point_sample
+    xyz = D.batch(kind, b, n)
+    ref = O.farthest_point_sample(m, xyz)
+    got = farthest_point_sample(m, dev(xyz)).cpu().numpy()
+    assert got.dtype == np.int32 and got.shape == (b, m)
+    np.testing.assert_array_equal(got, ref)
+
+
+def test_fps_streaming_large_n():
+    from gspn_amd.tf_sampling import farthest_point_sample
+    xyz = D.batch("D", 2, 40000)
+    ref = O.farthest_point_sample(200, xyz)
+    got = farthest_point_sample(200, dev(xyz)).cpu().numpy()
+    np.testing.assert_array_equal(got, ref)
+
+
+def test_fps_all_points_identical():
+    from gspn_amd.tf_sampling import farthest_point_sample
+    xyz = np.ones((2, 1500, 3), np.float32) * 0.25
+    ref = O.farthest_point_sample(20, xyz)
+    got = farthest_point_sample(20, dev(xyz)).cpu().numpy()
+    np.testing.assert_array_equal(got, ref)
+    assert (got == 0).all()
+
+
+@pytest.mark.parametrize("kind,b,n,m,r,ns", [
+    ("U", 1, 4096, 512, 0.2, 32),     # BASELINE config 1
+    ("U", 2, 8192, 256, 0.1, 32), ("D", 2, 4096, 300, 0.15, 64), ("U", 2, 2048, 512, 0.4, 32),
+    ("U", 2, 1000, 77, 0.05, 16), ("U", 1, 5000, 128, 1.5, 512), ("U", 2, 300, 300, 1e-3, 8),
+    ("S", 1, 6000, 256, 0.4, 32), ("U", 1, 33, 5, 0.5, 100),
+])
+def test_ball_query_matches_oracle(kind, b, n, m, r, ns):
+    from gspn_amd.tf_grouping import query_ball_point
+    xyz = D.batch(kind, b, n)
+    q = O.gather_point(xyz, O.farthest_point_sample(m, xyz))
+    ridx, rcnt = O.query_ball_point(r, ns, xyz, q)
+    idx, cnt = query_ball_point(r, ns, dev(xyz), dev(q))
+    np.testing.assert_array_equal(cnt.cpu().numpy(), rcnt)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ridx)
+
+
+def test_ball_query_no_hit_rows_zero_filled():
+    from gspn_amd.tf_grouping import query_ball_point
+    xyz = D.batch("U", 1, 500)
+    q = (xyz[:, :10] + 10.0).astype(np.float32)
+    idx, cnt = query_ball_point(0.1, 16, dev(xyz), dev(q))
+    assert (cnt.cpu().numpy() == 0).all() and (idx.cpu().numpy() == 0).all()
+
+
+def test_ball_query_radius_boundary():
+    """hit test is sqrtf(d2) < radius, not d2 < radius^2: probe radii at exact distances"""
+    from gspn_amd.tf_grouping import query_ball_point
+    xyz = D.batch("U", 1, 2048)
+    q = xyz[:, :4].copy()
+    d = np.sqrt(((xyz[0][None] - q[0][:, None]).astype(np.float64) ** 2).sum(-1))
+    for r in [float(np.float32(d[0, 100])), float(np.float32(d[1, 7])), float(np.nextafter(np.float32(d[2, 900]), np.float32(1)))]:
+        ridx, rcnt = O.query_ball_point(r, 2048, xyz, q)
+        idx, cnt = query_ball_point(r, 2048, dev(xyz), dev(q))
+        np.testing.assert_array_equal(cnt.cpu().numpy(), rcnt)
+        np.testing.assert_array_equal(idx.cpu().numpy(), ridx)
+
+
+@pytest.mark.parametrize("c", [3, 6, 64, 67])
+def test_group_point_and_grad(c):
+    from gspn_amd.tf_grouping import group_point
+    rng = np.random.default_rng(5)
+    b, n, m, ns = 2, 1024, 128, 16
+    pts = rng.standard_normal((b, n, c)).astype(np.float32)
+    idx = rng.integers(0, n, size=(b, m, ns)).astype(np.int32)
+    idx[:, :, 8:] = idx[:, :, :1]           # padded rows repeat one index (atomic contention)
+    p = dev(pts).requires_grad_(True)
+    out = group_point(p, dev(idx))
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), O.group_point(pts, idx))
+    go = rng.standard_normal(out.shape).astype(np.float32)
+    out.backward(dev(go))
+    np.testing.assert_allclose(p.grad.cpu().numpy(), O.group_point_grad(pts, idx, go), rtol=1e-5, atol=1e-5)
+
+
+def test_gather_point_and_grad():
+    from gspn_amd.tf_sampling import gather_point
+    rng = np.random.default_rng(6)
+    b, n, m = 3, 2000, 500
+    xyz = rng.standard_normal((b, n, 3)).astype(np.float32)
+    idx = rng.integers(0, n, size=(b, m)).astype(np.int32)
+    x = dev(xyz).requires_grad_(True)
+    out = gather_point(x, dev(idx))
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), O.gather_point(xyz, idx))
+    go = rng.standard_normal(out.shape).astype(np.float32)
+    out.backward(dev(go))
+    np.testing.assert_allclose(x.grad.cpu().numpy(), O.gather_point_grad(xyz, idx, go), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("b,n,m", [(2, 2048, 512), (1, 1000, 2), (2, 700, 1500), (1, 50, 1), (1, 300, 3)])
+def test_three_nn_matches_oracle(b, n, m):
+    from gspn_amd.tf_interpolate import three_nn
+    dense = D.batch("D", b, n, 10)
+    sparse = D.batch("D", b, m, 50)
+    rd, ri = O.three_nn(dense, sparse)
+    d, i = three_nn(dev(dense), dev(sparse))
+    np.testing.assert_array_equal(i.cpu().numpy(), ri)
+    np.testing.assert_array_equal(d.cpu().numpy(), rd)
+
+
+@pytest.mark.parametrize("c", [1, 16, 64, 131])
+def test_three_interpolate_and_grad(c):
+    from gspn_amd.tf_interpolate import three_interpolate
+    rng = np.random.default_rng(7)
+    b, n, m = 2, 900, 128
+    pts = rng.standard_normal((b, m, c)).astype(np.float32)
+    idx = rng.integers(0, m, size=(b, n, 3)).astype(np.int32)
+    w = rng.random((b, n, 3)).astype(np.float32)
+    w /= w.sum(-1, keepdims=True)
+    p = dev(pts).requires_grad_(True)
+    out = three_interpolate(p, dev(idx), dev(w))
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), O.three_interpolate(pts, idx, w))   # same op order -> bitwise
+    go = rng.standard_normal(out.shape).astype(np.float32)
+    out.backward(dev(go))
+    np.testing.assert_allclose(p.grad.cpu().numpy(), O.three_interpolate_grad(pts, idx, w, go), rtol=1e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("b,n,m", [(4, 512, 512), (2, 1500, 700), (3, 100, 2500), (1, 1, 1)])
+def test_nn_distance_and_grad(b, n, m):
+    from gspn_amd.tf_nndistance import nn_distance
+    a = D.batch("D", b, n, 3)
+    c = D.batch("D", b, m, 30)
+    rd1, ri1, rd2, ri2 = O.nn_distance(a, c)
+    ta, tc = dev(a).requires_grad_(True), dev(c).requires_grad_(True)
+    d1, i1, d2, i2 = nn_distance(ta, tc)
+    np.testing.assert_array_equal(i1.cpu().numpy(), ri1)
+    np.testing.assert_array_equal(i2.cpu().numpy(), ri2)
+    np.testing.assert_array_equal(d1.detach().cpu().numpy(), rd1)
+    np.testing.assert_array_equal(d2.detach().cpu().numpy(), rd2)
+    rng = np.random.default_rng(8)
+    g1 = rng.standard_normal(rd1.shape).astype(np.float32)
+    g2 = rng.standard_normal(rd2.shape).astype(np.float32)
+    (d1 * dev(g1)).sum().add((d2 * dev(g2)).sum()).backward()
+    rg1, rg2 = O.nn_distance_grad(a, c, g1, ri1, g2, ri2)
+    np.testing.assert_allclose(ta.grad.cpu().numpy(), rg1, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(tc.grad.cpu().numpy(), rg2, rtol=1e-5, atol=1e-5)
+
+
+def test_group_maxpool_and_selection_sort():
+    from gspn_amd.tf_grouping import group_maxpool, select_top_k, knn_point
+    rng = np.random.default_rng(9)
+    b, n, m, ns, c = 2, 600, 70, 12, 10
+    pts = rng.standard_normal((b, n, c)).astype(np.float32)
+    idx = rng.integers(0, n, size=(b, m, ns)).astype(np.int32)
+    p = dev(pts).requires_grad_(True)
+    out, mi = group_maxpool(p, dev(idx))
+    ro, rmi = O.group_maxpool(pts, idx)
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), ro)
+    np.testing.assert_array_equal(mi.cpu().numpy(), rmi)
+    go = rng.standard_normal(ro.shape).astype(np.float32)
+    out.backward(dev(go))
+    np.testing.assert_allclose(p.grad.cpu().numpy(), O.group_maxpool_grad(pts, rmi, go), rtol=1e-5, atol=1e-5)
+    dist = rng.integers(0, 20, size=(2, 9, 150)).astype(np.float32)    # many ties
+    oi, od = select_top_k(17, dev(dist))
+    roi, rod = O.select_top_k(17, dist)
+    np.testing.assert_array_equal(oi.cpu().numpy(), roi)
+    np.testing.assert_array_equal(od.cpu().numpy(), rod)
+    x1 = D.batch("D", 2, 400, 1)
+    x2 = D.batch("D", 2, 30, 2)
+    v, i = knn_point(8, dev(x1), dev(x2))
+    rv, ri = O.knn_point(8, x1, x2)
+    np.testing.assert_array_equal(i.cpu().numpy(), ri)
+    np.testing.assert_array_equal(v.cpu().numpy(), rv)
+
+
+def test_prob_sample():
+    from gspn_amd.tf_sampling import prob_sample
+    rng = np.random.default_rng(11)
+    for (b, n, m) in [(3, 1000, 64), (2, 20000, 500), (1, 5, 9)]:
+        w = rng.random((b, n)).astype(np.float32)
+        r = rng.random((b, m)).astype(np.float32)
+        got = prob_sample(dev(w), dev(r)).cpu().numpy()
+        np.testing.assert_array_equal(got, O.prob_sample(w, r))
+
+
+def test_cpu_tensor_is_rejected_loudly():
+    from gspn_amd import _lib
+    from gspn_amd.tf_sampling import farthest_point_sample
+    with pytest.raises(_lib.GspnHipError):
+        farthest_point_sample(4, torch.zeros(1, 16, 3))
