@@ -5,28 +5,41 @@
 // ============================================================================================
 // Farthest point sampling (reference: tf_sampling_g.cu:105-170)
 //
-// The reference is m-1 strictly serial rounds of {update min-dist of all n points, arg-max}.
+// The reference is m-1 strictly serial rounds of {update the min-dist of all n points, arg-max}.
 // It re-reads xyz + the min-dist scratch from L2/global every round (20 B/point/round) and
 // spends 10 block barriers per round.  On MI355X a whole 32768-point scene fits ON CHIP in one
-// CU, so the resident kernel below keeps it there for all rounds:
+// CU, so the resident kernel keeps it there for all rounds (zero HBM/L2 traffic in the loop):
 //
-//   * one 512-thread workgroup (8 waves, 2 per SIMD) per scene; thread t owns the points
-//     k = p*512 + t, p = 0..P-1  -- exactly the reference's per-thread stride (:130), so the
-//     reference tie order (d desc, k mod 512 asc, k asc) becomes (d desc, t asc, p asc);
+//   * one 1024-thread workgroup (16 waves, 4 per SIMD) per scene.  Measured on gfx950
+//     (tools/valu_probe.hip): one wave issues at most one VALU op per ~5 cycles, a SIMD reaches
+//     ~1.27 cycles/op only with 4 waves, and v_pk_*_f32 costs the same issue slot as a scalar
+//     op -- hence 16 waves and packed-fp32 math (two points per instruction);
+//   * thread t = 2*rho + half owns the points k = (half*P + p)*512 + rho, p = 0..P-1: all of
+//     one residue class k mod 512 sits in two adjacent lanes in ascending k, so the reference
+//     tie order (d desc, k mod 512 asc, k asc) is simply (d desc, t asc, p asc);
 //   * x, y and the running min-dist live in VGPRs (3*P registers); z lives in VGPRs too for
-//     P <= 32 and in LDS (128 KiB, read-only, ds_read_b128) for P = 64, which is what lets
-//     32768 points fit: 384 KiB of registers + 128 KiB of LDS, no HBM/L2 traffic in the loop;
+//     P <= 16 and in LDS (128 KiB, read-only, ds_read_b128) for P = 32, which is what lets
+//     32768 points fit: 384 KiB of registers + 128 KiB of LDS;
 //   * arg-max = integer max on the float bit patterns (all candidates are >= +0, padding is
-//     -1.0f, so signed-int order == float order): DPP row reductions inside a wave, one LDS
-//     hop across the 8 waves, 2 workgroup barriers per round;
-//   * the index of the maximum is NOT tracked in the hot loop (that would cost 2 more VALU per
-//     point); only the winning wave resolves it afterwards, helped by per-8-point group maxima
-//     that the max3 tree produces for free.
+//     -1.0f, so signed-int order == float order): DPP row reductions inside a wave, one LDS hop
+//     across the 16 waves, ONE workgroup barrier per round (double-buffered candidates);
+//   * the slot of the maximum is NOT tracked in the hot loop (2 more VALU per point); each wave
+//     resolves it afterwards for its best lane only, through per-8-point group maxima that the
+//     max3 tree yields for free, wave-uniform switches and v_readlane.
 // ============================================================================================
 
-#define FPS_T 512
+#define FPS_T 1024
+#define FPS_W (FPS_T / 64)
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 #define NEG_ONE_BITS ((int)0xBF800000)
+#ifdef FPS_PROFILE
+__device__ long long g_fps_prof[8];
+__device__ long long g_fps_tl[16 * 8];
+#define FPS_TICK(i) do { const long long _n = clock64(); prof[i] += _n - tprev; tprev = _n; if (j == 100 && blockIdx.x == 0 && lane == 0) g_fps_tl[wave * 8 + i] = _n; } while (0)
+#else
+#define FPS_TICK(i) do {} while (0)
+#endif
 
 template <int P>
 struct FpsGroup {
@@ -34,30 +47,39 @@ struct FpsGroup {
     static constexpr int NG = P / G;
 };
 
+__device__ __forceinline__ int vmax3_i32(int a, int b, int c) {
+    int r;
+    asm("v_max3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// P = points per thread (even), ZLDS = z plane in LDS instead of VGPRs
 template <int P, bool ZLDS>
 __global__ __launch_bounds__(FPS_T) void fps_resident_kernel(int n, int m, const float* __restrict__ inp, int* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // [0,64)  : per-wave candidates, int2 {max bits, lane}
-    // [64,80) : winner record int4 {k, x, y, z}
-    // [128,..): z plane, float4 [P/4][512]   (ZLDS only)
-    int2* s_wave = reinterpret_cast<int2*>(smem);
-    int4* s_ctr = reinterpret_cast<int4*>(smem + 64);
-    v4f* s_z = reinterpret_cast<v4f*>(smem + 128);
+    // [0,512)    : candidates, 2 buffers x 16 waves x int4 {max bits, x, y, z}
+    // [512,640)  : candidate indices, 2 buffers x 16 waves x int
+    // [1024,..)  : z plane, float4 [P/4][1024]   (ZLDS only)
+    int4* s_cand = reinterpret_cast<int4*>(smem);
+    int* s_k = reinterpret_cast<int*>(smem + 512);
+    v4f* s_z = reinterpret_cast<v4f*>(smem + 1024);
 
     constexpr int G = FpsGroup<P>::G;
     constexpr int NG = FpsGroup<P>::NG;
+    static_assert(P % 2 == 0 && (!ZLDS || P % 4 == 0), "P must be even (multiple of 4 with ZLDS)");
 
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = t >> 6;
+    const int rho = t >> 1;                       // residue class k mod 512 of this thread
+    const int kbase = (t & 1) * P * 512 + rho;    // slot p holds point kbase + p*512
     const float* xyz = inp + (size_t)blockIdx.x * n * 3;
     int* o = out + (size_t)blockIdx.x * m;
 
-    float x[P], y[P], z[ZLDS ? 1 : P];
-    float td[P];
+    v2f x[P / 2], y[P / 2], z[ZLDS ? 1 : P / 2], td[P / 2];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-        const int k = p * FPS_T + t;
+        const int k = kbase + p * 512;
         float px = 0.f, py = 0.f, pz = 0.f;
         float d0 = -1.0f;                         // padding never wins (real candidates are >= 0)
         if (k < n) {
@@ -66,47 +88,54 @@ __global__ __launch_bounds__(FPS_T) void fps_resident_kernel(int n, int m, const
             pz = xyz[k * 3 + 2];
             d0 = 1e38f;                           // :117-119
         }
-        // detach x/y from the dwordx2/x3 load tuple so the allocator may place them independently
+        // detach x/y/z from the dwordx3 load tuple so the allocator may place them independently
         asm volatile("" : "+v"(px), "+v"(py), "+v"(pz));
-        x[p] = px;
-        y[p] = py;
-        td[p] = d0;
+        x[p >> 1][p & 1] = px;
+        y[p >> 1][p & 1] = py;
+        td[p >> 1][p & 1] = d0;
         if (ZLDS) reinterpret_cast<float*>(s_z)[((p >> 2) * FPS_T + t) * 4 + (p & 3)] = pz;
-        else z[p] = pz;
+        else z[p >> 1][p & 1] = pz;
     }
     if (t == 0) o[0] = 0;                          // :114-116
     float cx = xyz[0], cy = xyz[1], cz = xyz[2];   // centre of round 1 = point 0
     __syncthreads();
 
+#ifdef FPS_PROFILE
+    long long prof[5] = {0, 0, 0, 0, 0};
+    long long tprev = clock64();
+#endif
     for (int j = 1; j < m; ++j) {
-        // ---- update + per-group maxima (value only) ----
+        // ---- update min-dist + per-group maxima (value only) ----
         int g[NG];
 #pragma unroll
         for (int q = 0; q < NG; ++q) {
             int gm = NEG_ONE_BITS;
-            if constexpr (ZLDS) {
+            v2f zhold = {0.f, 0.f};
 #pragma unroll
-                for (int h = 0; h < G / 4; ++h) {
-                    // one ds_read_b128 serves 4 consecutive p; the empty asm keeps the compiler from
-                    // narrowing it back into four scalar LDS reads
-                    v4f zz = s_z[((q * G) / 4 + h) * FPS_T + t];
-                    asm("" : "+v"(zz));
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int p = q * G + h * 4 + e;
-                        const float d = dist2_cuda(x[p] - cx, y[p] - cy, zz[e] - cz);   // :142
-                        td[p] = vmin_f32(d, td[p]);                                     // :143
-                        gm = max(gm, __float_as_int(td[p]));
+            for (int h = 0; h < G / 2; ++h) {
+                const int pp = (q * G) / 2 + h;            // pair index
+                v2f zz;
+                if constexpr (ZLDS) {
+                    // one ds_read_b128 serves 4 consecutive slots; the empty asm keeps the compiler
+                    // from narrowing it back into scalar LDS reads
+                    if ((h & 1) == 0) {
+                        v4f z4 = s_z[(pp >> 1) * FPS_T + t];
+                        asm("" : "+v"(z4));
+                        zz = z4.xy;
+                        zhold = z4.zw;
+                    } else {
+                        zz = zhold;
                     }
+                } else {
+                    zz = z[pp];
                 }
-            } else {
-#pragma unroll
-                for (int i = 0; i < G; ++i) {
-                    const int p = q * G + i;
-                    const float d = dist2_cuda(x[p] - cx, y[p] - cy, z[p] - cz);        // :142
-                    td[p] = vmin_f32(d, td[p]);                                         // :143
-                    gm = max(gm, __float_as_int(td[p]));
-                }
+                const v2f dx = x[pp] - cx, dy = y[pp] - cy, dz = zz - cz;
+                v2f d = dy * dy;                                   // dist2_cuda, GSPN_DIST_POLICY 2, :142
+                d = __builtin_elementwise_fma(dx, dx, d);
+                d = __builtin_elementwise_fma(dz, dz, d);
+                td[pp][0] = vmin_f32(d[0], td[pp][0]);             // :143
+                td[pp][1] = vmin_f32(d[1], td[pp][1]);
+                gm = vmax3_i32(gm, __float_as_int(td[pp][0]), __float_as_int(td[pp][1]));
             }
             g[q] = gm;
             __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from interleaving groups (VGPR pressure)
@@ -114,55 +143,72 @@ __global__ __launch_bounds__(FPS_T) void fps_resident_kernel(int n, int m, const
         int best = g[0];
 #pragma unroll
         for (int q = 1; q < NG; ++q) best = max(best, g[q]);
+        FPS_TICK(0);
 
-        // ---- wave arg-max: value, then lowest lane holding it ----
+        // ---- wave arg-max: value -> lowest lane holding it -> lowest slot inside that lane ----
+        int qsel = NG - 1;                         // per lane: first group that holds the lane's best
+#pragma unroll
+        for (int q = NG - 2; q >= 0; --q) qsel = (g[q] == best) ? q : qsel;
         const int wmax = wave_max_i32(best);
-        const unsigned long long wm = __ballot(best == wmax);
-        const int wlane = __builtin_ctzll(wm);
-        if (lane == 0) s_wave[wave] = make_int2(wmax, wlane);
-        __syncthreads();
-
-        // ---- workgroup arg-max: every wave reduces the 8 candidates redundantly ----
-        const int2 cand = s_wave[lane & 7];
-        const int M = __builtin_amdgcn_readfirstlane(oct_max_i32(cand.x));
-        const unsigned wmask = (unsigned)(__ballot(cand.x == M) & 0xFFull);
-        const int wbest = __builtin_ctz(wmask);                  // lowest wave wins ties
-        if (wave == wbest) {
-            const int lw = __builtin_amdgcn_readlane(cand.y, wbest);
-            // resolve the register slot inside lane lw: lowest p with td[p] == M
-            int fp = -1;
-            float fx = 0.f, fy = 0.f, fz = 0.f;
+        const int lw = __builtin_ctzll(__ballot(best == wmax));
+        const int qw = __builtin_amdgcn_readlane(qsel, lw);
+        int isel = G - 1;                          // per lane: first slot of group qw equal to the lane's best
 #pragma unroll
-            for (int q = 0; q < NG; ++q) {
-                const unsigned long long gq = __ballot(g[q] == M);
-                if (fp < 0 && ((gq >> lw) & 1ull)) {
+        for (int q = 0; q < NG; ++q) {
+            if (qw == q) {                         // wave-uniform: static register indices inside
 #pragma unroll
-                    for (int i = 0; i < G; ++i) {
+                for (int i = G - 2; i >= 0; --i) {
+                    const int p = q * G + i;
+                    isel = (__float_as_int(td[p >> 1][p & 1]) == best) ? i : isel;
+                }
+            }
+        }
+        const int iw = __builtin_amdgcn_readlane(isel, lw);
+        float fx = 0.f, fy = 0.f, fz = 0.f;
+#pragma unroll
+        for (int q = 0; q < NG; ++q) {
+            if (qw == q) {
+#pragma unroll
+                for (int i = 0; i < G; ++i) {
+                    if (iw == i) {
                         const int p = q * G + i;
-                        const unsigned long long pq = __ballot(__float_as_int(td[p]) == M);
-                        if (fp < 0 && ((pq >> lw) & 1ull)) {
-                            fp = p;
-                            fx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x[p]), lw));
-                            fy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y[p]), lw));
-                            if (!ZLDS) fz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(z[p]), lw));
-                        }
+                        fx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x[p >> 1][p & 1]), lw));
+                        fy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y[p >> 1][p & 1]), lw));
+                        if (!ZLDS) fz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(z[ZLDS ? 0 : (p >> 1)][p & 1]), lw));
                     }
                 }
             }
-            const int tw = wbest * 64 + lw;
-            if (ZLDS) fz = reinterpret_cast<const float*>(s_z)[((fp >> 2) * FPS_T + tw) * 4 + (fp & 3)];
-            const int k = fp * FPS_T + tw;
-            if (lane == 0) {
-                *s_ctr = make_int4(k, __float_as_int(fx), __float_as_int(fy), __float_as_int(fz));
-                o[j] = k;                                      // :166-168
-            }
+        }
+        const int fp = qw * G + iw;
+        const int tw = wave * 64 + lw;
+        if (ZLDS) fz = reinterpret_cast<const float*>(s_z)[((fp >> 2) * FPS_T + tw) * 4 + (fp & 3)];
+        FPS_TICK(1);
+        const int buf = (j & 1) * FPS_W;
+        if (lane == 0) {
+            s_cand[buf + wave] = make_int4(wmax, __float_as_int(fx), __float_as_int(fy), __float_as_int(fz));
+            s_k[buf + wave] = ((tw & 1) * P + fp) * 512 + (tw >> 1);
         }
         __syncthreads();
-        const int4 c = *s_ctr;
-        cx = __int_as_float(__builtin_amdgcn_readfirstlane(c.y));
-        cy = __int_as_float(__builtin_amdgcn_readfirstlane(c.z));
-        cz = __int_as_float(__builtin_amdgcn_readfirstlane(c.w));
+        FPS_TICK(2);
+
+        // ---- workgroup arg-max: every wave reduces the 16 candidates redundantly (lowest wave wins ties)
+        const int4 cand = s_cand[buf + (lane & (FPS_W - 1))];
+        const int ck = s_k[buf + (lane & (FPS_W - 1))];
+        const int M = __builtin_amdgcn_readfirstlane(row_max_i32(cand.x));
+        const int wbest = __builtin_ctz((unsigned)(__ballot(cand.x == M) & 0xFFFFull));
+        cx = __int_as_float(__builtin_amdgcn_readlane(cand.y, wbest));
+        cy = __int_as_float(__builtin_amdgcn_readlane(cand.z, wbest));
+        cz = __int_as_float(__builtin_amdgcn_readlane(cand.w, wbest));
+        // cross-lane reads stay OUTSIDE the divergent store (a readlane sunk under `if (t == 0)` would
+        // let the compiler load s_k for lane 0 only)
+        const int kbest = __builtin_amdgcn_readlane(ck, wbest);
+        if (t == 0) o[j] = kbest;                                  // :166-168
+        FPS_TICK(3);
     }
+#ifdef FPS_PROFILE
+    if (blockIdx.x == 0 && (t == 0 || t == FPS_T - 64))
+        for (int i = 0; i < 4; ++i) g_fps_prof[i + (t ? 4 : 0)] = prof[i];
+#endif
 }
 
 // Fallback for scenes that do not fit one CU (n > 32768): one 1024-thread workgroup per scene
@@ -223,7 +269,7 @@ __global__ __launch_bounds__(1024) void fps_streaming_kernel(int b, int n, int m
 
 template <int P, bool ZLDS>
 static int launch_fps_resident(int b, int n, int m, const float* inp, int* out, hipStream_t st) {
-    const size_t lds = 128 + (ZLDS ? (size_t)P * FPS_T * sizeof(float) : 0);
+    const size_t lds = 1024 + (ZLDS ? (size_t)P * FPS_T * sizeof(float) : 0);
     if (ZLDS) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fps_resident_kernel<P, ZLDS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -238,13 +284,11 @@ extern "C" int gspn_farthestpointsampling(int b, int n, int m, const float* inp,
     if (b == 0) return 0;
     if (!inp || !out) return GSPN_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    if (n <= 512) return launch_fps_resident<1, false>(b, n, m, inp, out, st);
-    if (n <= 1024) return launch_fps_resident<2, false>(b, n, m, inp, out, st);
-    if (n <= 2048) return launch_fps_resident<4, false>(b, n, m, inp, out, st);
-    if (n <= 4096) return launch_fps_resident<8, false>(b, n, m, inp, out, st);
-    if (n <= 8192) return launch_fps_resident<16, false>(b, n, m, inp, out, st);
-    if (n <= 16384) return launch_fps_resident<32, false>(b, n, m, inp, out, st);
-    if (n <= GSPN_FPS_RESIDENT_MAX) return launch_fps_resident<64, true>(b, n, m, inp, out, st);
+    if (n <= 2048) return launch_fps_resident<2, false>(b, n, m, inp, out, st);
+    if (n <= 4096) return launch_fps_resident<4, false>(b, n, m, inp, out, st);
+    if (n <= 8192) return launch_fps_resident<8, false>(b, n, m, inp, out, st);
+    if (n <= 16384) return launch_fps_resident<16, false>(b, n, m, inp, out, st);
+    if (n <= GSPN_FPS_RESIDENT_MAX) return launch_fps_resident<32, true>(b, n, m, inp, out, st);
     if (!temp) return GSPN_ERR_ARG;
     if ((long long)n >= (1ll << 31) / 3) return GSPN_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(fps_streaming_kernel, dim3(b < 32 ? b : 32), dim3(1024), 0, st, b, n, m, inp, temp, out);
