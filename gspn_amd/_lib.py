@@ -18,11 +18,10 @@ _L = _c.c_long
 _F = _c.c_float
 
 
-class BnBwdArgs(_c.Structure):
-    """mirror of struct gspn_bn_bwd_args (include/gspn_hip.h)"""
+class DyArgs(_c.Structure):
+    """mirror of struct gspn_dy_args (include/gspn_hip.h)"""
     _fields_ = [("Y", _P), ("ldy", _I), ("dZ", _P), ("ldz", _I), ("dPool", _P), ("pool_arg", _P), ("ns", _I),
-                ("mean", _P), ("var", _P), ("gamma", _P), ("beta", _P), ("eps", _F), ("red", _P),
-                ("use_bn", _I), ("is_training", _I)]
+                ("scale", _P), ("shift", _P), ("cA", _P), ("cB", _P), ("cC", _P)]
 
 
 # symbol -> argtypes; every entry point of include/gspn_hip.h (tests check the list against the header)
@@ -46,18 +45,16 @@ SIGNATURES = {
     "gspn_nmdistance_grad": [_I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P],
     "gspn_sa_group_concat": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P],
     "gspn_sa_group_concat_grad": [_I, _I, _I, _I, _I, _P, _I, _I, _P, _P, _P],
-}
-# MLP entry points: bound once mlp.hip lands
-PENDING = {
     "gspn_mlp_fwd": [_L, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P],
     "gspn_bn_finalize": [_L, _I, _P, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P],
     "gspn_bnrelu_maxpool": [_L, _I, _I, _P, _I, _P, _P, _P, _P, _P],
     "gspn_bnrelu_apply": [_L, _I, _P, _I, _P, _P, _P, _I, _P],
-    "gspn_bn_bwd_reduce": [_L, _I, _c.POINTER(BnBwdArgs), _P, _P, _P, _P],
-    "gspn_mlp_bwd_data": [_L, _I, _I, _c.POINTER(BnBwdArgs), _P, _P, _I, _P],
-    "gspn_mlp_bwd_weight": [_L, _I, _I, _c.POINTER(BnBwdArgs), _P, _I, _P, _P, _P, _P, _P],
+    "gspn_bn_bwd_reduce": [_L, _I, _c.POINTER(DyArgs), _P, _P, _F, _P, _P],
+    "gspn_bn_bwd_coeffs": [_L, _I, _P, _P, _P, _P, _F, _I, _I, _P, _P, _P, _P, _P, _P, _P],
+    "gspn_mlp_bwd_data": [_L, _I, _I, _c.POINTER(DyArgs), _P, _P, _I, _P],
+    "gspn_mlp_bwd_weight": [_L, _I, _I, _c.POINTER(DyArgs), _P, _I, _P, _P, _P, _P],
+    "gspn_fill_zero": [_P, _L, _P],
 }
-SIGNATURES["gspn_fill_zero"] = [_P, _L, _P]
 
 _lib = None
 

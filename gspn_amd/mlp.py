@@ -1,0 +1,165 @@
+"""Shared-MLP stack on the MFMA kernels (C ABI gspn_mlp_* / gspn_bn_*).
+
+One `conv2d(1x1) + bias + batch_norm + relu` layer of utils/tf_util.py:120-185 over a
+(batch, npoint, nsample, C) tensor is a row-major GEMM over rows = batch*npoint*nsample.
+`mlp_stack` runs a whole `for num_out_channel in mlp:` loop of pointnet_util.py:109-113 (and the
+reduce_max of :123-124 when `pool_ns` is given) as one autograd node: pre-BN activations are written
+once, the BN+ReLU of layer l is applied inside the operand load of layer l+1, and backward rebuilds
+dY on the fly inside the two backward GEMMs.
+"""
+import ctypes
+
+import torch
+
+from . import _lib as L
+
+BN_EPS = 1e-3      # tf.contrib.layers.batch_norm default epsilon (tf_util.py:529-534 passes none)
+
+
+class LayerParams:
+    """Variables of one conv2d scope (tf_util.py:159-183): weights (cin,cout) [= the (1,1,cin,cout) kernel],
+    biases, and under bn: beta, gamma, moving_mean, moving_variance."""
+
+    def __init__(self, weights, biases, bn=True, beta=None, gamma=None, moving_mean=None, moving_variance=None):
+        self.weights, self.biases, self.bn = weights, biases, bn
+        self.beta, self.gamma, self.moving_mean, self.moving_variance = beta, gamma, moving_mean, moving_variance
+
+    def tensors(self):
+        t = [self.weights, self.biases]
+        if self.bn:
+            t += [self.beta, self.gamma]
+        return t
+
+
+def _zeros(n, dev, dtype=torch.float32):
+    return torch.zeros(n, dtype=dtype, device=dev)
+
+
+class _MlpStack(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, cin0, spec, *params):
+        """x: (rows, ld) float32 contiguous; spec: dict(layers=[LayerParams], is_training, decay, pool_ns);
+        params: flat list of the differentiable tensors (w, b[, beta, gamma]) per layer, for autograd."""
+        lib = L.lib()
+        st = L.stream()
+        dev = x.device
+        rows, ld = x.shape
+        layers = spec["layers"]
+        is_training = bool(spec["is_training"])
+        decay = float(spec["decay"])
+        pool_ns = spec["pool_ns"]
+        saved = []
+        cur, cur_ld, cin = x, ld, cin0
+        in_scale = in_shift = None
+        with torch.cuda.device(dev):
+            for lp in layers:
+                cout = lp.weights.shape[1]
+                y = torch.empty((rows, cout), dtype=torch.float32, device=dev)
+                use_stats = lp.bn and is_training
+                stats = _zeros(2 * cout, dev, torch.float64) if use_stats else None
+                L.check(lib.gspn_mlp_fwd(rows, cin, cout, L.ptr(cur), cur_ld, L.ptr(in_scale), L.ptr(in_shift),
+                                         L.ptr(lp.weights), L.ptr(lp.biases), L.ptr(y), cout, L.ptr(stats), st), "mlp_fwd")
+                mean = torch.empty(cout, dtype=torch.float32, device=dev)
+                var = torch.empty(cout, dtype=torch.float32, device=dev)
+                scale = torch.empty(cout, dtype=torch.float32, device=dev)
+                shift = torch.empty(cout, dtype=torch.float32, device=dev)
+                if lp.bn:
+                    L.check(lib.gspn_bn_finalize(rows, cout, L.ptr(stats), L.ptr(lp.gamma), L.ptr(lp.beta), BN_EPS, decay,
+                                                 int(is_training), L.ptr(lp.moving_mean), L.ptr(lp.moving_variance),
+                                                 L.ptr(mean), L.ptr(var), L.ptr(scale), L.ptr(shift), st), "bn_finalize")
+                else:
+                    scale.fill_(1.0)
+                    shift.zero_()
+                    mean.zero_()
+                    var.fill_(1.0)
+                saved.append((cur, cur_ld, cin, in_scale, in_shift, y, mean, var, scale, shift))
+                cur, cur_ld, cin, in_scale, in_shift = y, cout, cout, scale, shift
+            cl = cin
+            arg = None
+            if pool_ns:
+                groups = rows // pool_ns
+                out = torch.empty((groups, cl), dtype=torch.float32, device=dev)
+                arg = torch.empty((groups, cl), dtype=torch.int32, device=dev)
+                L.check(lib.gspn_bnrelu_maxpool(groups, pool_ns, cl, L.ptr(cur), cur_ld, L.ptr(in_scale), L.ptr(in_shift),
+                                                L.ptr(out), L.ptr(arg), st), "bnrelu_maxpool")
+            else:
+                out = torch.empty((rows, cl), dtype=torch.float32, device=dev)
+                L.check(lib.gspn_bnrelu_apply(rows, cl, L.ptr(cur), cur_ld, L.ptr(in_scale), L.ptr(in_shift), L.ptr(out), cl, st), "bnrelu_apply")
+        ctx.saved = saved
+        ctx.arg = arg
+        ctx.spec = spec
+        ctx.rows = rows
+        ctx.x_needs_grad = x.requires_grad
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        lib = L.lib()
+        st = L.stream()
+        spec = ctx.spec
+        layers = spec["layers"]
+        is_training = bool(spec["is_training"])
+        pool_ns = spec["pool_ns"]
+        rows = ctx.rows
+        d_out = d_out.contiguous()
+        dev = d_out.device
+        grads = []
+        dz = None if pool_ns else d_out          # dense upstream gradient of the current layer
+        ldz = d_out.shape[1]
+        dx0 = None
+        with torch.cuda.device(dev):
+            for li in range(len(layers) - 1, -1, -1):
+                lp = layers[li]
+                (xin, xld, cin, in_scale, in_shift, y, mean, var, scale, shift) = ctx.saved[li]
+                cout = lp.weights.shape[1]
+                cA = torch.empty(cout, dtype=torch.float32, device=dev)
+                cB = torch.empty(cout, dtype=torch.float32, device=dev)
+                cC = torch.empty(cout, dtype=torch.float32, device=dev)
+                a = L.DyArgs()
+                a.Y, a.ldy = y.data_ptr(), cout
+                if dz is None:
+                    a.dZ, a.ldz, a.dPool, a.pool_arg, a.ns = None, 0, d_out.data_ptr(), ctx.arg.data_ptr(), pool_ns
+                else:
+                    a.dZ, a.ldz, a.dPool, a.pool_arg, a.ns = dz.data_ptr(), ldz, None, None, 0
+                a.scale, a.shift = scale.data_ptr(), shift.data_ptr()
+                a.cA, a.cB, a.cC = cA.data_ptr(), cB.data_ptr(), cC.data_ptr()
+                red = _zeros(2 * cout, dev, torch.float64)
+                L.check(lib.gspn_bn_bwd_reduce(rows, cout, ctypes.byref(a), L.ptr(mean), L.ptr(var), BN_EPS, L.ptr(red), st), "bn_bwd_reduce")
+                dgamma = torch.empty(cout, dtype=torch.float32, device=dev) if lp.bn else None
+                dbeta = torch.empty(cout, dtype=torch.float32, device=dev) if lp.bn else None
+                dbias = torch.empty(cout, dtype=torch.float32, device=dev)
+                L.check(lib.gspn_bn_bwd_coeffs(rows, cout, L.ptr(red), L.ptr(mean), L.ptr(var), L.ptr(lp.gamma if lp.bn else None), BN_EPS,
+                                               int(lp.bn), int(is_training), L.ptr(cA), L.ptr(cB), L.ptr(cC),
+                                               L.ptr(dgamma), L.ptr(dbeta), L.ptr(dbias), st), "bn_bwd_coeffs")
+                dW = torch.empty_like(lp.weights)
+                L.check(lib.gspn_mlp_bwd_weight(rows, cin, cout, ctypes.byref(a), L.ptr(xin), xld, L.ptr(in_scale), L.ptr(in_shift), L.ptr(dW), st),
+                        "mlp_bwd_weight")
+                g = [dW, dbias]
+                if lp.bn:
+                    g += [dbeta, dgamma]
+                grads = g + grads
+                if li > 0 or ctx.x_needs_grad:
+                    dx = torch.empty((rows, xld), dtype=torch.float32, device=dev) if li == 0 else torch.empty((rows, cin), dtype=torch.float32, device=dev)
+                    if li == 0 and xld > cin:
+                        dx.zero_()
+                    L.check(lib.gspn_mlp_bwd_data(rows, cin, cout, ctypes.byref(a), L.ptr(lp.weights), L.ptr(dx), dx.shape[1], st), "mlp_bwd_data")
+                    if li == 0:
+                        dx0 = dx
+                    dz, ldz = dx, dx.shape[1]
+                # keep the buffers referenced by `a` alive until the kernels are enqueued (same stream: ordered)
+                del a
+        return (dx0, None, None) + tuple(grads)
+
+
+def mlp_stack(x, cin, layers, is_training, bn_decay, pool_ns=None):
+    """x: (rows, ld>=cin) float32 on a ROCm device.  Returns (rows/pool_ns, C_last) if pool_ns else (rows, C_last)."""
+    if not layers:
+        raise ValueError("mlp_stack needs at least one layer")
+    x = L.need(x, torch.float32, 2, "x")
+    if pool_ns and x.shape[0] % pool_ns:
+        raise ValueError("rows must be a multiple of pool_ns")
+    spec = {"layers": layers, "is_training": is_training, "decay": 0.9 if bn_decay is None else float(bn_decay), "pool_ns": pool_ns}
+    flat = []
+    for lp in layers:
+        flat += lp.tensors()
+    return _MlpStack.apply(x, cin, spec, *flat)

@@ -1,0 +1,166 @@
+"""Drop-in for utils/pointnet_util.py: sample_and_group, sample_and_group_all,
+pointnet_sa_module, pointnet_fp_module -- same argument names and return tuples as the reference,
+over torch tensors on a ROCm device.
+
+pointnet_sa_module / pointnet_fp_module run the fused device path: FPS -> gather -> ball query ->
+one grouping kernel that writes concat([xyz[idx]-new_xyz, points[idx]]) straight into the MLP's
+input matrix -> MFMA MLP stack with the max-pool folded into its last layer.
+"""
+import torch
+
+from . import _lib as L
+from . import tf_util
+from .mlp import mlp_stack
+from .tf_grouping import group_point, knn_point, query_ball_point
+from .tf_interpolate import three_interpolate, three_nn
+from .tf_sampling import farthest_point_sample, gather_point
+
+
+class _GroupConcat(torch.autograd.Function):
+    """rows = concat([xyz[idx]-new_xyz, points[idx]]) (pointnet_util.py:41-48) as a (b*m*ns, 3+c) matrix;
+    gradient flows to `points` only (xyz/new_xyz are inputs of the network)."""
+
+    @staticmethod
+    def forward(ctx, xyz, new_xyz, points, idx, xyz_first):
+        b, n, _ = xyz.shape
+        _, m, ns = idx.shape
+        c = 0 if points is None else points.shape[2]
+        out = torch.empty((b * m * ns, 3 + c), dtype=torch.float32, device=xyz.device)
+        with torch.cuda.device(xyz.device):
+            L.check(L.lib().gspn_sa_group_concat(b, n, c, m, ns, L.ptr(xyz), L.ptr(new_xyz), L.ptr(points), L.ptr(idx),
+                                                 int(xyz_first), 3 + c, L.ptr(out), L.stream()), "sa_group_concat")
+        ctx.save_for_backward(idx)
+        ctx.dims = (b, n, c, m, ns, int(xyz_first))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        b, n, c, m, ns, xyz_first = ctx.dims
+        gp = None
+        if c > 0 and ctx.needs_input_grad[2]:
+            g = g.contiguous()
+            gp = torch.empty((b, n, c), dtype=torch.float32, device=g.device)
+            with torch.cuda.device(g.device):
+                L.check(L.lib().gspn_sa_group_concat_grad(b, n, c, m, ns, L.ptr(idx), xyz_first, 3 + c, L.ptr(g), L.ptr(gp), L.stream()),
+                        "sa_group_concat_grad")
+        return None, None, gp, None, None
+
+
+def group_concat(xyz, new_xyz, points, idx, xyz_first=True):
+    xyz = L.need(xyz.detach(), torch.float32, 3, "xyz")
+    new_xyz = L.need(new_xyz.detach(), torch.float32, 3, "new_xyz")
+    idx = L.need(idx, torch.int32, 3, "idx")
+    if points is not None:
+        points = L.need(points, torch.float32, 3, "points")
+    return _GroupConcat.apply(xyz, new_xyz, points, idx, xyz_first)
+
+
+def sample_and_group(npoint, radius, nsample, xyz, points, tnet_spec=None, knn=False, use_xyz=True):
+    """pointnet_util.py:17-54.  Returns new_xyz (b,npoint,3), new_points (b,npoint,nsample,3+c),
+    idx (b,npoint,nsample), grouped_xyz (b,npoint,nsample,3)."""
+    if tnet_spec is not None:
+        raise NotImplementedError("tnet_spec: `tnet` is an undefined name in the reference (pointnet_util.py:44)")
+    new_xyz = gather_point(xyz, farthest_point_sample(npoint, xyz))
+    if knn:
+        _, idx = knn_point(nsample, xyz, new_xyz)
+    else:
+        idx, pts_cnt = query_ball_point(radius, nsample, xyz, new_xyz)
+    grouped_xyz = group_point(xyz, idx)
+    grouped_xyz = grouped_xyz - new_xyz.unsqueeze(2)                      # :42 translation normalisation
+    if points is not None:
+        grouped_points = group_point(points, idx)
+        new_points = torch.cat([grouped_xyz, grouped_points], dim=-1) if use_xyz else grouped_points   # :48
+    else:
+        new_points = grouped_xyz
+    return new_xyz, new_points, idx, grouped_xyz
+
+
+def sample_and_group_all(xyz, points, use_xyz=True):
+    """pointnet_util.py:57-82"""
+    b, n, _ = xyz.shape
+    new_xyz = torch.zeros((b, 1, 3), dtype=torch.float32, device=xyz.device)
+    idx = torch.arange(n, dtype=torch.int32, device=xyz.device).view(1, 1, n).repeat(b, 1, 1)
+    grouped_xyz = xyz.reshape(b, 1, n, 3)
+    if points is not None:
+        new_points = torch.cat([xyz, points], dim=2) if use_xyz else points
+        new_points = new_points.unsqueeze(1)
+    else:
+        new_points = grouped_xyz
+    return new_xyz, new_points, idx, grouped_xyz
+
+
+def _mlp_layers(channels, cin, prefix, bn):
+    layers = []
+    for i, cout in enumerate(channels):
+        layers.append(tf_util._layer_params('%s%d' % (prefix, i), cin, cout, [1, 1, cin, cout], True, 1e-3, None, bn))
+        cin = cout
+    return layers
+
+
+def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_all, is_training, bn_decay, scope, bn=True,
+                       pooling='max', tnet_spec=None, knn=False, use_xyz=True):
+    """pointnet_util.py:85-139.  Returns new_xyz (b,npoint,3), new_points (b,npoint,mlp[-1] or mlp2[-1]), idx (b,npoint,nsample)."""
+    with tf_util.variable_scope(scope):
+        b = xyz.shape[0]
+        fused = (pooling == 'max') and not group_all and not knn and tnet_spec is None and len(mlp) > 0 and (points is None or use_xyz)
+        if fused:
+            new_xyz = gather_point(xyz, farthest_point_sample(npoint, xyz))
+            idx, pts_cnt = query_ball_point(radius, nsample, xyz, new_xyz)
+            rows = group_concat(xyz, new_xyz, points, idx, xyz_first=True)
+            cin = rows.shape[1]
+            layers = _mlp_layers(mlp, cin, 'conv', bn)
+            pooled = mlp_stack(rows, cin, layers, bool(is_training), bn_decay, pool_ns=nsample)     # (b*npoint, mlp[-1])
+            new_points = pooled.view(b, npoint, 1, mlp[-1])
+        else:
+            if group_all:
+                nsample = xyz.shape[1]
+                new_xyz, new_points, idx, grouped_xyz = sample_and_group_all(xyz, points, use_xyz)
+            else:
+                new_xyz, new_points, idx, grouped_xyz = sample_and_group(npoint, radius, nsample, xyz, points, tnet_spec, knn, use_xyz)
+            for i, num_out_channel in enumerate(mlp):
+                new_points = tf_util.conv2d(new_points, num_out_channel, [1, 1], padding='VALID', stride=[1, 1], bn=bn,
+                                            is_training=is_training, scope='conv%d' % (i), bn_decay=bn_decay)
+            if pooling == 'avg':
+                new_points = tf_util.avg_pool2d(new_points, [1, nsample], stride=[1, 1], padding='VALID', scope='avgpool1')
+            elif pooling == 'weighted_avg':
+                dists = torch.linalg.vector_norm(grouped_xyz, dim=-1, keepdim=True)
+                exp_dists = torch.exp(-dists * 5)
+                weights = exp_dists / exp_dists.sum(dim=2, keepdim=True)
+                new_points = (new_points * weights).sum(dim=2, keepdim=True)
+            elif pooling == 'max':
+                new_points = new_points.max(dim=2, keepdim=True).values
+            elif pooling == 'min':
+                new_points = tf_util.max_pool2d(-1 * new_points, [1, nsample], stride=[1, 1], padding='VALID', scope='minpool1')
+            elif pooling == 'max_and_avg':
+                avg_points = tf_util.max_pool2d(new_points, [1, nsample], stride=[1, 1], padding='VALID', scope='maxpool1')
+                max_points = tf_util.avg_pool2d(new_points, [1, nsample], stride=[1, 1], padding='VALID', scope='avgpool1')
+                new_points = torch.cat([avg_points, max_points], dim=-1)
+        if mlp2 is None:
+            mlp2 = []
+        for i, num_out_channel in enumerate(mlp2):
+            new_points = tf_util.conv2d(new_points.contiguous(), num_out_channel, [1, 1], padding='VALID', stride=[1, 1], bn=bn,
+                                        is_training=is_training, scope='conv_post_%d' % (i), bn_decay=bn_decay)
+        new_points = new_points.squeeze(2)
+        return new_xyz, new_points, idx
+
+
+def pointnet_fp_module(xyz1, xyz2, points1, points2, mlp, is_training, bn_decay, scope, bn=True, reuse=False):
+    """pointnet_util.py:142-174.  xyz1 (b,n1,3) dense, xyz2 (b,n2,3) sparse, points1 (b,n1,c1) or None,
+    points2 (b,n2,c2) -> (b,n1,mlp[-1])  (or the concatenated features when mlp == [])."""
+    with tf_util.variable_scope(scope, reuse=reuse):
+        dist, idx = three_nn(xyz1, xyz2)
+        dist = torch.clamp(dist, min=1e-10)                               # :157
+        norm = (1.0 / dist).sum(dim=2, keepdim=True)                      # :158
+        weight = (1.0 / dist) / norm                                      # :160
+        interpolated_points = three_interpolate(points2, idx, weight)
+        if points1 is not None:
+            new_points1 = torch.cat([interpolated_points, points1], dim=2)   # :164 (interp FIRST)
+        else:
+            new_points1 = interpolated_points
+        if len(mlp) == 0:
+            return new_points1
+        b, n1, cin = new_points1.shape
+        layers = _mlp_layers(mlp, cin, 'conv_', bn)
+        out = mlp_stack(new_points1.reshape(b * n1, cin), cin, layers, bool(is_training), bn_decay, pool_ns=None)
+        return out.view(b, n1, mlp[-1])

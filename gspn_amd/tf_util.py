@@ -1,0 +1,224 @@
+"""Drop-in for the parts of utils/tf_util.py the set-abstraction path uses: variable helpers,
+conv2d / conv1d / fully_connected (1x1 only: that is all SA/FP modules use), batch-norm wrappers,
+dropout and the (1, nsample) pooling helpers.  NHWC tensors, torch on a ROCm device.
+
+TensorFlow's variable scopes are mirrored by a small VariableStore: `with variable_scope('layer1'):`
++ `get_variable('weights', ...)` create-or-reuse parameters under 'layer1/weights', so model code
+written against the reference (scope strings, `bn=`, `is_training=`, `bn_decay=`) runs unchanged.
+"""
+import contextlib
+import math
+
+import torch
+
+from . import _lib as L
+from .mlp import LayerParams, mlp_stack
+
+
+# --------------------------------------------------------------------------- variables / scopes
+class VariableStore:
+    def __init__(self, device=None, seed=None):
+        self.vars = {}
+        self.trainable = []
+        self.device = device
+        self.generator = None
+        if seed is not None:
+            self.generator = torch.Generator(device="cpu")
+            self.generator.manual_seed(seed)
+
+    def dev(self):
+        return self.device if self.device is not None else torch.device("cuda", torch.cuda.current_device())
+
+    def parameters(self):
+        return [self.vars[n] for n in self.trainable]
+
+    def named_parameters(self):
+        return [(n, self.vars[n]) for n in self.trainable]
+
+
+_store = VariableStore()
+_scopes = []
+
+
+def set_variable_store(store):
+    global _store
+    _store = store
+    return store
+
+
+def get_variable_store():
+    return _store
+
+
+@contextlib.contextmanager
+def variable_scope(name, reuse=None):
+    _scopes.append(str(name))
+    try:
+        yield "/".join(_scopes)
+    finally:
+        _scopes.pop()
+
+
+def get_variable(name, shape, initializer, trainable=True):
+    full = "/".join(_scopes + [name])
+    if full in _store.vars:
+        v = _store.vars[full]
+        if tuple(v.shape) != tuple(shape):
+            raise ValueError("variable %s exists with shape %s, requested %s" % (full, tuple(v.shape), tuple(shape)))
+        return v
+    data = initializer(tuple(shape), _store.generator).to(dtype=torch.float32, device=_store.dev())
+    v = torch.nn.Parameter(data, requires_grad=trainable) if trainable else data
+    _store.vars[full] = v
+    if trainable:
+        _store.trainable.append(full)
+    return v
+
+
+def xavier_initializer():
+    """tf.contrib.layers.xavier_initializer(uniform=True): U(-l, l), l = sqrt(6/(fan_in+fan_out));
+    for a (kh,kw,cin,cout) kernel fan_in = kh*kw*cin, fan_out = kh*kw*cout."""
+    def init(shape, gen):
+        rf = 1
+        for d in shape[:-2]:
+            rf *= d
+        fan_in, fan_out = shape[-2] * rf, shape[-1] * rf
+        lim = math.sqrt(6.0 / (fan_in + fan_out))
+        return (torch.rand(shape, generator=gen) * 2.0 - 1.0) * lim
+    return init
+
+
+def truncated_normal_initializer(stddev):
+    def init(shape, gen):
+        t = torch.empty(shape)
+        torch.nn.init.trunc_normal_(t, mean=0.0, std=stddev, a=-2 * stddev, b=2 * stddev, generator=gen)
+        return t
+    return init
+
+
+def constant_initializer(value):
+    return lambda shape, gen: torch.full(shape, float(value))
+
+
+def _variable_on_cpu(name, shape, initializer, use_fp16=False):
+    """tf_util.py:10-22.  The reference pins variables to /cpu:0 and copies them to the GPU every
+    step; here they live in HBM (fp32 only)."""
+    return get_variable(name, shape, initializer)
+
+
+_losses = []
+
+
+def _variable_with_weight_decay(name, shape, stddev, wd, use_xavier=True):
+    """tf_util.py:24-49"""
+    init = xavier_initializer() if use_xavier else truncated_normal_initializer(stddev)
+    var = _variable_on_cpu(name, shape, init)
+    if wd is not None:
+        _losses.append((var, float(wd)))          # tf.add_to_collection('losses', l2_loss(var)*wd)
+    return var
+
+
+def weight_decay_loss():
+    return sum((0.5 * (v * v).sum() * wd for v, wd in _losses), torch.zeros((), device=_store.dev()))
+
+
+# --------------------------------------------------------------------------- layers
+def _bn_variables(c):
+    """tf.contrib.layers.batch_norm(center=True, scale=True) variables under scope 'bn' (tf_util.py:529-534)."""
+    beta = get_variable("beta", (c,), constant_initializer(0.0))
+    gamma = get_variable("gamma", (c,), constant_initializer(1.0))
+    mm = get_variable("moving_mean", (c,), constant_initializer(0.0), trainable=False)
+    mv = get_variable("moving_variance", (c,), constant_initializer(1.0), trainable=False)
+    return beta, gamma, mm, mv
+
+
+def _layer_params(scope, cin, cout, kernel_shape, use_xavier, stddev, weight_decay, bn):
+    with variable_scope(scope):
+        kernel = _variable_with_weight_decay("weights", shape=kernel_shape, use_xavier=use_xavier, stddev=stddev, wd=weight_decay)
+        biases = _variable_on_cpu("biases", [cout], constant_initializer(0.0))
+        w2d = kernel.view(cin, cout)
+        if bn:
+            with variable_scope("bn"):
+                beta, gamma, mm, mv = _bn_variables(cout)
+            return LayerParams(w2d, biases, True, beta, gamma, mm, mv)
+        return LayerParams(w2d, biases, False)
+
+
+def conv2d(inputs, num_output_channels, kernel_size, scope, stride=[1, 1], padding='SAME', data_format='NHWC',
+           use_xavier=True, stddev=1e-3, weight_decay=None, activation_fn=torch.relu, bn=False, bn_decay=None, is_training=None):
+    """tf_util.py:120-185 for the 1x1 / stride-1 kernels the SA and FP modules use (pointnet_util.py:109-113,168-172).
+    inputs: (B,H,W,C) -> (B,H,W,num_output_channels) = activation(BN(inputs.W + biases))."""
+    kh, kw = kernel_size
+    if (kh, kw) != (1, 1) or list(stride) != [1, 1] or data_format != 'NHWC':
+        raise NotImplementedError("gspn_amd.tf_util.conv2d implements the 1x1 stride-1 NHWC case of the set-abstraction path")
+    inputs = L.need(inputs, torch.float32, 4, "inputs")
+    cin = inputs.shape[-1]
+    lp = _layer_params(scope, cin, num_output_channels, [1, 1, cin, num_output_channels], use_xavier, stddev, weight_decay, bn)
+    out = _apply_layer(inputs.reshape(-1, cin), cin, lp, activation_fn, bool(is_training) if is_training is not None else False, bn_decay)
+    return out.view(*inputs.shape[:-1], num_output_channels)
+
+
+def conv1d(inputs, num_output_channels, kernel_size, scope, stride=1, padding='SAME', data_format='NHWC',
+           use_xavier=True, stddev=1e-3, weight_decay=None, activation_fn=torch.relu, bn=False, bn_decay=None, is_training=None):
+    """tf_util.py:52-115 for kernel_size 1.  inputs: (B,L,C)."""
+    if kernel_size != 1 or stride != 1 or data_format != 'NHWC':
+        raise NotImplementedError("gspn_amd.tf_util.conv1d implements kernel_size=1, stride=1, NHWC")
+    inputs = L.need(inputs, torch.float32, 3, "inputs")
+    cin = inputs.shape[-1]
+    lp = _layer_params(scope, cin, num_output_channels, [1, cin, num_output_channels], use_xavier, stddev, weight_decay, bn)
+    out = _apply_layer(inputs.reshape(-1, cin), cin, lp, activation_fn, bool(is_training) if is_training is not None else False, bn_decay)
+    return out.view(*inputs.shape[:-1], num_output_channels)
+
+
+def fully_connected(inputs, num_outputs, scope, use_xavier=True, stddev=1e-3, weight_decay=None, activation_fn=torch.relu,
+                    bn=False, bn_decay=None, is_training=None):
+    """tf_util.py:330-366.  inputs: (B,N)."""
+    inputs = L.need(inputs, torch.float32, 2, "inputs")
+    cin = inputs.shape[-1]
+    lp = _layer_params(scope, cin, num_outputs, [cin, num_outputs], use_xavier, stddev, weight_decay, bn)
+    return _apply_layer(inputs, cin, lp, activation_fn, bool(is_training) if is_training is not None else False, bn_decay)
+
+
+def _apply_layer(x2d, cin, lp, activation_fn, is_training, bn_decay):
+    if activation_fn is torch.relu or activation_fn is torch.nn.functional.relu:
+        return mlp_stack(x2d, cin, [lp], is_training, bn_decay, None)
+    raise NotImplementedError("only activation_fn=relu is implemented on the MFMA path (all SA/FP layers use it)")
+
+
+def batch_norm_for_conv2d(inputs, is_training, bn_decay, scope, data_format='NHWC'):
+    """tf_util.py:568-580 (stand-alone BN over N,H,W): torch ops; the fused path is inside conv2d."""
+    c = inputs.shape[-1]
+    with variable_scope(scope):
+        beta, gamma, mm, mv = _bn_variables(c)
+    decay = 0.9 if bn_decay is None else float(bn_decay)
+    x = inputs.reshape(-1, c)
+    if is_training:
+        mean = x.mean(0)
+        var = x.var(0, unbiased=False)
+        with torch.no_grad():
+            mm.mul_(decay).add_(mean.detach() * (1 - decay))
+            mv.mul_(decay).add_(var.detach() * (1 - decay))
+    else:
+        mean, var = mm, mv
+    inv = torch.rsqrt(var + 1e-3) * gamma
+    return (x * inv + (beta - mean * inv)).view_as(inputs)
+
+
+def max_pool2d(inputs, kernel_size, scope, stride=[2, 2], padding='VALID'):
+    """tf_util.py:369-393 for the (1, nsample) window used by pointnet_util.py:126-129"""
+    kh, kw = kernel_size
+    if kh != 1 or kw != inputs.shape[2]:
+        raise NotImplementedError("only the [1, nsample] pooling window of the SA module is implemented")
+    return inputs.max(dim=2, keepdim=True).values
+
+
+def avg_pool2d(inputs, kernel_size, scope, stride=[2, 2], padding='VALID'):
+    """tf_util.py:395-418 for the (1, nsample) window"""
+    kh, kw = kernel_size
+    if kh != 1 or kw != inputs.shape[2]:
+        raise NotImplementedError("only the [1, nsample] pooling window of the SA module is implemented")
+    return inputs.mean(dim=2, keepdim=True)
+
+
+def dropout(inputs, is_training, scope, keep_prob=0.5, noise_shape=None):
+    """tf_util.py:597-618"""
+    return torch.nn.functional.dropout(inputs, p=1.0 - keep_prob, training=bool(is_training))

@@ -61,10 +61,8 @@ int gspn_queryballpoint(int b, int n, int m, float radius, int nsample, const fl
 /* selectionSortLauncher(b,n,m,k,dist,outi,out)  tf_grouping.cpp:138, tf_grouping_g.cu:190-193 */
 int gspn_selectionsort(int b, int n, int m, int k, const float* dist, int* outi, float* out, void* stream);
 
-/* Direct k-NN replacing tf_grouping.py:71-96 (dense (b,m,n) matrix + selection sort):
- * xyz1 (b,n,3) data, xyz2 (b,m,3) queries -> val (b,m,k) squared distances, idx (b,m,k); same
- * arithmetic ((x1-x2)^2 summed x,y,z) and tie rule (lowest index first). k <= 64. */
-int gspn_knnpoint(int b, int n, int m, int k, const float* xyz1, const float* xyz2, float* val, int* idx, void* stream);
+/* knn_point (tf_grouping.py:71-96) is composed on the host side exactly as the reference does:
+ * dense squared-distance matrix + gspn_selectionsort + slice (see gspn_amd/tf_grouping.py). */
 
 /* groupPointLauncher(b,n,c,m,nsample,points,idx,out)  tf_grouping.cpp:172, tf_grouping_g.cu:194-197 */
 int gspn_grouppoint(int b, int n, int c, int m, int nsample, const float* points, const int* idx, float* out, void* stream);
@@ -113,68 +111,75 @@ int gspn_sa_group_concat_grad(int b, int n, int c, int m, int nsample, const int
                               const float* grad_out, float* grad_points, void* stream);
 
 /* ---------------- utils/tf_util.py conv2d 1x1 (+bias +BN +ReLU) : the shared MLP ------- */
-/* The reference delegates this arithmetic to TensorFlow (tf_util.py:120-185, 515-534).
- * One layer is   y = x.W + bias ;  z = relu(gamma*(y-mean)*rsqrt(var+eps)+beta)
- * over `rows` = b*m*nsample rows.  The kernels are fp32 MFMA GEMMs with the element-wise work
- * fused into the operand load (prologue) / the accumulator store (epilogue).
+/* The reference delegates this arithmetic to TensorFlow (tf_util.py:120-185, 515-534):
+ *      y = x.W + bias ;  z = relu(gamma*(y-mean)*rsqrt(var+eps)+beta)
+ * per layer over `rows` = b*m*nsample rows (NHWC, 1x1 kernel == a row-major GEMM).  Here each
+ * layer is an fp32-MFMA GEMM (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate) with the
+ * element-wise work fused into the operand staging (prologue) / accumulator store (epilogue), so an
+ * activation tensor is written once (pre-BN) and read once by its consumer.
  *
- * gspn_mlp_fwd:  Y(rows,ldy) = act(X)(rows,ldx)[:, :cin] . W(cin,cout) + bias
+ * gspn_mlp_fwd:  Y(rows,ldy)[:, :cout] = act(X)(rows,ldx)[:, :cin] . W(cin,cout) + bias
  *   act(X) = X                           if in_scale == NULL
- *          = relu(X*in_scale+in_shift)   otherwise (per input channel; the previous layer's BN+ReLU)
- *   stats (2*cout floats, may be NULL): column sums of Y and Y^2 are ATOMICALLY ADDED; the caller
- *   zeroes it (gspn_fill_zero) -- they feed training-mode BN.
+ *          = relu(X*in_scale+in_shift)   otherwise (per input channel: the previous layer's BN+ReLU)
+ *   stats (2*cout DOUBLES, may be NULL): column sums of Y and Y^2 are atomically added (the caller
+ *   zeroes it); they feed training-mode BN.
  */
 int gspn_mlp_fwd(long rows, int cin, int cout, const float* X, int ldx, const float* in_scale, const float* in_shift,
-                 const float* W, const float* bias, float* Y, int ldy, float* stats, void* stream);
+                 const float* W, const float* bias, float* Y, int ldy, double* stats, void* stream);
 
-/* BN finalize: from stats (sum, sumsq) over `rows` rows produce scale/shift (2*c each), the batch
- * mean / biased variance (saved for backward) and update the moving averages in place
- * (moving = moving*decay + batch*(1-decay), tf.contrib.layers.batch_norm semantics; the moving
- * variance uses the biased batch variance).  When is_training==0, scale/shift come from the
- * moving statistics and nothing is updated. */
-int gspn_bn_finalize(long rows, int c, const float* stats, const float* gamma, const float* beta, float eps, float decay,
+/* BN finalize (tf.contrib.layers.batch_norm, tf_util.py:529-534): from stats = (sum, sumsq) over
+ * `rows` rows produce the batch mean / biased variance (saved for backward), scale = gamma*rsqrt(var+eps),
+ * shift = beta - mean*scale, and update the moving averages in place
+ * (moving = moving*decay + batch*(1-decay)).  is_training==0: scale/shift come from the moving
+ * statistics, mean/var are set to them and nothing is updated (stats may be NULL). */
+int gspn_bn_finalize(long rows, int c, const double* stats, const float* gamma, const float* beta, float eps, float decay,
                      int is_training, float* moving_mean, float* moving_var, float* mean, float* var,
                      float* scale, float* shift, void* stream);
 
-/* out(groups,c) = max over the ns rows of each group of relu(Y*scale+shift); arg (groups,c) gets the
- * row offset (0..ns-1) of the first maximum.  scale==NULL: plain max of Y. */
+/* out(groups,c) = max over the ns rows of each group of relu(Y*scale+shift)   (tf.reduce_max,
+ * pointnet_util.py:123-124); arg (groups,c) gets the row offset (0..ns-1) of the first maximum. */
 int gspn_bnrelu_maxpool(long groups, int ns, int c, const float* Y, int ldy, const float* scale, const float* shift,
                         float* out, int* arg, void* stream);
-/* z = relu(Y*scale+shift) materialised (used after the last layer of an FP module) */
+/* out = relu(Y*scale+shift) materialised (last layer of an FP module) */
 int gspn_bnrelu_apply(long rows, int c, const float* Y, int ldy, const float* scale, const float* shift, float* out, int ldo, void* stream);
 
-/* Backward of one layer.  Given dZ (the gradient w.r.t. z = relu(bn(y))) this computes
- *   dY = BN-backward(relu-backward(dZ))          (training-mode batch statistics)
- * in two passes.  Pass 1 (gspn_bn_bwd_reduce) accumulates per channel
- *   red[0:c]  = sum(dZ*[z>0]),  red[c:2c] = sum(dZ*[z>0]*xhat)      (atomically; caller zeroes)
- * where dZ is either a dense (rows,ldz) tensor or, when pool_arg != NULL, the scatter of a
- * pooled gradient dPool(groups,c) to its arg-max rows.  Pass 2 is fused into the two GEMMs:
- *   gspn_mlp_bwd_data :  dX(rows,ldx)[:, :cin] = dY . W^T
- *   gspn_mlp_bwd_weight: dW(cin,cout) += act(X)^T . dY ,  dbias += colsum(dY)   (atomic; caller zeroes)
- * both of which recompute dY on the fly from (Y, dZ|dPool+arg, mean, var, gamma, red).
- */
-typedef struct gspn_bn_bwd_args {
-    const float* Y;        /* (rows, ldy) pre-BN output of this layer (saved from forward) */
+/* ---- backward of one layer -------------------------------------------------------------
+ * With z = relu(s*y+t) and upstream gradient dz (dense, or the scatter of a pooled gradient to its
+ * arg-max rows), the gradient w.r.t. the pre-BN output is
+ *      dyh = dz * [s*y+t > 0]
+ *      dY  = cA*dyh + cB*y + cC                     (per output channel coefficients)
+ * which covers BN-training (cA=gamma*rstd, cB/cC from the two batch reductions), BN-inference
+ * (cA=scale, cB=cC=0) and no-BN (cA=1).  dY is never materialised: the reduction kernel and both
+ * GEMMs rebuild it on the fly from (Y, dz) while staging their operands. */
+typedef struct gspn_dy_args {
+    const float* Y;        /* (rows, ldy) pre-BN output saved by the forward pass */
     int ldy;
     const float* dZ;       /* dense upstream gradient (rows, ldz), or NULL when pooled */
     int ldz;
     const float* dPool;    /* pooled upstream gradient (rows/ns, c), or NULL */
     const int* pool_arg;   /* (rows/ns, c) arg-max row offsets from gspn_bnrelu_maxpool */
     int ns;
-    const float* mean;     /* c : batch mean */
-    const float* var;      /* c : biased batch variance */
-    const float* gamma;    /* c */
-    const float* beta;     /* c */
-    float eps;
-    const float* red;      /* 2c: output of gspn_bn_bwd_reduce */
-    int use_bn;            /* 0: layer without BN (y -> relu only); mean/var/gamma/red ignored */
-    int is_training;       /* 0: BN used moving statistics (constant w.r.t. the batch) */
-} gspn_bn_bwd_args;
+    const float* scale;    /* c : forward scale/shift (relu mask) */
+    const float* shift;
+    const float* cA;       /* c each: coefficients written by gspn_bn_bwd_coeffs */
+    const float* cB;
+    const float* cC;
+} gspn_dy_args;
 
-int gspn_bn_bwd_reduce(long rows, int c, const gspn_bn_bwd_args* a, float* red, float* dgamma, float* dbeta, void* stream);
-int gspn_mlp_bwd_data(long rows, int cin, int cout, const gspn_bn_bwd_args* a, const float* W, float* dX, int ldx, void* stream);
-int gspn_mlp_bwd_weight(long rows, int cin, int cout, const gspn_bn_bwd_args* a, const float* X, int ldx,
-                        const float* in_scale, const float* in_shift, float* dW, float* dbias, void* stream);
+/* red (2c doubles, caller zeroes): red[0:c] += sum(dyh), red[c:2c] += sum(dyh * (y-mean)*rstd) */
+int gspn_bn_bwd_reduce(long rows, int c, const gspn_dy_args* a, const float* mean, const float* var, float eps, double* red, void* stream);
+/* per-channel coefficients + parameter gradients from the reductions:
+ *   use_bn && is_training : cA=g*rstd, cB=-g*rstd^2*r1/R, cC=-g*rstd*(r0/R - mean*rstd*r1/R); dgamma=r1, dbeta=r0
+ *   use_bn && !is_training: cA=g*rstd(moving), cB=cC=0; dgamma=r1, dbeta=r0
+ *   !use_bn               : cA=1, cB=cC=0
+ * dbias = sum(dY) = cA*r0 + cB*sum(y) + cC*R   (sum(y) = mean*R).  Any output pointer may be NULL. */
+int gspn_bn_bwd_coeffs(long rows, int c, const double* red, const float* mean, const float* var, const float* gamma, float eps,
+                       int use_bn, int is_training, float* cA, float* cB, float* cC, float* dgamma, float* dbeta, float* dbias, void* stream);
+/* dX(rows,ldx)[:, :cin] = dY . W^T */
+int gspn_mlp_bwd_data(long rows, int cin, int cout, const gspn_dy_args* a, const float* W, float* dX, int ldx, void* stream);
+/* dW(cin,cout) = act(X)^T . dY   (zeroed here, then accumulated with fp32 atomics over row chunks) */
+int gspn_mlp_bwd_weight(long rows, int cin, int cout, const gspn_dy_args* a, const float* X, int ldx,
+                        const float* in_scale, const float* in_shift, float* dW, void* stream);
 
 int gspn_fill_zero(void* ptr, long bytes, void* stream);
 

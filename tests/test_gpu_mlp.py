@@ -1,0 +1,131 @@
+"""GPU parity of the MFMA shared-MLP stack vs the fp64 restatement (oracle/mlp_ref.py).
+Tolerance: 1e-5 relative (BASELINE.json north_star) on outputs; gradients 1e-4 of their scale
+(the reference's own gradient tests use 1e-4: tf_grouping_op_test.py:27, tf_interpolate_op_test.py:21)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import mlp_ref as R
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(a, b):
+    a = a.double().cpu()
+    b = b.double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def make_params(chans, cin, seed, bn=True):
+    g = torch.Generator().manual_seed(seed)
+    ps = []
+    for c in chans:
+        lim = (6.0 / (cin + c)) ** 0.5
+        p = {"w": (torch.rand(cin, c, generator=g, dtype=torch.float64) * 2 - 1) * lim,
+             "b": (torch.rand(c, generator=g, dtype=torch.float64) - 0.5) * 0.2, "bn": bn}
+        if bn:
+            p.update(gamma=torch.rand(c, generator=g, dtype=torch.float64) + 0.5, beta=(torch.rand(c, generator=g, dtype=torch.float64) - 0.5),
+                     moving_mean=torch.zeros(c, dtype=torch.float64), moving_var=torch.ones(c, dtype=torch.float64))
+        ps.append(p)
+        cin = c
+    return ps
+
+
+def to_layers(ps):
+    from gspn_amd.mlp import LayerParams
+    layers = []
+    for p in ps:
+        f = lambda t, rg=True: torch.nn.Parameter(t.float().cuda(), requires_grad=rg)
+        if p["bn"]:
+            layers.append(LayerParams(f(p["w"]), f(p["b"]), True, f(p["beta"]), f(p["gamma"]),
+                                      p["moving_mean"].float().cuda(), p["moving_var"].float().cuda()))
+        else:
+            layers.append(LayerParams(f(p["w"]), f(p["b"]), False))
+    return layers
+
+
+@pytest.mark.parametrize("rows,ld,cin,chans,ns", [
+    (4096, 6, 6, [32, 32, 64], 32),        # SA1-shaped
+    (2048, 67, 67, [64, 64, 128], 32),     # SA2-shaped
+    (1024, 131, 131, [128, 128, 256], 32), # SA3-shaped
+    (768, 384, 384, [256, 128], None),     # FP1-shaped
+    (1000, 67, 67, [64, 64, 64], None),    # FP3-shaped, ragged rows
+    (512, 8, 5, [20], 16),                 # padded pitch, odd channel counts
+    (130, 3, 3, [7, 33], 2),
+])
+@pytest.mark.parametrize("training", [True, False])
+def test_mlp_stack_forward_backward(rows, ld, cin, chans, ns, training):
+    from gspn_amd.mlp import mlp_stack
+    g = torch.Generator().manual_seed(rows + cin)
+    x64 = torch.randn(rows, ld, generator=g, dtype=torch.float64)
+    x64[:, cin:] = 0
+    ps = make_params(chans, cin, seed=cin)
+    if not training:
+        for p in ps:
+            p["moving_mean"] = torch.randn(p["w"].shape[1], generator=g, dtype=torch.float64) * 0.1
+            p["moving_var"] = torch.rand(p["w"].shape[1], generator=g, dtype=torch.float64) + 0.5
+    layers = to_layers(ps)
+    x = x64.float().cuda().requires_grad_(True)
+    out = mlp_stack(x, cin, layers, training, 0.7, pool_ns=ns)
+
+    xr = x64[:, :cin].clone().requires_grad_(True)
+    for p in ps:
+        for k in ("w", "b", "gamma", "beta"):
+            p[k] = p[k].clone().requires_grad_(True)
+    ref, moving = R.stack(xr, ps, training, 0.7, ns)
+    assert out.shape == ref.shape
+    assert rel_err(out, ref) < 1e-5
+    if training:
+        for lp, (mm, mv) in zip(layers, moving):
+            assert rel_err(lp.moving_mean, mm) < 1e-5 and rel_err(lp.moving_variance, mv) < 1e-5
+
+    go = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+    ref.backward(go)
+    out.backward(go.float().cuda())
+    tol = 1e-4
+    assert rel_err(x.grad[:, :cin], xr.grad) < tol
+    for lp, p in zip(layers, ps):
+        assert rel_err(lp.weights.grad, p["w"].grad) < tol
+        assert rel_err(lp.gamma.grad, p["gamma"].grad) < tol
+        assert rel_err(lp.beta.grad, p["beta"].grad) < tol
+        # bias feeds a batch-normalised layer: its true gradient is ~0 in training mode
+        scale = max(float(p["w"].grad.abs().max()), 1e-6)
+        assert float((lp.biases.grad.double().cpu() - p["b"].grad).abs().max()) < tol * max(scale, float(p["b"].grad.abs().max()))
+
+
+def test_mlp_stack_no_bn():
+    from gspn_amd.mlp import mlp_stack
+    g = torch.Generator().manual_seed(3)
+    rows, cin = 640, 19
+    x64 = torch.randn(rows, cin, generator=g, dtype=torch.float64)
+    ps = make_params([24, 40], cin, 5, bn=False)
+    layers = to_layers(ps)
+    x = x64.float().cuda().requires_grad_(True)
+    out = mlp_stack(x, cin, layers, True, None, pool_ns=4)
+    xr = x64.clone().requires_grad_(True)
+    for p in ps:
+        for k in ("w", "b"):
+            p[k] = p[k].clone().requires_grad_(True)
+    ref, _ = R.stack(xr, ps, True, 0.9, 4)
+    assert rel_err(out, ref) < 1e-5
+    go = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+    ref.backward(go)
+    out.backward(go.float().cuda())
+    assert rel_err(x.grad, xr.grad) < 1e-4
+    for lp, p in zip(layers, ps):
+        assert rel_err(lp.weights.grad, p["w"].grad) < 1e-4
+        assert rel_err(lp.biases.grad, p["b"].grad) < 1e-4
+
+
+def test_mfma_layout_is_not_transposed():
+    """A = I-like with an asymmetric W: catches a row/col swap in the accumulator store"""
+    from gspn_amd.mlp import mlp_stack, LayerParams
+    rows, cin, cout = 128, 32, 64
+    x = torch.zeros(rows, cin)
+    for r in range(rows):
+        x[r, r % cin] = 1.0 + r
+    w = torch.arange(cin * cout, dtype=torch.float32).view(cin, cout) / 100.0
+    lp = LayerParams(w.cuda(), torch.zeros(cout).cuda(), False)
+    out = mlp_stack(x.cuda(), cin, [lp], False, None, None).cpu()
+    ref = torch.relu(x.double() @ w.double())
+    assert rel_err(out, ref) < 1e-6
