@@ -75,6 +75,8 @@ def lib():
             fn = getattr(h, name)          # AttributeError if the ABI and the binding drift apart
             fn.argtypes = args
             fn.restype = _I
+        h.gspn_ball_threshold.argtypes = [_F]
+        h.gspn_ball_threshold.restype = _F
         _lib = h
     return _lib
 

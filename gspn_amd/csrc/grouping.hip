@@ -82,6 +82,9 @@ static float ball_threshold(float radius) {
     return t;
 }
 
+// exported so the host-side threshold search can be tested without a GPU
+extern "C" float gspn_ball_threshold(float radius) { return ball_threshold(radius); }
+
 extern "C" int gspn_queryballpoint(int b, int n, int m, float radius, int nsample, const float* xyz1, const float* xyz2,
                                    int* idx, int* pts_cnt, void* stream) {
     if (!(radius > 0.0f) || nsample <= 0) return GSPN_ERR_ARG;        // tf_grouping.cpp:101,104

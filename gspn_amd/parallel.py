@@ -1,0 +1,68 @@
+"""Data parallelism over scenes.  The reference is single-GPU; scenes are
+independent in every kernel, so rank r simply owns scenes [r*B/W, (r+1)*B/W) and the only exchange
+is ONE flat-bucket all-reduce of the MLP parameter gradients (~1 MB for the SA/FP stack: latency
+bound, so a single bucket) over RCCL/xGMI via torch.distributed (backend 'nccl' == RCCL on ROCm;
+'gloo' on CPU for tests).  Batch-norm statistics stay per replica (standard DP)."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """One process per GPU, launched by torch.distributed.run: RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* from the env."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend=backend or ("nccl" if torch.cuda.is_available() else "gloo"), rank=rank, world_size=world)
+    return rank, local, world
+
+
+def shard_range(total, rank, world):
+    """contiguous scene shard of rank `rank` (sizes differ by at most one)"""
+    base, rem = divmod(total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class FlatGradBucket:
+    """Flat fp32 bucket over a fixed parameter list: pack grads -> one all_reduce(SUM) -> /world -> unpack."""
+
+    def __init__(self, params):
+        self.params = [p for p in params]
+        self.sizes = [p.numel() for p in self.params]
+        n = sum(self.sizes)
+        dev = self.params[0].device if self.params else torch.device("cpu")
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+
+    def pack(self):
+        off = 0
+        for p, s in zip(self.params, self.sizes):
+            if p.grad is None:
+                self.flat[off:off + s].zero_()
+            else:
+                self.flat[off:off + s].copy_(p.grad.reshape(-1))
+            off += s
+        return self.flat
+
+    def unpack(self):
+        off = 0
+        for p, s in zip(self.params, self.sizes):
+            g = self.flat[off:off + s].view_as(p)
+            if p.grad is None:
+                p.grad = g.clone()
+            else:
+                p.grad.copy_(g)
+            off += s
+
+    def all_reduce_mean(self):
+        self.pack()
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            self.flat.div_(dist.get_world_size())
+        self.unpack()
+        return self.flat

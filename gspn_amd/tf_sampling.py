@@ -4,6 +4,10 @@ import torch
 
 from . import _lib as L
 
+# bench.py sets this to a list to collect (start_event, end_event, b, n, m) around every FPS launch,
+# recorded on the stream the kernel is launched on (roofline.achieved is measured live from these)
+PROFILE = None
+
 
 def farthest_point_sample(npoint, inp):
     """tf_sampling.py:48-57 -- inp (batch, ndataset, 3) float32 -> (batch, npoint) int32.
@@ -20,8 +24,15 @@ def farthest_point_sample(npoint, inp):
     if n > 32768:   # GSPN_FPS_RESIDENT_MAX: only the streaming kernel needs the (32,n) scratch of tf_sampling.cpp:115
         temp = torch.empty((min(b, 32), n), dtype=torch.float32, device=inp.device)
     with torch.cuda.device(inp.device):
+        ev = None
+        if PROFILE is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         L.check(L.lib().gspn_farthestpointsampling(b, n, npoint, L.ptr(inp), L.ptr(temp), L.ptr(out), L.stream()),
                 "farthest_point_sample")
+        if ev is not None:
+            ev[1].record()
+            PROFILE.append((ev[0], ev[1], b, n, npoint))
     return out
 
 

@@ -58,6 +58,11 @@ int gspn_probsample(int b, int n, int m, const float* inp_p, const float* inp_r,
 int gspn_queryballpoint(int b, int n, int m, float radius, int nsample, const float* xyz1, const float* xyz2,
                         int* idx, int* pts_cnt, void* stream);
 
+/* Host helper (no GPU work): the squared-distance threshold T the ball-query kernel compares against,
+ * i.e. the smallest float with sqrtf(T) >= radius, so that  s < T  <=>  max(sqrtf(s),1e-20f) < radius
+ * (tf_grouping_g.cu:27-28) bit-exactly; 0 when radius <= 1e-20f. */
+float gspn_ball_threshold(float radius);
+
 /* selectionSortLauncher(b,n,m,k,dist,outi,out)  tf_grouping.cpp:138, tf_grouping_g.cu:190-193 */
 int gspn_selectionsort(int b, int n, int m, int k, const float* dist, int* outi, float* out, void* stream);
 

@@ -1,0 +1,123 @@
+"""CPU suite 2: the C-ABI library loads and exports everything include/gspn_hip.h declares; host-side logic
+(argument validation, ball-query threshold search, variable scopes/initialisers, sharding, flat bucket) without a GPU."""
+import ctypes
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "gspn_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(?:int|float)\s+(gspn_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from gspn_amd import _lib
+    from gspn_amd import build
+    build.build()
+    h = ctypes.CDLL(_lib.LIB_PATH)
+    syms = header_symbols()
+    assert len(syms) >= 29
+    for s in syms:
+        assert hasattr(h, s), "libgspn_hip.so does not export %s" % s
+    bound = set(_lib.SIGNATURES) | {"gspn_ball_threshold"}
+    assert bound == set(syms), "binding table and header disagree: %s" % (bound ^ set(syms))
+    lib = _lib.lib()
+    assert lib.gspn_abi_version() == 1
+    assert lib.gspn_dist_policy() == 2        # same contraction policy as the oracle
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from gspn_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libgspn_hip.so")
+    with pytest.raises(_lib.GspnHipError):
+        _lib.lib()
+
+
+def test_ball_threshold_is_exact():
+    """s < T  <=>  max(sqrtf(s),1e-20f) < radius for floats around the boundary (tf_grouping_g.cu:27-28)"""
+    from gspn_amd import _lib
+    lib = _lib.lib()
+    rng = np.random.default_rng(0)
+    radii = list(rng.random(200).astype(np.float32) * 2) + [np.float32(0.1), np.float32(0.2), np.float32(1e-19), np.float32(3e19), np.float32(1e-10)]
+    for r in radii:
+        r = np.float32(r)
+        T = np.float32(lib.gspn_ball_threshold(ctypes.c_float(float(r))))
+        cand = [T]
+        lo, hi = T, T
+        for _ in range(4):
+            lo = np.nextafter(lo, np.float32(0), dtype=np.float32)
+            hi = np.nextafter(hi, np.float32(np.inf), dtype=np.float32)
+            cand += [lo, hi]
+        for s in cand:
+            ref = max(np.sqrt(np.float32(s), dtype=np.float32), np.float32(1e-20)) < r
+            assert (np.float32(s) < T) == bool(ref), (r, s, T)
+    assert lib.gspn_ball_threshold(ctypes.c_float(1e-21)) == 0.0
+    assert math.isinf(lib.gspn_ball_threshold(ctypes.c_float(float("inf"))))
+
+
+def test_argument_validation_mirrors_op_requires():
+    from gspn_amd import _lib
+    from gspn_amd.tf_grouping import query_ball_point, select_top_k
+    from gspn_amd.tf_sampling import farthest_point_sample
+    x = torch.zeros(1, 8, 3)
+    with pytest.raises(ValueError):
+        farthest_point_sample(0, x)                     # tf_sampling.cpp:99
+    with pytest.raises(ValueError):
+        query_ball_point(0.0, 4, x, x)                  # tf_grouping.cpp:101
+    with pytest.raises(ValueError):
+        query_ball_point(0.1, 0, x, x)                  # tf_grouping.cpp:104
+    with pytest.raises(ValueError):
+        select_top_k(0, torch.zeros(1, 2, 3))           # tf_grouping.cpp:143
+    with pytest.raises(_lib.GspnHipError):              # CPU tensors never fall back to a CPU path
+        farthest_point_sample(4, x)
+    with pytest.raises(ValueError):
+        farthest_point_sample(4, torch.zeros(1, 8, 3, dtype=torch.float64))
+    # the ABI itself rejects bad sizes without touching the device
+    lib = _lib.lib()
+    assert lib.gspn_farthestpointsampling(1, 0, 4, None, None, None, None) == -1
+    assert lib.gspn_queryballpoint(1, 8, 2, ctypes.c_float(-1.0), 4, None, None, None, None, None) == -1
+    assert lib.gspn_mlp_fwd(8, 4, 4, None, 2, None, None, None, None, None, 4, None, None) == -1      # ldx < cin
+
+
+def test_variable_store_scopes_and_xavier():
+    from gspn_amd import tf_util
+    store = tf_util.set_variable_store(tf_util.VariableStore(device=torch.device("cpu"), seed=3))
+    lp = tf_util._layer_params('conv0', 6, 64, [1, 1, 6, 64], True, 1e-3, None, True)
+    assert set(store.vars) == {'conv0/weights', 'conv0/biases', 'conv0/bn/beta', 'conv0/bn/gamma', 'conv0/bn/moving_mean', 'conv0/bn/moving_variance'}
+    w = store.vars['conv0/weights']
+    lim = math.sqrt(6.0 / (6 + 64))
+    assert w.shape == (1, 1, 6, 64) and float(w.abs().max()) <= lim and float(w.abs().max()) > 0.8 * lim
+    assert float(store.vars['conv0/biases'].abs().max()) == 0 and float(store.vars['conv0/bn/gamma'].min()) == 1
+    assert not store.vars['conv0/bn/moving_mean'].requires_grad and store.vars['conv0/bn/moving_variance'].mean() == 1
+    assert lp.weights.shape == (6, 64) and lp.weights.data_ptr() == w.data_ptr()      # the GEMM sees the same storage
+    with tf_util.variable_scope('a'):
+        with tf_util.variable_scope('b'):
+            v = tf_util.get_variable('x', (3,), tf_util.constant_initializer(2.0))
+    assert 'a/b/x' in store.vars and v is tf_util.get_variable_store().vars['a/b/x']
+    lp2 = tf_util._layer_params('conv0', 6, 64, [1, 1, 6, 64], True, 1e-3, None, True)     # reuse, not re-create
+    assert lp2.weights.data_ptr() == w.data_ptr() and len(store.parameters()) == 5
+    with pytest.raises(ValueError):
+        tf_util._layer_params('conv0', 7, 64, [1, 1, 7, 64], True, 1e-3, None, True)
+
+
+def test_shard_range_and_bucket():
+    from gspn_amd.parallel import FlatGradBucket, shard_range
+    for total in (8, 32, 64, 13):
+        for world in (1, 2, 4, 8):
+            r = [shard_range(total, k, world) for k in range(world)]
+            assert r[0][0] == 0 and r[-1][1] == total and all(a[1] == b[0] for a, b in zip(r, r[1:]))
+            assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1
+    ps = [torch.nn.Parameter(torch.zeros(3, 4)), torch.nn.Parameter(torch.zeros(5))]
+    ps[0].grad = torch.arange(12.).view(3, 4)
+    bk = FlatGradBucket(ps)
+    flat = bk.all_reduce_mean()                        # world 1: identity
+    assert flat.numel() == 17 and float(flat[:12].sum()) == 66 and float(ps[1].grad.abs().sum()) == 0

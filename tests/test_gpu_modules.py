@@ -1,0 +1,135 @@
+"""GPU parity of the composed SA / FP modules (utils/pointnet_util.py) against the oracle composition:
+C oracle for FPS / gather / ball query / grouping / 3-NN / interpolation, fp64 restatement for the MLP."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import mlp_ref as R
+from oracle import oracle as O
+from tests import data as D
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(a, b):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def fresh_store(seed=1234):
+    from gspn_amd import tf_util
+    return tf_util.set_variable_store(tf_util.VariableStore(seed=seed))
+
+
+def ref_params(store, scope, names):
+    ps = []
+    for nm in names:
+        g = lambda k: store.vars["%s/%s/%s" % (scope, nm, k)].detach().double().cpu()
+        w = g("weights")
+        ps.append({"w": w.view(w.shape[-2], w.shape[-1]).clone().requires_grad_(True), "b": g("biases").clone().requires_grad_(True),
+                   "gamma": g("bn/gamma").clone().requires_grad_(True), "beta": g("bn/beta").clone().requires_grad_(True),
+                   "moving_mean": g("bn/moving_mean"), "moving_var": g("bn/moving_variance"), "bn": True})
+    return ps
+
+
+@pytest.mark.parametrize("kind,b,n,c,npoint,radius,ns,mlp", [
+    ("U", 2, 4096, 3, 512, 0.2, 32, [32, 32, 64]),
+    ("D", 2, 2048, 64, 256, 0.4, 32, [64, 64, 128]),
+    ("U", 1, 1000, 0, 100, 0.3, 16, [16, 24]),
+])
+def test_sa_module_matches_oracle(kind, b, n, c, npoint, radius, ns, mlp):
+    from gspn_amd import tf_util
+    from gspn_amd.pointnet_util import pointnet_sa_module
+    store = fresh_store()
+    xyz = D.batch(kind, b, n)
+    rng = np.random.default_rng(7)
+    pts = rng.random((b, n, c)).astype(np.float32) if c else None
+    txyz = torch.from_numpy(xyz).cuda()
+    tpts = torch.from_numpy(pts).cuda().requires_grad_(True) if c else None
+    new_xyz, new_points, idx = pointnet_sa_module(txyz, tpts, npoint, radius, ns, mlp, None, False, True, 0.5, 'layer1')
+    # snapshot initial params before they are touched (moving stats were already updated in place: rebuild from init)
+    # ---- oracle composition ----
+    ridx_fps = O.farthest_point_sample(npoint, xyz)
+    rnew = O.gather_point(xyz, ridx_fps)
+    ridx, _ = O.query_ball_point(radius, ns, xyz, rnew)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ridx)
+    np.testing.assert_array_equal(new_xyz.cpu().numpy(), rnew)
+    gx = O.group_point(xyz, ridx) - rnew[:, :, None, :]
+    rows = gx if c == 0 else np.concatenate([gx, O.group_point(pts, ridx)], -1)
+    ps = ref_params(store, 'layer1', ['conv%d' % i for i in range(len(mlp))])
+    for p in ps:   # undo the in-place moving-average update for the reference run
+        p["moving_mean"] = torch.zeros_like(p["moving_mean"])
+        p["moving_var"] = torch.ones_like(p["moving_var"])
+    x64 = torch.from_numpy(rows.reshape(-1, rows.shape[-1])).double()
+    pts64 = None
+    if c:
+        pts64 = torch.from_numpy(pts).double().requires_grad_(True)
+        gidx = torch.from_numpy(ridx.astype(np.int64))
+        bi = torch.arange(b)[:, None, None].expand_as(gidx)
+        x64 = torch.cat([torch.from_numpy(gx).double(), pts64[bi, gidx]], -1).reshape(-1, 3 + c)
+    ref, moving = R.stack(x64, ps, True, 0.5, ns)
+    ref = ref.view(b, npoint, mlp[-1])
+    assert rel_err(new_points, ref) < 1e-5
+    g = torch.from_numpy(rng.standard_normal(ref.shape)).double()
+    ref.backward(g)
+    new_points.backward(g.float().cuda())
+    for i, p in enumerate(ps):
+        wgrad = store.vars['layer1/conv%d/weights' % i].grad
+        assert rel_err(wgrad.view(p["w"].shape), p["w"].grad) < 1e-4
+        assert rel_err(store.vars['layer1/conv%d/bn/gamma' % i].grad, p["gamma"].grad) < 1e-4
+        assert rel_err(store.vars['layer1/conv%d/bn/moving_mean' % i], moving[i][0]) < 1e-5
+    if c:
+        assert rel_err(tpts.grad, pts64.grad) < 1e-4
+
+
+@pytest.mark.parametrize("b,n1,n2,c1,c2,mlp", [(2, 2048, 512, 64, 128, [128, 64]), (1, 700, 100, 0, 32, [16]), (2, 512, 128, 128, 256, [])])
+def test_fp_module_matches_oracle(b, n1, n2, c1, c2, mlp):
+    from gspn_amd.pointnet_util import pointnet_fp_module
+    store = fresh_store(99)
+    xyz1 = D.batch("D", b, n1, 3)
+    xyz2 = O.gather_point(xyz1, O.farthest_point_sample(n2, xyz1))
+    rng = np.random.default_rng(17)
+    p1 = rng.standard_normal((b, n1, c1)).astype(np.float32) if c1 else None
+    p2 = rng.standard_normal((b, n2, c2)).astype(np.float32)
+    t1 = torch.from_numpy(p1).cuda().requires_grad_(True) if c1 else None
+    t2 = torch.from_numpy(p2).cuda().requires_grad_(True)
+    out = pointnet_fp_module(torch.from_numpy(xyz1).cuda(), torch.from_numpy(xyz2).cuda(), t1, t2, mlp, True, 0.5, 'fa')
+    rd, ri = O.three_nn(xyz1, xyz2)
+    w64 = R.fp_weights(torch.from_numpy(rd).double())
+    p2r = torch.from_numpy(p2).double().requires_grad_(True)
+    gi = torch.from_numpy(ri.astype(np.int64))
+    bi = torch.arange(b)[:, None, None].expand_as(gi)
+    interp = (p2r[bi, gi] * w64[..., None]).sum(2)
+    p1r = torch.from_numpy(p1).double().requires_grad_(True) if c1 else None
+    cat = torch.cat([interp, p1r], 2) if c1 else interp
+    if mlp:
+        ps = ref_params(store, 'fa', ['conv_%d' % i for i in range(len(mlp))])
+        for p in ps:
+            p["moving_mean"] = torch.zeros_like(p["moving_mean"])
+            p["moving_var"] = torch.ones_like(p["moving_var"])
+        ref, _ = R.stack(cat.reshape(b * n1, -1), ps, True, 0.5, None)
+        ref = ref.view(b, n1, mlp[-1])
+    else:
+        ref = cat
+    assert rel_err(out, ref) < 1e-5
+    g = torch.from_numpy(rng.standard_normal(ref.shape)).double()
+    ref.backward(g)
+    out.backward(g.float().cuda())
+    assert rel_err(t2.grad, p2r.grad) < 1e-4
+    if c1:
+        assert rel_err(t1.grad, p1r.grad) < 1e-4
+
+
+def test_fea_extractor_runs_and_backprops():
+    """BASELINE config 3 graph at a reduced cloud size: shapes, finiteness, every parameter gets a gradient"""
+    from gspn_amd import tf_util
+    from gspn_amd.fea_extractor import pn2_fea_extractor
+    store = fresh_store(5)
+    xyz = torch.from_numpy(D.batch("U", 2, 8192)).cuda()
+    col = torch.rand(2, 8192, 3, device="cuda")
+    out = pn2_fea_extractor(xyz, col, 'fea', True, 0.5)
+    assert out.shape == (2, 8192, 64) and torch.isfinite(out).all()
+    out.square().mean().backward()
+    for name, p in store.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), name
