@@ -49,10 +49,8 @@ SIGNATURES = {
     "gspn_bn_finalize": [_L, _I, _P, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P],
     "gspn_bnrelu_maxpool": [_L, _I, _I, _P, _I, _P, _P, _P, _P, _P],
     "gspn_bnrelu_apply": [_L, _I, _P, _I, _P, _P, _P, _I, _P],
-    "gspn_bn_bwd_reduce": [_L, _I, _c.POINTER(DyArgs), _P, _P, _F, _P, _P],
-    "gspn_bn_bwd_coeffs": [_L, _I, _P, _P, _P, _P, _F, _I, _I, _P, _P, _P, _P, _P, _P, _P],
+    "gspn_mlp_bwd_wgrad": [_L, _I, _I, _c.POINTER(DyArgs), _P, _I, _P, _P, _P, _P, _P, _F, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "gspn_mlp_bwd_data": [_L, _I, _I, _c.POINTER(DyArgs), _P, _P, _I, _P],
-    "gspn_mlp_bwd_weight": [_L, _I, _I, _c.POINTER(DyArgs), _P, _I, _P, _P, _P, _P],
     "gspn_fill_zero": [_P, _L, _P],
 }
 
@@ -77,6 +75,10 @@ def lib():
             fn.restype = _I
         h.gspn_ball_threshold.argtypes = [_F]
         h.gspn_ball_threshold.restype = _F
+        h.gspn_mlp_bwd_work_bytes.argtypes = [_L, _I, _I]
+        h.gspn_mlp_bwd_work_bytes.restype = _L
+        h.gspn_mlp_fwd_stats_bytes.argtypes = [_L, _I]
+        h.gspn_mlp_fwd_stats_bytes.restype = _L
         _lib = h
     return _lib
 

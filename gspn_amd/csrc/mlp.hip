@@ -8,10 +8,14 @@
 // TF32/xf32 on gfx950 and the 1e-5 parity target rules out bf16):
 //     * the previous layer's BN+ReLU is applied while the A operand is staged into LDS,
 //     * bias and the per-channel sum / sum-of-squares for training-mode BN come out of the epilogue,
-//     * backward never materialises dY: the BN/ReLU backward is folded into the operand staging of
-//       the two backward GEMMs (dX = dY.W^T, dW = A^T.dY).
+//     * backward is two passes per layer and never materialises dY:
+//         pass A  reads (X, Y, dz) once and produces the BN reductions r0, r1 AND the raw weight-gradient
+//                 products G1 = A^T.dyh, Gx = A^T.xhat, g3 = A^T.1   (dW is linear in them:
+//                 dW = cA (.) (G1 - r0/R g3 1^T - r1/R (.) Gx), so no coefficient is needed up front);
+//         pass B  dX = dY.W^T with dY rebuilt on the fly from the coefficients.
 // Rows are the long dimension (up to 524288), channels are 6..384: every GEMM is tall and skinny and
-// HBM-bound, so the design goal is one read + one write per activation, not MFMA occupancy.
+// HBM-bound, so the design goal is one read + one write per activation: float4 global loads, register
+// prefetch of the next K chunk under the MFMAs of the current one, persistent row tiles.
 //
 // MFMA 32x32x2 f32 fragment layout (wave64):  A: lane l holds A[i=l&31][k=l>>5];  B: lane l holds
 // B[k=l>>5][j=l&31];  C/D: 16 registers, reg r -> row (r&3)+8*(r>>2)+4*(l>>5), col l&31.
@@ -21,112 +25,247 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define TM 128          // rows of C per workgroup (4 waves x 32)
 #define TK 32           // K chunk staged per iteration
-#define LDA (TK + 1)    // sA row pitch (row-major [TM][TK]): odd pitch -> conflict-free column reads
+#define LDT 129         // pitch of a K-major LDS tile [TK][128]: == 1 (mod 32) -> transposing writes and column reads conflict-free
 
 __device__ __forceinline__ int c_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
-__device__ __forceinline__ float act_in(float v, bool act, float sc, float sh) {
-    if (act) { v = v * sc + sh; v = v > 0.f ? v : 0.f; }     // relu(x*scale+shift), two roundings like tf.nn.batch_normalization
+__device__ __forceinline__ float act1(float v, bool act, float sc, float sh) {
+    if (act) { v = v * sc + sh; v = v > 0.f ? v : 0.f; }     // relu(x*scale+shift): two roundings, like tf.nn.batch_normalization
     return v;
 }
 
-// dY element from (y, dz) and the per-channel constants  (see gspn_dy_args in gspn_hip.h)
-struct DyChan { float sc, sh, cA, cB, cC; };
-__device__ __forceinline__ float dy_elem(float y, float dz, const DyChan& c) {
-    const float z = y * c.sc + c.sh;
-    const float dyh = z > 0.f ? dz : 0.f;
-    return c.cA * dyh + c.cB * y + c.cC;
+#define MAXCH 512       // per-channel constants are staged in LDS for layers up to this many channels
+// fill dst[0..MAXCH) with src[0..n) (or `dflt` when src is NULL / beyond n); callers __syncthreads() afterwards
+__device__ __forceinline__ void stage_chan(float* dst, const float* __restrict__ src, int n, float dflt) {
+    for (int i = threadIdx.x; i < MAXCH; i += blockDim.x) dst[i] = (src && i < n) ? src[i] : dflt;
 }
-__device__ __forceinline__ float dz_at(const gspn_dy_args& a, long row, int col, int c) {
-    if (a.dZ) return a.dZ[row * a.ldz + col];
+__device__ __forceinline__ float4 lds4(const float* p, int k) {      // 4 consecutive constants, index clamped
+    return make_float4(p[min(k, MAXCH - 1)], p[min(k + 1, MAXCH - 1)], p[min(k + 2, MAXCH - 1)], p[min(k + 3, MAXCH - 1)]);
+}
+
+// ---- 4-wide row-segment loads --------------------------------------------------------------------------------
+// load4_raw issues UNCONDITIONAL loads (indices clamped into the array) so that all of a thread's loads of one stage are
+// in flight together; validity is applied afterwards by mask4 (a select), never by a branch around the load.
+template <bool VEC>
+__device__ __forceinline__ float4 load4_raw(const float* __restrict__ src, long row, int ld, int k, int kvalid) {
+    if (VEC) {
+        const int kc = k < kvalid ? k : 0;                  // ld % 4 == 0, k % 4 == 0: an aligned quad inside the row
+        return *reinterpret_cast<const float4*>(src + row * ld + kc);
+    }
+    const float* p = src + row * ld;
+    const int last = kvalid - 1;
+    float4 v;
+    v.x = p[min(k + 0, last)];
+    v.y = p[min(k + 1, last)];
+    v.z = p[min(k + 2, last)];
+    v.w = p[min(k + 3, last)];
+    return v;
+}
+__device__ __forceinline__ float4 mask4(float4 v, int k, int kvalid, bool live) {
+    v.x = (live && k + 0 < kvalid) ? v.x : 0.f;
+    v.y = (live && k + 1 < kvalid) ? v.y : 0.f;
+    v.z = (live && k + 2 < kvalid) ? v.z : 0.f;
+    v.w = (live && k + 3 < kvalid) ? v.w : 0.f;
+    return v;
+}
+
+struct Chan4 { float4 sc, sh; };
+__device__ __forceinline__ Chan4 load_chan4(const float* scale, const float* shift, int k, int kvalid) {
+    Chan4 c;
+    c.sc = make_float4(1.f, 1.f, 1.f, 1.f);
+    c.sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (scale) {                                             // wave-uniform branch; clamped, unconditional loads inside
+        const int last = kvalid - 1;
+        c.sc.x = scale[min(k + 0, last)]; c.sh.x = shift[min(k + 0, last)];
+        c.sc.y = scale[min(k + 1, last)]; c.sh.y = shift[min(k + 1, last)];
+        c.sc.z = scale[min(k + 2, last)]; c.sh.z = shift[min(k + 2, last)];
+        c.sc.w = scale[min(k + 3, last)]; c.sh.w = shift[min(k + 3, last)];
+    }
+    return c;
+}
+// relu(x*scale+shift) on a raw quad, then validity mask
+__device__ __forceinline__ float4 act4(float4 v, bool act, const Chan4& c, int k, int kvalid, bool live) {
+    if (act) {
+        v.x = act1(v.x, true, c.sc.x, c.sh.x);
+        v.y = act1(v.y, true, c.sc.y, c.sh.y);
+        v.z = act1(v.z, true, c.sc.z, c.sh.z);
+        v.w = act1(v.w, true, c.sc.w, c.sh.w);
+    }
+    return mask4(v, k, kvalid, live);
+}
+
+// raw dz for (row, 4 channels): dense load, or (pooled) the arg-max offsets + pooled gradient; resolved by dz4_resolve
+struct DzRaw { float4 v; int4 arg; };
+template <bool VEC>
+__device__ __forceinline__ DzRaw dz4_raw(const gspn_dy_args& a, long row, int col, int c) {
+    DzRaw r;
+    r.arg = make_int4(0, 0, 0, 0);
+    if (a.dZ) {                                              // wave-uniform
+        r.v = load4_raw<VEC>(a.dZ, row, a.ldz, col, c);
+        return r;
+    }
     const long g = row / a.ns;
-    const int off = (int)(row - g * a.ns);
-    return a.pool_arg[g * c + col] == off ? a.dPool[g * c + col] : 0.f;
+    const int last = c - 1;
+    const int* ar = a.pool_arg + g * c;
+    const float* dp = a.dPool + g * c;
+    r.arg = make_int4(ar[min(col + 0, last)], ar[min(col + 1, last)], ar[min(col + 2, last)], ar[min(col + 3, last)]);
+    r.v = make_float4(dp[min(col + 0, last)], dp[min(col + 1, last)], dp[min(col + 2, last)], dp[min(col + 3, last)]);
+    return r;
+}
+__device__ __forceinline__ float4 dz4_resolve(const gspn_dy_args& a, const DzRaw& r, long row) {
+    if (a.dZ) return r.v;
+    const int off = (int)(row % a.ns);
+    float4 v;
+    v.x = r.arg.x == off ? r.v.x : 0.f;
+    v.y = r.arg.y == off ? r.v.y : 0.f;
+    v.z = r.arg.z == off ? r.v.z : 0.f;
+    v.w = r.arg.w == off ? r.v.w : 0.f;
+    return v;
 }
 
 // ============================================================================================
 // Forward:  Y = act(X).W + bias  (+ column sum / sumsq)
-// grid (row tiles [persistent], cout tiles of BN); block 256 = 4 waves, wave w owns rows w*32..+31
+// grid (persistent row tiles, cout tiles of BN); block 256 = 4 waves, wave w owns rows w*32..+31.
+// sA is K-major [TK][129] (written transposed from float4 row segments, 2 x ds_write2_b32),
+// sB is [TK][BN+4] (straight float4 copy of W rows).
 // ============================================================================================
-template <int BN>
+template <int BN, bool VEC>
 __global__ __launch_bounds__(256) void mlp_fwd_kernel(long rows, int cin, int cout, const float* __restrict__ X, int ldx,
                                                       const float* __restrict__ in_scale, const float* __restrict__ in_shift,
                                                       const float* __restrict__ W, const float* __restrict__ bias,
-                                                      float* __restrict__ Y, int ldy, double* __restrict__ stats) {
+                                                      float* __restrict__ Y, int ldy, float* __restrict__ stats) {
     constexpr int NT = BN / 32;
-    constexpr int LDB = BN + 1;
-    __shared__ float sA[TM * LDA];
-    __shared__ float sB[TK * LDB];
+    constexpr int LDB = BN + 4;
+    constexpr int BQ = BN / 4;                   // float4 per B row
+    constexpr int NB = (TK * BQ) / 256;          // B float4 per thread per chunk
+    __shared__ __attribute__((aligned(16))) float sA[TK * LDT];
+    __shared__ __attribute__((aligned(16))) float sB[TK * LDB];
     __shared__ float sRed[2 * 4 * BN];
+    __shared__ float sSc[MAXCH], sSh[MAXCH];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int n0 = blockIdx.y * BN;
     const bool act = in_scale != nullptr;
+    stage_chan(sSc, in_scale, cin, 1.f);
+    stage_chan(sSh, in_shift, cin, 0.f);
+    __syncthreads();
     const long ntiles = (rows + TM - 1) / TM;
+    const int nchunks = (cin + TK - 1) / TK;
+    const int kq = (t & 7) * 4;                  // this thread's k offset inside a chunk (fixed: 256 % 8 == 0)
+    const int arow = t >> 3;                     // + 32*i
 
     float csum[NT], csq[NT];
 #pragma unroll
     for (int i = 0; i < NT; ++i) { csum[i] = 0.f; csq[i] = 0.f; }
 
-    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    float4 ra[4], rb[NB];
+    long f_tile = 0;
+    int f_c = 0;
+    auto fetch = [&](long tile, int c) {              // raw loads only: everything stays in flight until commit()
+        f_tile = tile; f_c = c;
         const long m0 = tile * TM;
-        f32x16 acc[NT];
+        const int k = c * TK + kq;
 #pragma unroll
-        for (int i = 0; i < NT; ++i)
+        for (int i = 0; i < 4; ++i) {
+            const long row = m0 + arow + 32 * i;
+            ra[i] = load4_raw<VEC>(X, row < rows ? row : rows - 1, ldx, k, cin);
+        }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        for (int i = 0; i < NB; ++i) {
+            const int f = t + 256 * i;
+            const int kk = f / BQ, nq = (f - kk * BQ) * 4;
+            const int kg = c * TK + kk;
+            rb[i] = load4_raw<VEC>(W, kg < cin ? kg : cin - 1, cout, n0 + nq, cout);
+        }
+    };
+    auto commit = [&]() {
+        const long m0 = f_tile * TM;
+        const int k = f_c * TK + kq;
+        Chan4 ch;
+        ch.sc = lds4(sSc, k);
+        ch.sh = lds4(sSh, k);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float4 v = act4(ra[i], act, ch, k, cin, (m0 + arow + 32 * i) < rows);
+            float* d = sA + kq * LDT + arow + 32 * i;
+            d[0 * LDT] = v.x; d[1 * LDT] = v.y; d[2 * LDT] = v.z; d[3 * LDT] = v.w;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int f = t + 256 * i;
+            const int kk = f / BQ, nq = (f - kk * BQ) * 4;
+            *reinterpret_cast<float4*>(sB + kk * LDB + nq) = mask4(rb[i], n0 + nq, cout, (f_c * TK + kk) < cin);
+        }
+    };
 
-        for (int k0 = 0; k0 < cin; k0 += TK) {
-            __syncthreads();
-            // ---- stage A: 128 x 32, lanes run along k (coalesced row segments) ----
-            {
-                const int kk = t & 31;
-                const int k = k0 + kk;
-                float sc = 1.f, sh = 0.f;
-                if (act && k < cin) { sc = in_scale[k]; sh = in_shift[k]; }
+    float bv[NT];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int r = (t >> 5) + 8 * i;
-                    const long row = m0 + r;
-                    float v = 0.f;
-                    if (row < rows && k < cin) v = act_in(X[row * ldx + k], act, sc, sh);
-                    sA[r * LDA + kk] = v;
-                }
+    for (int nt = 0; nt < NT; ++nt) {
+        const int col = n0 + nt * 32 + (lane & 31);
+        bv[nt] = (bias && col < cout) ? bias[col] : 0.f;
+    }
+    f32x16 acc[NT];
+    // software pipeline over the flat sequence of (tile, chunk) steps of this block: each iteration issues the loads of
+    // step s, runs the MFMAs of step s-1 out of LDS while they fly, then commits step s to LDS.  No load result is live
+    // across a loop back-edge (hipcc otherwise shuffles loop-carried quads with v_mov right after the loads and waits).
+    const long my_tiles = blockIdx.x < ntiles ? (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    const long nsteps = my_tiles * nchunks;
+    for (long sidx = 0; sidx <= nsteps; ++sidx) {
+        if (sidx < nsteps) fetch(blockIdx.x + (sidx / nchunks) * gridDim.x, (int)(sidx % nchunks));
+        if (sidx > 0) {
+            const long ps = sidx - 1;
+            const long tile = blockIdx.x + (ps / nchunks) * gridDim.x;
+            const int c = (int)(ps % nchunks);
+            if (c == 0) {
+#pragma unroll
+                for (int i = 0; i < NT; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
             }
-            // ---- stage B: 32 x BN from W(cin,cout) ----
-            for (int e = t; e < TK * BN; e += 256) {
-                const int kk = e / BN, j = e - kk * BN;
-                const int k = k0 + kk, n = n0 + j;
-                sB[kk * LDB + j] = (k < cin && n < cout) ? W[(size_t)k * cout + n] : 0.f;
-            }
-            __syncthreads();
-            const int kmax = min(TK, (cin - k0 + 1) & ~1);
+            const int kmax = min(TK, (cin - c * TK + 1) & ~1);
             for (int kk = 0; kk < kmax; kk += 2) {
-                const float a = sA[(wave * 32 + (lane & 31)) * LDA + kk + (lane >> 5)];
+                const float a = sA[(kk + (lane >> 5)) * LDT + wave * 32 + (lane & 31)];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     const float b = sB[(kk + (lane >> 5)) * LDB + nt * 32 + (lane & 31)];
                     acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[nt], 0, 0, 0);
                 }
             }
-        }
-        // ---- epilogue: + bias, store, column statistics ----
+            if (c == nchunks - 1) {
+                // ---- epilogue: + bias, store, column statistics ----
+                const long m0 = tile * TM;
+                const bool full = m0 + TM <= rows;          // wave-uniform: full tiles store without per-row guards
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int col = n0 + nt * 32 + (lane & 31);
-            if (col < cout) {
-                const float bv = bias ? bias[col] : 0.f;
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int col = n0 + nt * 32 + (lane & 31);
+                    if (col < cout) {
+                        float* yp = Y + (m0 + wave * 32 + 4 * (lane >> 5)) * ldy + col;
+                        if (full) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const long row = m0 + wave * 32 + c_row(r, lane);
-                    if (row < rows) {
-                        const float y = acc[nt][r] + bv;
-                        Y[row * ldy + col] = y;
-                        csum[nt] += y;
-                        csq[nt] += y * y;
+                            for (int r = 0; r < 16; ++r) {
+                                const float y = acc[nt][r] + bv[nt];
+                                yp[(long)((r & 3) + 8 * (r >> 2)) * ldy] = y;
+                                csum[nt] += y;
+                                csq[nt] += y * y;
+                            }
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const long row = m0 + wave * 32 + c_row(r, lane);
+                                if (row < rows) {
+                                    const float y = acc[nt][r] + bv[nt];
+                                    Y[row * ldy + col] = y;
+                                    csum[nt] += y;
+                                    csq[nt] += y * y;
+                                }
+                            }
+                        }
                     }
                 }
             }
         }
+        __syncthreads();
+        if (sidx < nsteps) commit();
+        __syncthreads();
     }
     if (stats) {
         // lanes l and l+32 hold the same columns; then 4 waves -> LDS -> one double atomic per column
@@ -140,60 +279,86 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(long rows, int cin, int co
             }
         }
         __syncthreads();
+        // per-block partial sums (no hot-spot atomics): stats[blockIdx.x][2][cout]; gspn_bn_finalize adds them in double
+        float* ws = stats + (size_t)blockIdx.x * 2 * cout;
         for (int j = t; j < BN; j += 256) {
             const int col = n0 + j;
             if (col < cout) {
-                double s = 0.0, q = 0.0;
-                for (int w = 0; w < 4; ++w) { s += (double)sRed[(w * 2 + 0) * BN + j]; q += (double)sRed[(w * 2 + 1) * BN + j]; }
-                atomicAdd(stats + col, s);
-                atomicAdd(stats + cout + col, q);
+                float s = 0.f, q = 0.f;
+                for (int w = 0; w < 4; ++w) { s += sRed[(w * 2 + 0) * BN + j]; q += sRed[(w * 2 + 1) * BN + j]; }
+                ws[col] = s;
+                ws[cout + col] = q;
             }
         }
     }
 }
 
-static inline unsigned row_grid(long rows, int ytiles) {
+static inline unsigned row_grid(long rows, int ytiles, int per_cu) {
     const long ntiles = (rows + TM - 1) / TM;
-    long cap = 256L * 6 / (ytiles > 0 ? ytiles : 1);     // a few workgroups per CU in total
+    long cap = 256L * per_cu / (ytiles > 0 ? ytiles : 1);
     if (cap < 64) cap = 64;
     return (unsigned)(ntiles < cap ? ntiles : cap);
 }
+// number of row-blocks (= partial-statistics rows) the forward launch of a (rows, cout) layer uses
+static inline unsigned fwd_blocks(long rows, int cout) { return row_grid(rows, cout <= 64 ? 1 : (cout + 127) / 128, 4); }
+extern "C" long gspn_mlp_fwd_stats_bytes(long rows, int cout) {
+    if (rows < 0 || cout <= 0) return GSPN_ERR_ARG;
+    return (long)sizeof(float) * 2 * cout * (long)fwd_blocks(rows > 0 ? rows : 1, cout);
+}
+static inline bool vec_ok(const void* p, int ld) { return (ld % 4 == 0) && (((uintptr_t)p) % 16 == 0); }
 
 extern "C" int gspn_mlp_fwd(long rows, int cin, int cout, const float* X, int ldx, const float* in_scale, const float* in_shift,
-                            const float* W, const float* bias, float* Y, int ldy, double* stats, void* stream) {
+                            const float* W, const float* bias, float* Y, int ldy, float* stats, void* stream) {
     if (rows < 0 || cin <= 0 || cout <= 0 || ldx < cin || ldy < cout) return GSPN_ERR_ARG;
     if ((in_scale == nullptr) != (in_shift == nullptr)) return GSPN_ERR_ARG;
+    if (cin > MAXCH || cout > MAXCH) return GSPN_ERR_UNSUPPORTED;
     if (rows == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    if (cout <= 32) {
-        hipLaunchKernelGGL(mlp_fwd_kernel<32>, dim3(row_grid(rows, 1), 1), dim3(256), 0, st, rows, cin, cout, X, ldx, in_scale, in_shift, W, bias, Y, ldy, stats);
-    } else if (cout <= 64) {
-        hipLaunchKernelGGL(mlp_fwd_kernel<64>, dim3(row_grid(rows, 1), 1), dim3(256), 0, st, rows, cin, cout, X, ldx, in_scale, in_shift, W, bias, Y, ldy, stats);
-    } else {
-        const int yt = (cout + 127) / 128;
-        hipLaunchKernelGGL(mlp_fwd_kernel<128>, dim3(row_grid(rows, yt), yt), dim3(256), 0, st, rows, cin, cout, X, ldx, in_scale, in_shift, W, bias, Y, ldy, stats);
-    }
+    const bool v = vec_ok(X, ldx) && vec_ok(W, cout);
+#define FWD_LAUNCH(BN_, V_, YT_)                                                                                                   \
+    hipLaunchKernelGGL((mlp_fwd_kernel<BN_, V_>), dim3(row_grid(rows, YT_, 4), YT_), dim3(256), 0, st, rows, cin, cout, X, ldx, \
+                       in_scale, in_shift, W, bias, Y, ldy, stats)
+    if (cout <= 32) { if (v) FWD_LAUNCH(32, true, 1); else FWD_LAUNCH(32, false, 1); }
+    else if (cout <= 64) { if (v) FWD_LAUNCH(64, true, 1); else FWD_LAUNCH(64, false, 1); }
+    else { const int yt = (cout + 127) / 128; if (v) FWD_LAUNCH(128, true, yt); else FWD_LAUNCH(128, false, yt); }
+#undef FWD_LAUNCH
     return gspn_launch_status();
 }
 
 // ============================================================================================
 // BN finalize / element-wise tails
 // ============================================================================================
-__global__ void bn_finalize_kernel(long rows, int c, const double* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   float eps, float decay, int is_training, float* __restrict__ moving_mean, float* __restrict__ moving_var,
-                                   float* __restrict__ mean, float* __restrict__ var, float* __restrict__ scale, float* __restrict__ shift) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+// wave-wide sum of a double (all lanes get the total)
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s, 64);
+    return v;
+}
+// one WAVE per channel: 64 lanes stride over the forward's per-block partials (double accumulation), then finalise
+__global__ __launch_bounds__(256) void bn_finalize_kernel(long rows, int c, const float* __restrict__ stats, int nparts, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps, float decay, int is_training,
+                                                          float* __restrict__ moving_mean, float* __restrict__ moving_var,
+                                                          float* __restrict__ mean, float* __restrict__ var, float* __restrict__ scale, float* __restrict__ shift) {
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= c) return;
     double mu, v;
     if (is_training) {
-        mu = stats[j] / (double)rows;
-        v = stats[c + j] / (double)rows - mu * mu;         // biased variance (tf.nn.moments)
+        double a0 = 0.0, a1 = 0.0;
+        for (int p = lane; p < nparts; p += 64) { a0 += (double)stats[(size_t)p * 2 * c + j]; a1 += (double)stats[(size_t)p * 2 * c + c + j]; }
+        a0 = wave_sum_f64(a0);
+        a1 = wave_sum_f64(a1);
+        mu = a0 / (double)rows;
+        v = a1 / (double)rows - mu * mu;                   // biased variance (tf.nn.moments)
         if (v < 0.0) v = 0.0;
-        if (moving_mean) moving_mean[j] = (float)((double)moving_mean[j] * decay + mu * (1.0 - (double)decay));
-        if (moving_var) moving_var[j] = (float)((double)moving_var[j] * decay + v * (1.0 - (double)decay));
     } else {
         mu = moving_mean[j];
         v = moving_var[j];
+    }
+    if (lane != 0) return;
+    if (is_training) {
+        if (moving_mean) moving_mean[j] = (float)((double)moving_mean[j] * decay + mu * (1.0 - (double)decay));
+        if (moving_var) moving_var[j] = (float)((double)moving_var[j] * decay + v * (1.0 - (double)decay));
     }
     const float g = gamma ? gamma[j] : 1.f;
     const float be = beta ? beta[j] : 0.f;
@@ -203,14 +368,14 @@ __global__ void bn_finalize_kernel(long rows, int c, const double* __restrict__ 
     scale[j] = inv;
     shift[j] = be - (float)mu * inv;                                     // beta - mean*inv
 }
-extern "C" int gspn_bn_finalize(long rows, int c, const double* stats, const float* gamma, const float* beta, float eps, float decay,
+extern "C" int gspn_bn_finalize(long rows, int c, const float* stats, const float* gamma, const float* beta, float eps, float decay,
                                 int is_training, float* moving_mean, float* moving_var, float* mean, float* var,
                                 float* scale, float* shift, void* stream) {
     if (rows <= 0 || c <= 0 || !mean || !var || !scale || !shift) return GSPN_ERR_ARG;
     if (is_training && !stats) return GSPN_ERR_ARG;
     if (!is_training && (!moving_mean || !moving_var)) return GSPN_ERR_ARG;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 127) / 128), dim3(128), 0, (hipStream_t)stream, rows, c, stats, gamma, beta, eps, decay,
-                       is_training, moving_mean, moving_var, mean, var, scale, shift);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, (hipStream_t)stream, rows, c, stats, (int)fwd_blocks(rows, c), gamma, beta,
+                       eps, decay, is_training, moving_mean, moving_var, mean, var, scale, shift);
     return gspn_launch_status();
 }
 
@@ -261,264 +426,532 @@ extern "C" int gspn_bnrelu_apply(long rows, int c, const float* Y, int ldy, cons
 }
 
 // ============================================================================================
-// Backward pass 1: per-channel reductions  r0 = sum(dyh),  r1 = sum(dyh * xhat)
-// block 256 = 8 row-lanes x 32 channel-lanes; grid (row chunks, channel groups of 32)
+// Backward pass A:  one read of (X, Y, dz) per layer ->
+//    red[0:c]   += sum_rows dyh                 red[c:2c] += sum_rows dyh*xhat        (double atomics)
+//    G1(cin,cout) += A^T.dyh     Gx(cin,cout) += A^T.xhat     g3(cin) += A^T.1         (fp32 atomics)
+// with dyh = dz*[scale*y+shift > 0], xhat = (y-mean)*rstd, A = act(X).
+// M = cin tile (32*WM), N = cout tile (BN), K = rows (split over grid.x chunks).  Both operands are
+// K-major in memory (one row of X / of Y is one k), so staging is a straight float4 copy.
+// WANT_GX = training-mode BN (otherwise dW = cA (.) G1 and Gx is skipped).
 // ============================================================================================
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(long rows, int c, gspn_dy_args a, const float* __restrict__ mean, const float* __restrict__ var,
-                                                            float eps, double* __restrict__ red) {
-    __shared__ float s0[8][33], s1[8][33];
-    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
-    const int col = blockIdx.y * 32 + cx;
-    float r0 = 0.f, r1 = 0.f;
-    if (col < c) {
-        const float sc = a.scale[col], sh = a.shift[col];
-        const float mu = mean ? mean[col] : 0.f;
-        const float rstd = var ? (float)(1.0 / sqrt((double)var[col] + (double)eps)) : 1.f;
-        for (long row = blockIdx.x * 8L + ry; row < rows; row += (long)gridDim.x * 8) {
-            const float y = a.Y[row * a.ldy + col];
-            const float dz = dz_at(a, row, col, c);
-            const float dyh = (y * sc + sh) > 0.f ? dz : 0.f;
-            r0 += dyh;
-            r1 += dyh * ((y - mu) * rstd);
+// Tile shape: MT x NTT tiles of 32x32 (BM = 32*MT rows of dW, BN = 32*NTT columns), right-sized to the layer so
+// no MFMA is spent on padding.  T = MT*NTT tiles are dealt round-robin to the 4 waves; when T < 4 the spare waves
+// split K instead (each takes a slice of the staged rows) so all four SIMDs work.  TKW rows are staged per
+// iteration (more for narrow layers, to keep ~25-50 KB in flight per workgroup).
+template <int MT, int NTT, int TKW, bool VEC, bool WANT_GX>
+__global__ __launch_bounds__(256) void mlp_bwd_wgrad_kernel(long rows, int cin, int cout, gspn_dy_args a, const float* __restrict__ X, int ldx,
+                                                            const float* __restrict__ in_scale, const float* __restrict__ in_shift,
+                                                            const float* __restrict__ mean, const float* __restrict__ var, float eps,
+                                                            float* __restrict__ RP, float* __restrict__ GP, float* __restrict__ PP,
+                                                            long rows_per_chunk) {
+    // per-chunk partial outputs (no hot-spot atomics; summed by the finalize kernels):
+    //   RP[chunk][2][cout] = (sum dyh, sum dyh*xhat)   GP[chunk][cin] = column sums of A   PP[chunk][2][cin][cout] = (A^T.dyh, A^T.xhat)
+    constexpr int BM = 32 * MT, BN = 32 * NTT;
+    constexpr int T = MT * NTT;
+    constexpr int WK = T >= 4 ? 1 : (T == 2 ? 2 : (T == 1 ? 4 : 1));   // K split among waves when tiles are scarce
+    constexpr int TPW = (T * WK + 3) / 4;                                // tiles per wave
+    constexpr int LDAW = BM + 4;
+    constexpr int LDB = BN + 4;
+    constexpr int AQ = BM / 4, BQ = BN / 4;
+    constexpr int NA = (TKW * AQ + 255) / 256;    // A float4 per thread per chunk
+    constexpr int NBV = (TKW * BQ + 255) / 256;   // B float4 per thread per chunk
+    constexpr int ASTEP = 256 / AQ, BSTEP = 256 / BQ;   // row stride between a thread's consecutive quads (256 % AQ == 0 needs AQ | 256)
+    static_assert(256 % AQ == 0 || MT == 3, "A quad mapping");
+    __shared__ __attribute__((aligned(16))) float sA[TKW * LDAW];     // [k=row][m=cin]
+    __shared__ __attribute__((aligned(16))) float sB[TKW * LDB];      // [k=row][n=cout]  dyh
+    __shared__ __attribute__((aligned(16))) float sX[WANT_GX ? TKW * LDB : 4];   // [k=row][n=cout]  xhat
+    __shared__ float sSc[MAXCH], sSh[MAXCH];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.z * BN;
+    const bool act = in_scale != nullptr;
+    stage_chan(sSc, in_scale, cin, 1.f);
+    stage_chan(sSh, in_shift, cin, 0.f);
+    __syncthreads();
+    const long r_begin = blockIdx.x * rows_per_chunk;
+    const long r_end = r_begin + rows_per_chunk < rows ? r_begin + rows_per_chunk : rows;
+    const bool dzvec = VEC && a.dZ && (a.ldz % 4 == 0) && (((uintptr_t)a.dZ) % 16 == 0);
+
+    // quad mapping: item f = t + 256*i -> row f / Q, quad f % Q.  When Q divides 256 the quad is fixed per thread.
+    constexpr bool AFIX = (256 % AQ) == 0, BFIX = (256 % BQ) == 0;
+    static_assert(BFIX, "BN must be 32, 64 or 128");
+    const int b_nq = (t % BQ) * 4, b_kk0 = t / BQ;
+    float4 bsc = make_float4(1, 1, 1, 1), bsh = make_float4(0, 0, 0, 0), bmu = make_float4(0, 0, 0, 0), brs = make_float4(1, 1, 1, 1);
+    {
+        float* psc = &bsc.x; float* psh = &bsh.x; float* pmu = &bmu.x; float* prs = &brs.x;
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + b_nq + j;
+            if (n < cout) {
+                psc[j] = a.scale[n]; psh[j] = a.shift[n];
+                if (mean) pmu[j] = mean[n];
+                if (var) prs[j] = (float)(1.0 / sqrt((double)var[n] + (double)eps));
+            }
         }
     }
-    s0[ry][cx] = r0;
-    s1[ry][cx] = r1;
+    float4 s_r0 = make_float4(0, 0, 0, 0), s_r1 = make_float4(0, 0, 0, 0);
+
+    f32x16 acc1[TPW], accx[WANT_GX ? TPW : 1];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc1[i][r] = 0.f; if (WANT_GX) accx[i][r] = 0.f; }
+
+    float4 ra[NA], ry[NBV];
+    DzRaw rz[NBV];
+    const long r_last = r_end - 1;
+    auto fetch = [&](long k0) {                       // raw, unconditional loads (clamped rows): all in flight until commit()
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int f = t + 256 * i;
+            const int kk = f / AQ, mq = (f - kk * AQ) * 4;
+            const long row = k0 + kk;
+            ra[i] = load4_raw<VEC>(X, row < r_end ? row : r_last, ldx, m0 + mq, cin);
+        }
+#pragma unroll
+        for (int i = 0; i < NBV; ++i) {
+            const long row = k0 + b_kk0 + BSTEP * i;
+            const long rc = row < r_end ? row : r_last;
+            ry[i] = load4_raw<VEC>(a.Y, rc, a.ldy, n0 + b_nq, cout);
+            rz[i] = dzvec ? dz4_raw<true>(a, rc, n0 + b_nq, cout) : dz4_raw<false>(a, rc, n0 + b_nq, cout);
+        }
+    };
+    auto commit = [&](long k0) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int f = t + 256 * i;
+            const int kk = f / AQ, mq = (f - kk * AQ) * 4;
+            if (kk < TKW) {
+                Chan4 cha;
+                cha.sc = lds4(sSc, m0 + mq);
+                cha.sh = lds4(sSh, m0 + mq);
+                *reinterpret_cast<float4*>(sA + kk * LDAW + mq) = act4(ra[i], act, cha, m0 + mq, cin, (k0 + kk) < r_end);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NBV; ++i) {
+            const int kk = b_kk0 + BSTEP * i;
+            if (kk < TKW) {
+                const long row = k0 + kk;
+                const bool live = row < r_end;
+                const float4 y = mask4(ry[i], n0 + b_nq, cout, live);
+                const float4 dz = mask4(dz4_resolve(a, rz[i], row < r_end ? row : r_last), n0 + b_nq, cout, live);
+                float4 dyh, xh;
+                dyh.x = (y.x * bsc.x + bsh.x) > 0.f ? dz.x : 0.f;
+                dyh.y = (y.y * bsc.y + bsh.y) > 0.f ? dz.y : 0.f;
+                dyh.z = (y.z * bsc.z + bsh.z) > 0.f ? dz.z : 0.f;
+                dyh.w = (y.w * bsc.w + bsh.w) > 0.f ? dz.w : 0.f;
+                xh = mask4(make_float4((y.x - bmu.x) * brs.x, (y.y - bmu.y) * brs.y, (y.z - bmu.z) * brs.z, (y.w - bmu.w) * brs.w), n0 + b_nq, cout, live);
+                *reinterpret_cast<float4*>(sB + kk * LDB + b_nq) = dyh;
+                if (WANT_GX) *reinterpret_cast<float4*>(sX + kk * LDB + b_nq) = xh;
+                if (blockIdx.y == 0) {
+                    s_r0.x += dyh.x; s_r0.y += dyh.y; s_r0.z += dyh.z; s_r0.w += dyh.w;
+                    s_r1.x += dyh.x * xh.x; s_r1.y += dyh.y * xh.y; s_r1.z += dyh.z * xh.z; s_r1.w += dyh.w * xh.w;
+                }
+            }
+        }
+    };
+    (void)AFIX; (void)ASTEP;
+
+    // g3 = column sums of A: accumulated from LDS by the first BM threads (cheap: TKW adds per iteration)
+    float g3acc = 0.f;
+
+    const long nit = r_begin < r_end ? (r_end - r_begin + TKW - 1) / TKW : 0;
+    for (long it = 0; it <= nit; ++it) {
+        if (it < nit) fetch(r_begin + it * TKW);
+        if (it > 0) {
+            if (blockIdx.z == 0 && t < BM) {
+#pragma unroll 8
+                for (int kk = 0; kk < TKW; ++kk) g3acc += sA[kk * LDAW + t];
+            }
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) {
+                const int slot = wave + 4 * i;              // (tile, k-part) slot of this wave
+                if (slot < T * WK) {
+                    const int tile = slot % T, kp = slot / T;
+                    const int tm = tile % MT, tn = tile / MT;
+                    constexpr int KPER = TKW / WK;
+#pragma unroll 4
+                    for (int kk = kp * KPER; kk < (kp + 1) * KPER; kk += 2) {
+                        const float av = sA[(kk + (lane >> 5)) * LDAW + tm * 32 + (lane & 31)];
+                        const int off = (kk + (lane >> 5)) * LDB + tn * 32 + (lane & 31);
+                        acc1[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, sB[off], acc1[i], 0, 0, 0);
+                        if (WANT_GX) accx[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, sX[off], accx[i], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (it < nit) commit(r_begin + it * TKW);
+        __syncthreads();
+    }
+    // ---- epilogue: this chunk's partial tiles / sums ----
+    float* P1 = PP + (size_t)blockIdx.x * 2 * cin * cout;
+    float* Px = P1 + (size_t)cin * cout;
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int slot = wave + 4 * i;
+        if (slot < T * WK) {
+            const int tile = slot % T, kp = slot / T;
+            const int tm = tile % MT, tn = tile / MT;
+            const int col = n0 + tn * 32 + (lane & 31);
+            if (WK == 1) {
+                if (col < cout) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = m0 + tm * 32 + c_row(r, lane);
+                        if (m < cin) {
+                            P1[(size_t)m * cout + col] = acc1[i][r];
+                            if (WANT_GX) Px[(size_t)m * cout + col] = accx[i][r];
+                        }
+                    }
+                }
+            } else {
+                // WK waves own K-slices of the same 32x32 tile: the chunk's partial is their sum -> plain float atomics into
+                // THIS chunk's private (zeroed) tile: at most 4-way, no cross-workgroup contention
+                if (col < cout) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = m0 + tm * 32 + c_row(r, lane);
+                        if (m < cin) {
+                            atomicAdd(P1 + (size_t)m * cout + col, acc1[i][r]);
+                            if (WANT_GX) atomicAdd(Px + (size_t)m * cout + col, accx[i][r]);
+                        }
+                    }
+                }
+                (void)kp;
+            }
+        }
+    }
+    if (blockIdx.z == 0 && t < BM && m0 + t < cin) GP[(size_t)blockIdx.x * cin + m0 + t] = g3acc;
     __syncthreads();
-    if (ry == 0 && col < c) {
-        double a0 = 0.0, a1 = 0.0;
-        for (int i = 0; i < 8; ++i) { a0 += (double)s0[i][cx]; a1 += (double)s1[i][cx]; }
-        atomicAdd(red + col, a0);
-        atomicAdd(red + c + col, a1);
+    // column sums: threads with the same quad differ in (t / BQ); reduce through LDS (reuse sB)
+    if (blockIdx.y == 0) {
+        float* s0 = sB;                 // [BSTEP][BN] x2
+        float* s1 = sB + BSTEP * BN;
+        *reinterpret_cast<float4*>(s0 + b_kk0 * BN + b_nq) = s_r0;
+        *reinterpret_cast<float4*>(s1 + b_kk0 * BN + b_nq) = s_r1;
+    }
+    __syncthreads();
+    if (blockIdx.y == 0) {
+        for (int j = t; j < BN; j += 256) {
+            const int n = n0 + j;
+            if (n < cout) {
+                float v0 = 0.f, v1 = 0.f;
+                for (int i = 0; i < BSTEP; ++i) { v0 += sB[i * BN + j]; v1 += sB[BSTEP * BN + i * BN + j]; }
+                RP[(size_t)blockIdx.x * 2 * cout + n] = v0;
+                RP[(size_t)blockIdx.x * 2 * cout + cout + n] = v1;
+            }
+        }
     }
 }
-extern "C" int gspn_bn_bwd_reduce(long rows, int c, const gspn_dy_args* a, const float* mean, const float* var, float eps, double* red, void* stream) {
-    if (rows < 0 || c <= 0 || !a || !a->Y || !a->scale || !a->shift || !red) return GSPN_ERR_ARG;
-    if (!a->dZ && !(a->dPool && a->pool_arg && a->ns > 0)) return GSPN_ERR_ARG;
-    if (rows == 0) return 0;
-    long gx = (rows + 8 * 64 - 1) / (8 * 64);
-    if (gx > 1024) gx = 1024;
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)gx, (c + 31) / 32), dim3(256), 0, (hipStream_t)stream, rows, c, *a, mean, var, eps, red);
-    return gspn_launch_status();
+
+// ---- second stage: sum the per-chunk partials (double), then coefficients / parameter gradients / dW ----
+struct WgradPlan { int MTs, NTs, nrow, ncol, TKW; long rpc, nch; };
+static WgradPlan wgrad_plan(long rows, int cin, int cout) {
+    WgradPlan p;
+    const int mt = (cin + 31) / 32, nt = (cout + 31) / 32;
+    p.nrow = (mt + 3) / 4; p.ncol = (nt + 3) / 4;
+    p.MTs = (mt + p.nrow - 1) / p.nrow;
+    p.NTs = (nt + p.ncol - 1) / p.ncol;
+    if (p.NTs == 3) p.NTs = 4;                              // BN in {32, 64, 128}
+    // rows staged per iteration: more for narrow layers (keeps ~25-50 KB in flight per workgroup, <= 56 KB of LDS)
+    static const int tkw[4][3] = {{128, 64, 32}, {64, 64, 32}, {64, 32, 32}, {64, 32, 32}};     // [MT-1][NT: 1,2,4]
+    p.TKW = tkw[p.MTs - 1][p.NTs == 1 ? 0 : (p.NTs == 2 ? 1 : 2)];
+    long chunks = (256L * 3) / (p.ncol * p.nrow);
+    const long cap = (12L << 20) / (8L * cin * cout);        // keep the partial-tile workspace <= ~12 MB
+    if (chunks > cap) chunks = cap;
+    if (chunks < 1) chunks = 1;
+    long rpc = (rows + chunks - 1) / chunks;
+    if (rpc < 4L * p.TKW) rpc = 4L * p.TKW;
+    p.rpc = (rpc + p.TKW - 1) / p.TKW * p.TKW;
+    p.nch = (rows + p.rpc - 1) / p.rpc;
+    if (p.nch < 1) p.nch = 1;
+    return p;
+}
+// workspace: [red: 2*cout doubles][g3: cin floats, padded to 4][RP: nch*2*cout][GP: nch*cin][PP: nch*2*cin*cout]
+static size_t ws_off_g3(int cout) { return sizeof(double) * 2 * (size_t)cout; }
+static size_t ws_off_rp(int cin, int cout) { return ws_off_g3(cout) + sizeof(float) * (size_t)((cin + 3) / 4 * 4); }
+static size_t ws_off_gp(long nch, int cin, int cout) { return ws_off_rp(cin, cout) + sizeof(float) * (size_t)nch * 2 * cout; }
+static size_t ws_off_pp(long nch, int cin, int cout) { return (ws_off_gp(nch, cin, cout) + sizeof(float) * (size_t)nch * cin + 15) / 16 * 16; }
+static size_t ws_total(long nch, int cin, int cout) { return ws_off_pp(nch, cin, cout) + sizeof(float) * (size_t)nch * 2 * cin * cout; }
+extern "C" long gspn_mlp_bwd_work_bytes(long rows, int cin, int cout) {
+    if (rows <= 0 || cin <= 0 || cout <= 0) return GSPN_ERR_ARG;
+    return (long)ws_total(wgrad_plan(rows, cin, cout).nch, cin, cout);
 }
 
-__global__ void bn_bwd_coeffs_kernel(long rows, int c, const double* __restrict__ red, const float* __restrict__ mean, const float* __restrict__ var,
-                                     const float* __restrict__ gamma, float eps, int use_bn, int is_training,
-                                     float* __restrict__ cA, float* __restrict__ cB, float* __restrict__ cC,
-                                     float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dbias) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= c) return;
+// one WAVE per channel index n in [0, max(cin,cout)): r0, r1 (and g3[n]) summed over chunks in double -> coefficients etc.
+__global__ __launch_bounds__(256) void wgrad_small_reduce_kernel(long rows, int cin, int cout, int nch, const float* __restrict__ RP, const float* __restrict__ GP,
+                                                                 double* __restrict__ red, float* __restrict__ g3, const float* __restrict__ mean,
+                                                                 const float* __restrict__ var, const float* __restrict__ gamma, float eps, int use_bn, int is_training,
+                                                                 float* __restrict__ cA, float* __restrict__ cB, float* __restrict__ cC,
+                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dbias) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= cin && n >= cout) return;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    for (int p = lane; p < nch; p += 64) {
+        if (n < cout) { a0 += (double)RP[(size_t)p * 2 * cout + n]; a1 += (double)RP[(size_t)p * 2 * cout + cout + n]; }
+        if (n < cin) a2 += (double)GP[(size_t)p * cin + n];
+    }
+    const double r0 = wave_sum_f64(a0), r1 = wave_sum_f64(a1), gg = wave_sum_f64(a2);
+    if (lane != 0) return;
+    if (n < cin) g3[n] = (float)gg;
+    if (n >= cout) return;
+    red[n] = r0;
+    red[cout + n] = r1;
     const double R = (double)rows;
-    const double r0 = red ? red[j] : 0.0, r1 = red ? red[c + j] : 0.0;
     double A = 1.0, B = 0.0, C = 0.0;
-    const double mu = mean ? (double)mean[j] : 0.0;
+    const bool tr = use_bn && is_training;
     if (use_bn) {
-        const double g = gamma ? (double)gamma[j] : 1.0;
-        const double rstd = 1.0 / sqrt((double)var[j] + (double)eps);
+        const double g = gamma ? (double)gamma[n] : 1.0;
+        const double rstd = 1.0 / sqrt((double)var[n] + (double)eps);
+        const double mu = (double)mean[n];
         A = g * rstd;
-        if (is_training) {
+        if (tr) {
             B = -g * rstd * rstd * (r1 / R);
             C = -g * rstd * (r0 / R - mu * rstd * (r1 / R));
         }
-        if (dgamma) dgamma[j] = (float)r1;
-        if (dbeta) dbeta[j] = (float)r0;
+        if (dgamma) dgamma[n] = (float)r1;
+        if (dbeta) dbeta[n] = (float)r0;
     }
-    if (cA) cA[j] = (float)A;
-    if (cB) cB[j] = (float)B;
-    if (cC) cC[j] = (float)C;
-    if (dbias) dbias[j] = (float)(A * r0 + B * (mu * R) + C * R);   // sum(dY); sum(y) = mean*R only under batch statistics
+    if (cA) cA[n] = (float)A;
+    if (cB) cB[n] = (float)B;
+    if (cC) cC[n] = (float)C;
+    if (dbias) dbias[n] = (float)(tr ? 0.0 : A * r0);      // sum(dY): exactly 0 under batch statistics
 }
-extern "C" int gspn_bn_bwd_coeffs(long rows, int c, const double* red, const float* mean, const float* var, const float* gamma, float eps,
-                                  int use_bn, int is_training, float* cA, float* cB, float* cC, float* dgamma, float* dbeta, float* dbias, void* stream) {
-    if (rows <= 0 || c <= 0) return GSPN_ERR_ARG;
-    if (use_bn && (!var || !mean)) return GSPN_ERR_ARG;
-    hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3((c + 127) / 128), dim3(128), 0, (hipStream_t)stream, rows, c, red, mean, var, gamma, eps,
+// dW[m][n] = cA[n] * (sum_chunks G1 - r0/R * g3[m] - r1/R * sum_chunks Gx)
+// block 256 = 64 consecutive outputs x 4 chunk-slices (coalesced 256-B rows of the partial tiles, 4-way chunk parallelism)
+__global__ __launch_bounds__(256) void wgrad_dw_kernel(long rows, int cin, int cout, int nch, const float* __restrict__ PP, const double* __restrict__ red,
+                                                       const float* __restrict__ g3, const float* __restrict__ var, const float* __restrict__ gamma, float eps,
+                                                       int use_bn, int is_training, float* __restrict__ dW) {
+    __shared__ double s1[4][64], sx[4][64];
+    const long total = (long)cin * cout;
+    const double R = (double)rows;
+    const bool tr = use_bn && is_training;
+    const int ox = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const long i = blockIdx.x * 64L + ox;
+    double w1 = 0.0, wx = 0.0;
+    if (i < total) {
+        const float* p1 = PP + i;
+        int p = sl;
+        for (; p + 12 < nch; p += 16) {             // 4 independent loads in flight per accumulator
+            const float v0 = p1[(size_t)p * 2 * total], v1 = p1[(size_t)(p + 4) * 2 * total], v2 = p1[(size_t)(p + 8) * 2 * total], v3 = p1[(size_t)(p + 12) * 2 * total];
+            w1 += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+            if (tr) {
+                const float u0 = p1[(size_t)p * 2 * total + total], u1 = p1[(size_t)(p + 4) * 2 * total + total];
+                const float u2 = p1[(size_t)(p + 8) * 2 * total + total], u3 = p1[(size_t)(p + 12) * 2 * total + total];
+                wx += ((double)u0 + (double)u1) + ((double)u2 + (double)u3);
+            }
+        }
+        for (; p < nch; p += 4) {
+            w1 += (double)p1[(size_t)p * 2 * total];
+            if (tr) wx += (double)p1[(size_t)p * 2 * total + total];
+        }
+    }
+    s1[sl][ox] = w1;
+    sx[sl][ox] = wx;
+    __syncthreads();
+    if (sl != 0 || i >= total) return;
+    w1 = (s1[0][ox] + s1[1][ox]) + (s1[2][ox] + s1[3][ox]);
+    wx = (sx[0][ox] + sx[1][ox]) + (sx[2][ox] + sx[3][ox]);
+    const int n = (int)(i % cout), m = (int)(i / cout);
+    double A = 1.0;
+    if (use_bn) A = (gamma ? (double)gamma[n] : 1.0) / sqrt((double)var[n] + (double)eps);
+    if (tr) w1 -= (red[n] / R) * (double)g3[m] + (red[cout + n] / R) * wx;
+    dW[i] = (float)(A * w1);
+}
+
+extern "C" int gspn_mlp_bwd_wgrad(long rows, int cin, int cout, const gspn_dy_args* a, const float* X, int ldx,
+                                  const float* in_scale, const float* in_shift, const float* mean, const float* var, const float* gamma,
+                                  float eps, int use_bn, int is_training, float* work, float* cA, float* cB, float* cC,
+                                  float* dgamma, float* dbeta, float* dbias, float* dW, void* stream) {
+    if (rows <= 0 || cin <= 0 || cout <= 0 || ldx < cin || !a || !a->Y || !a->scale || !a->shift || !work || !dW) return GSPN_ERR_ARG;
+    if (!a->dZ && !(a->dPool && a->pool_arg && a->ns > 0)) return GSPN_ERR_ARG;
+    if ((in_scale == nullptr) != (in_shift == nullptr)) return GSPN_ERR_ARG;
+    if (use_bn && (!mean || !var)) return GSPN_ERR_ARG;
+    if (cin > MAXCH || cout > MAXCH) return GSPN_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const WgradPlan p = wgrad_plan(rows, cin, cout);
+    char* wb = reinterpret_cast<char*>(work);
+    double* red = reinterpret_cast<double*>(wb);
+    float* g3 = reinterpret_cast<float*>(wb + ws_off_g3(cout));
+    float* RP = reinterpret_cast<float*>(wb + ws_off_rp(cin, cout));
+    float* GP = reinterpret_cast<float*>(wb + ws_off_gp(p.nch, cin, cout));
+    float* PP = reinterpret_cast<float*>(wb + ws_off_pp(p.nch, cin, cout));
+    const bool tr = use_bn && is_training;
+    const bool v = vec_ok(X, ldx) && vec_ok(a->Y, a->ldy);
+    const int T = p.MTs * p.NTs;
+    if (T < 4 && T != 3) {      // K-split tiles accumulate with (uncontended) atomics into their chunk's tile: zero it first
+        hipError_t e = hipMemsetAsync(PP, 0, sizeof(float) * (size_t)p.nch * 2 * cin * cout, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    const float* mu = use_bn ? mean : nullptr;
+    const float* vr = use_bn ? var : nullptr;
+    const dim3 grid((unsigned)p.nch, p.nrow, p.ncol);
+    int launched = 0;
+#define WG_TRY(MT_, NT_, TKW_)                                                                                                          \
+    if (!launched && p.MTs == MT_ && p.NTs == NT_ && p.TKW == TKW_) {                                                                  \
+        if (v) { if (tr) hipLaunchKernelGGL((mlp_bwd_wgrad_kernel<MT_, NT_, TKW_, true, true>), grid, dim3(256), 0, st, rows, cin, cout, *a, X, ldx, in_scale, in_shift, mu, vr, eps, RP, GP, PP, p.rpc); \
+                 else    hipLaunchKernelGGL((mlp_bwd_wgrad_kernel<MT_, NT_, TKW_, true, false>), grid, dim3(256), 0, st, rows, cin, cout, *a, X, ldx, in_scale, in_shift, mu, vr, eps, RP, GP, PP, p.rpc); } \
+        else   { if (tr) hipLaunchKernelGGL((mlp_bwd_wgrad_kernel<MT_, NT_, TKW_, false, true>), grid, dim3(256), 0, st, rows, cin, cout, *a, X, ldx, in_scale, in_shift, mu, vr, eps, RP, GP, PP, p.rpc); \
+                 else    hipLaunchKernelGGL((mlp_bwd_wgrad_kernel<MT_, NT_, TKW_, false, false>), grid, dim3(256), 0, st, rows, cin, cout, *a, X, ldx, in_scale, in_shift, mu, vr, eps, RP, GP, PP, p.rpc); } \
+        launched = 1;                                                                                                                  \
+    }
+    WG_TRY(1, 1, 128) WG_TRY(1, 2, 64) WG_TRY(1, 4, 32)
+    WG_TRY(2, 1, 64)  WG_TRY(2, 2, 64) WG_TRY(2, 4, 32)
+    WG_TRY(3, 1, 64)  WG_TRY(3, 2, 32) WG_TRY(3, 4, 32)
+    WG_TRY(4, 1, 64)  WG_TRY(4, 2, 32) WG_TRY(4, 4, 32)
+#undef WG_TRY
+    if (!launched) return GSPN_ERR_UNSUPPORTED;
+    const int cmax = cin > cout ? cin : cout;
+    hipLaunchKernelGGL(wgrad_small_reduce_kernel, dim3((cmax + 3) / 4), dim3(256), 0, st, rows, cin, cout, (int)p.nch, RP, GP, red, g3, mean, var, gamma, eps,
                        use_bn, is_training, cA, cB, cC, dgamma, dbeta, dbias);
+    hipLaunchKernelGGL(wgrad_dw_kernel, dim3((unsigned)(((long)cin * cout + 63) / 64)), dim3(256), 0, st, rows, cin, cout, (int)p.nch, PP, red, g3, var, gamma, eps,
+                       use_bn, is_training, dW);
     return gspn_launch_status();
 }
 
 // ============================================================================================
-// Backward data:  dX(rows, cin) = dY(rows, cout) . W^T      (M = rows, K = cout, N = cin)
-// A = dY rebuilt on the fly while staging; B[k][n] = W[n][k] staged transposed.
+// Backward pass B:  dX(rows, cin) = dY(rows, cout) . W^T      (M = rows, K = cout, N = cin)
+// A = dY rebuilt on the fly (dY = cA*dyh + cB*y + cC) while staging; B[k][n] = W[n][k] staged transposed.
 // ============================================================================================
-template <int BN>
+template <int BN, bool VEC>
 __global__ __launch_bounds__(256) void mlp_bwd_data_kernel(long rows, int cin, int cout, gspn_dy_args a, const float* __restrict__ W,
                                                            float* __restrict__ dX, int ldx) {
     constexpr int NT = BN / 32;
-    constexpr int LDB = BN + 1;
-    __shared__ float sA[TM * LDA];
-    __shared__ float sB[TK * LDB];
+    constexpr int LDBT = BN + 1;                 // B written transposed: odd pitch
+    constexpr int NB = (TK / 4 * BN) / 256;      // float4 (along k) per thread per chunk
+    __shared__ __attribute__((aligned(16))) float sA[TK * LDT];
+    __shared__ __attribute__((aligned(16))) float sB[TK * LDBT];
+    __shared__ float sSc[MAXCH], sSh[MAXCH], sCA[MAXCH], sCB[MAXCH], sCC[MAXCH];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int n0 = blockIdx.y * BN;
     const long ntiles = (rows + TM - 1) / TM;
-    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int nchunks = (cout + TK - 1) / TK;
+    stage_chan(sSc, a.scale, cout, 1.f);
+    stage_chan(sSh, a.shift, cout, 0.f);
+    stage_chan(sCA, a.cA, cout, 0.f);         // channels >= cout contribute dY = 0
+    stage_chan(sCB, a.cB, cout, 0.f);
+    stage_chan(sCC, a.cC, cout, 0.f);
+    __syncthreads();
+    const int kq = (t & 7) * 4;
+    const int arow = t >> 3;
+    const bool dzvec = VEC && a.dZ && (a.ldz % 4 == 0) && (((uintptr_t)a.dZ) % 16 == 0);
+
+    float4 ry[4], rb[NB];
+    DzRaw rz[4];
+    long f_tile = 0;
+    int f_c = 0;
+    auto fetch = [&](long tile, int c) {              // raw, unconditional loads
+        f_tile = tile; f_c = c;
         const long m0 = tile * TM;
-        f32x16 acc[NT];
+        const int k = c * TK + kq;
 #pragma unroll
-        for (int i = 0; i < NT; ++i)
+        for (int i = 0; i < 4; ++i) {
+            const long row = m0 + arow + 32 * i;
+            const long rc = row < rows ? row : rows - 1;
+            ry[i] = load4_raw<VEC>(a.Y, rc, a.ldy, k, cout);
+            rz[i] = dzvec ? dz4_raw<true>(a, rc, k, cout) : dz4_raw<false>(a, rc, k, cout);
+        }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-        for (int k0 = 0; k0 < cout; k0 += TK) {
-            __syncthreads();
-            {
-                const int kk = t & 31;
-                const int k = k0 + kk;
-                DyChan ch = {1.f, 0.f, 1.f, 0.f, 0.f};
-                if (k < cout) ch = DyChan{a.scale[k], a.shift[k], a.cA[k], a.cB[k], a.cC[k]};
-#pragma unroll 4
-                for (int i = 0; i < 16; ++i) {
-                    const int r = (t >> 5) + 8 * i;
-                    const long row = m0 + r;
-                    float v = 0.f;
-                    if (row < rows && k < cout) v = dy_elem(a.Y[row * a.ldy + k], dz_at(a, row, k, cout), ch);
-                    sA[r * LDA + kk] = v;
-                }
+        for (int i = 0; i < NB; ++i) {
+            const int f = t + 256 * i;
+            const int j = f >> 3, kk4 = (f & 7) * 4;       // W row n0+j, columns c*TK + kk4 ..
+            const int n = n0 + j;
+            rb[i] = load4_raw<VEC>(W, n < cin ? n : cin - 1, cout, c * TK + kk4, cout);
+        }
+    };
+    auto commit = [&]() {
+        const long m0 = f_tile * TM;
+        const int c = f_c;
+        const int k = c * TK + kq;
+        const float4 q_sc = lds4(sSc, k), q_sh = lds4(sSh, k), q_a = lds4(sCA, k), q_b = lds4(sCB, k), q_c = lds4(sCC, k);
+        const float sc[4] = {q_sc.x, q_sc.y, q_sc.z, q_sc.w}, sh[4] = {q_sh.x, q_sh.y, q_sh.z, q_sh.w};
+        const float cA[4] = {q_a.x, q_a.y, q_a.z, q_a.w}, cB[4] = {q_b.x, q_b.y, q_b.z, q_b.w}, cC[4] = {q_c.x, q_c.y, q_c.z, q_c.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long row = m0 + arow + 32 * i;
+            const float4 dzv = dz4_resolve(a, rz[i], row < rows ? row : rows - 1);
+            const float yv[4] = {ry[i].x, ry[i].y, ry[i].z, ry[i].w};
+            const float zv[4] = {dzv.x, dzv.y, dzv.z, dzv.w};
+            float* d = sA + kq * LDT + arow + 32 * i;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float dyh = (yv[j] * sc[j] + sh[j]) > 0.f ? zv[j] : 0.f;
+                d[j * LDT] = cA[j] * dyh + cB[j] * yv[j] + cC[j];       // columns >= cout have cA=cB=cC=0
             }
-            // B[kk][j] = W[(n0+j)][k0+kk]: lanes run along kk (contiguous in W's row), odd pitch -> conflict-free
-            for (int e = t; e < TK * BN; e += 256) {
-                const int j = e / TK, kk = e - j * TK;
-                const int k = k0 + kk, n = n0 + j;
-                sB[kk * LDB + j] = (k < cout && n < cin) ? W[(size_t)n * cout + k] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int f = t + 256 * i;
+            const int j = f >> 3, kk4 = (f & 7) * 4;
+            const float4 w = mask4(rb[i], c * TK + kk4, cout, (n0 + j) < cin);
+            float* d = sB + kk4 * LDBT + j;
+            d[0 * LDBT] = w.x; d[1 * LDBT] = w.y; d[2 * LDBT] = w.z; d[3 * LDBT] = w.w;
+        }
+    };
+    f32x16 acc[NT];
+    const long my_tiles = blockIdx.x < ntiles ? (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    const long nsteps = my_tiles * nchunks;
+    for (long sidx = 0; sidx <= nsteps; ++sidx) {
+        if (sidx < nsteps) fetch(blockIdx.x + (sidx / nchunks) * gridDim.x, (int)(sidx % nchunks));
+        if (sidx > 0) {
+            const long ps = sidx - 1;
+            const long tile = blockIdx.x + (ps / nchunks) * gridDim.x;
+            const int c = (int)(ps % nchunks);
+            if (c == 0) {
+#pragma unroll
+                for (int i = 0; i < NT; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
             }
-            __syncthreads();
-            const int kmax = min(TK, (cout - k0 + 1) & ~1);
+            const int kmax = min(TK, (cout - c * TK + 1) & ~1);
             for (int kk = 0; kk < kmax; kk += 2) {
-                const float av = sA[(wave * 32 + (lane & 31)) * LDA + kk + (lane >> 5)];
+                const float av = sA[(kk + (lane >> 5)) * LDT + wave * 32 + (lane & 31)];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    const float bv = sB[(kk + (lane >> 5)) * LDB + nt * 32 + (lane & 31)];
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[nt], 0, 0, 0);
+                    const float bvv = sB[(kk + (lane >> 5)) * LDBT + nt * 32 + (lane & 31)];
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bvv, acc[nt], 0, 0, 0);
+                }
+            }
+            if (c == nchunks - 1) {
+                const long m0 = tile * TM;
+                const bool full = m0 + TM <= rows;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int col = n0 + nt * 32 + (lane & 31);
+                    if (col < cin) {
+                        float* xp = dX + (m0 + wave * 32 + 4 * (lane >> 5)) * ldx + col;
+                        if (full) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) xp[(long)((r & 3) + 8 * (r >> 2)) * ldx] = acc[nt][r];
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const long row = m0 + wave * 32 + c_row(r, lane);
+                                if (row < rows) dX[row * ldx + col] = acc[nt][r];
+                            }
+                        }
+                    }
                 }
             }
         }
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int col = n0 + nt * 32 + (lane & 31);
-            if (col < cin) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const long row = m0 + wave * 32 + c_row(r, lane);
-                    if (row < rows) dX[row * ldx + col] = acc[nt][r];
-                }
-            }
-        }
+        __syncthreads();
+        if (sidx < nsteps) commit();
+        __syncthreads();
     }
-}
-static int check_dy(const gspn_dy_args* a) {
-    if (!a || !a->Y || !a->scale || !a->shift || !a->cA || !a->cB || !a->cC) return GSPN_ERR_ARG;
-    if (!a->dZ && !(a->dPool && a->pool_arg && a->ns > 0)) return GSPN_ERR_ARG;
-    return 0;
 }
 extern "C" int gspn_mlp_bwd_data(long rows, int cin, int cout, const gspn_dy_args* a, const float* W, float* dX, int ldx, void* stream) {
-    if (rows < 0 || cin <= 0 || cout <= 0 || ldx < cin || check_dy(a)) return GSPN_ERR_ARG;
+    if (rows < 0 || cin <= 0 || cout <= 0 || ldx < cin || !a || !a->Y || !a->scale || !a->shift || !a->cA || !a->cB || !a->cC) return GSPN_ERR_ARG;
+    if (!a->dZ && !(a->dPool && a->pool_arg && a->ns > 0)) return GSPN_ERR_ARG;
+    if (cin > MAXCH || cout > MAXCH) return GSPN_ERR_UNSUPPORTED;
     if (rows == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    if (cin <= 32) {
-        hipLaunchKernelGGL(mlp_bwd_data_kernel<32>, dim3(row_grid(rows, 1), 1), dim3(256), 0, st, rows, cin, cout, *a, W, dX, ldx);
-    } else if (cin <= 64) {
-        hipLaunchKernelGGL(mlp_bwd_data_kernel<64>, dim3(row_grid(rows, 1), 1), dim3(256), 0, st, rows, cin, cout, *a, W, dX, ldx);
-    } else {
-        const int yt = (cin + 127) / 128;
-        hipLaunchKernelGGL(mlp_bwd_data_kernel<128>, dim3(row_grid(rows, yt), yt), dim3(256), 0, st, rows, cin, cout, *a, W, dX, ldx);
-    }
-    return gspn_launch_status();
-}
-
-// ============================================================================================
-// Backward weight:  dW(cin, cout) = act(X)^T . dY     (M = cin, N = cout, K = rows: split over row chunks)
-// Both operands are already K-major in memory (a row of X / of dY is one k), so staging is a
-// coalesced copy.  WM x WN wave layout: WM=4 for wide cin (4 x 32 rows of dW per workgroup), WM=1
-// for cin <= 32 (the 4 waves split the cout columns instead).  Partial tiles are added with fp32
-// atomics (order-free sum, like the reference's own atomic gradients).
-// ============================================================================================
-template <int WM, int BN>
-__global__ __launch_bounds__(256) void mlp_bwd_weight_kernel(long rows, int cin, int cout, gspn_dy_args a, const float* __restrict__ X, int ldx,
-                                                             const float* __restrict__ in_scale, const float* __restrict__ in_shift,
-                                                             float* __restrict__ dW, long rows_per_chunk) {
-    constexpr int WN = 4 / WM;
-    constexpr int BM = 32 * WM;
-    constexpr int NT = BN / 32 / WN;              // 32-column tiles per wave
-    constexpr int LDAW = BM + 1;
-    constexpr int LDB = BN + 1;
-    __shared__ float sA[TK * LDAW];               // [k=row][m=cin]
-    __shared__ float sB[TK * LDB];                // [k=row][n=cout]
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wm = wave % WM, wn = wave / WM;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.z * BN;
-    const bool act = in_scale != nullptr;
-    const long r_begin = blockIdx.x * rows_per_chunk;
-    const long r_end = r_begin + rows_per_chunk < rows ? r_begin + rows_per_chunk : rows;
-
-    f32x16 acc[NT];
-#pragma unroll
-    for (int i = 0; i < NT; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-
-    for (long k0 = r_begin; k0 < r_end; k0 += TK) {
-        __syncthreads();
-        for (int e = t; e < TK * BM; e += 256) {
-            const int kk = e / BM, i = e - kk * BM;
-            const long row = k0 + kk;
-            const int m = m0 + i;
-            float v = 0.f;
-            if (row < r_end && m < cin) v = act_in(X[row * ldx + m], act, act ? in_scale[m] : 1.f, act ? in_shift[m] : 0.f);
-            sA[kk * LDAW + i] = v;
-        }
-        for (int e = t; e < TK * BN; e += 256) {
-            const int kk = e / BN, j = e - kk * BN;
-            const long row = k0 + kk;
-            const int n = n0 + j;
-            float v = 0.f;
-            if (row < r_end && n < cout) {
-                const DyChan ch = {a.scale[n], a.shift[n], a.cA[n], a.cB[n], a.cC[n]};
-                v = dy_elem(a.Y[row * a.ldy + n], dz_at(a, row, n, cout), ch);
-            }
-            sB[kk * LDB + j] = v;
-        }
-        __syncthreads();
-#pragma unroll 4
-        for (int kk = 0; kk < TK; kk += 2) {
-            const float av = sA[(kk + (lane >> 5)) * LDAW + wm * 32 + (lane & 31)];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const float bv = sB[(kk + (lane >> 5)) * LDB + (wn * NT + nt) * 32 + (lane & 31)];
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[nt], 0, 0, 0);
-            }
-        }
-    }
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int col = n0 + (wn * NT + nt) * 32 + (lane & 31);
-        if (col < cout) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 32 + c_row(r, lane);
-                if (m < cin) atomicAdd(dW + (size_t)m * cout + col, acc[nt][r]);
-            }
-        }
-    }
-}
-extern "C" int gspn_mlp_bwd_weight(long rows, int cin, int cout, const gspn_dy_args* a, const float* X, int ldx,
-                                   const float* in_scale, const float* in_shift, float* dW, void* stream) {
-    if (rows < 0 || cin <= 0 || cout <= 0 || ldx < cin || check_dy(a) || !dW) return GSPN_ERR_ARG;
-    if ((in_scale == nullptr) != (in_shift == nullptr)) return GSPN_ERR_ARG;
-    hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(dW, 0, sizeof(float) * (size_t)cin * cout, st);
-    if (e != hipSuccess) return (int)e;
-    if (rows == 0) return 0;
-    // row chunks: enough workgroups to fill the chip, at least 256 rows each, multiple of TK
-    const int ncol = (cout + 127) / 128;
-    const int nrow = cin <= 32 ? 1 : (cin + 127) / 128;
-    long chunks = (256L * 4) / (ncol * nrow);
-    long rpc = (rows + chunks - 1) / chunks;
-    if (rpc < 256) rpc = 256;
-    rpc = (rpc + TK - 1) / TK * TK;
-    chunks = (rows + rpc - 1) / rpc;
-    if (cin <= 32) {
-        hipLaunchKernelGGL((mlp_bwd_weight_kernel<1, 128>), dim3((unsigned)chunks, 1, ncol), dim3(256), 0, st, rows, cin, cout, *a, X, ldx, in_scale, in_shift, dW, rpc);
-    } else {
-        hipLaunchKernelGGL((mlp_bwd_weight_kernel<4, 128>), dim3((unsigned)chunks, nrow, ncol), dim3(256), 0, st, rows, cin, cout, *a, X, ldx, in_scale, in_shift, dW, rpc);
-    }
+    const bool v = vec_ok(a->Y, a->ldy) && vec_ok(W, cout);
+#define BD_LAUNCH(BN_, V_, YT_) \
+    hipLaunchKernelGGL((mlp_bwd_data_kernel<BN_, V_>), dim3(row_grid(rows, YT_, 4), YT_), dim3(256), 0, st, rows, cin, cout, *a, W, dX, ldx)
+    if (cin <= 32) { if (v) BD_LAUNCH(32, true, 1); else BD_LAUNCH(32, false, 1); }
+    else if (cin <= 64) { if (v) BD_LAUNCH(64, true, 1); else BD_LAUNCH(64, false, 1); }
+    else { const int yt = (cin + 127) / 128; if (v) BD_LAUNCH(128, true, yt); else BD_LAUNCH(128, false, yt); }
+#undef BD_LAUNCH
     return gspn_launch_status();
 }

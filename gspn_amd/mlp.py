@@ -56,7 +56,7 @@ class _MlpStack(torch.autograd.Function):
                 cout = lp.weights.shape[1]
                 y = torch.empty((rows, cout), dtype=torch.float32, device=dev)
                 use_stats = lp.bn and is_training
-                stats = _zeros(2 * cout, dev, torch.float64) if use_stats else None
+                stats = torch.empty(int(lib.gspn_mlp_fwd_stats_bytes(rows, cout)) // 4, dtype=torch.float32, device=dev) if use_stats else None
                 L.check(lib.gspn_mlp_fwd(rows, cin, cout, L.ptr(cur), cur_ld, L.ptr(in_scale), L.ptr(in_shift),
                                          L.ptr(lp.weights), L.ptr(lp.biases), L.ptr(y), cout, L.ptr(stats), st), "mlp_fwd")
                 mean = torch.empty(cout, dtype=torch.float32, device=dev)
@@ -123,17 +123,15 @@ class _MlpStack(torch.autograd.Function):
                     a.dZ, a.ldz, a.dPool, a.pool_arg, a.ns = dz.data_ptr(), ldz, None, None, 0
                 a.scale, a.shift = scale.data_ptr(), shift.data_ptr()
                 a.cA, a.cB, a.cC = cA.data_ptr(), cB.data_ptr(), cC.data_ptr()
-                red = _zeros(2 * cout, dev, torch.float64)
-                L.check(lib.gspn_bn_bwd_reduce(rows, cout, ctypes.byref(a), L.ptr(mean), L.ptr(var), BN_EPS, L.ptr(red), st), "bn_bwd_reduce")
                 dgamma = torch.empty(cout, dtype=torch.float32, device=dev) if lp.bn else None
                 dbeta = torch.empty(cout, dtype=torch.float32, device=dev) if lp.bn else None
                 dbias = torch.empty(cout, dtype=torch.float32, device=dev)
-                L.check(lib.gspn_bn_bwd_coeffs(rows, cout, L.ptr(red), L.ptr(mean), L.ptr(var), L.ptr(lp.gamma if lp.bn else None), BN_EPS,
-                                               int(lp.bn), int(is_training), L.ptr(cA), L.ptr(cB), L.ptr(cC),
-                                               L.ptr(dgamma), L.ptr(dbeta), L.ptr(dbias), st), "bn_bwd_coeffs")
                 dW = torch.empty_like(lp.weights)
-                L.check(lib.gspn_mlp_bwd_weight(rows, cin, cout, ctypes.byref(a), L.ptr(xin), xld, L.ptr(in_scale), L.ptr(in_shift), L.ptr(dW), st),
-                        "mlp_bwd_weight")
+                work = torch.empty(int(lib.gspn_mlp_bwd_work_bytes(rows, cin, cout)) // 4 + 4, dtype=torch.float32, device=dev)
+                L.check(lib.gspn_mlp_bwd_wgrad(rows, cin, cout, ctypes.byref(a), L.ptr(xin), xld, L.ptr(in_scale), L.ptr(in_shift),
+                                               L.ptr(mean), L.ptr(var), L.ptr(lp.gamma if lp.bn else None), BN_EPS, int(lp.bn), int(is_training),
+                                               L.ptr(work), L.ptr(cA), L.ptr(cB), L.ptr(cC), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dbias), L.ptr(dW), st),
+                        "mlp_bwd_wgrad")
                 g = [dW, dbias]
                 if lp.bn:
                     g += [dbeta, dgamma]

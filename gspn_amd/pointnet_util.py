@@ -25,24 +25,25 @@ class _GroupConcat(torch.autograd.Function):
         b, n, _ = xyz.shape
         _, m, ns = idx.shape
         c = 0 if points is None else points.shape[2]
-        out = torch.empty((b * m * ns, 3 + c), dtype=torch.float32, device=xyz.device)
+        ld = (3 + c + 3) // 4 * 4          # row pitch padded to 16 B so the MLP stages float4 (pad columns are zero)
+        out = torch.empty((b * m * ns, ld), dtype=torch.float32, device=xyz.device)
         with torch.cuda.device(xyz.device):
             L.check(L.lib().gspn_sa_group_concat(b, n, c, m, ns, L.ptr(xyz), L.ptr(new_xyz), L.ptr(points), L.ptr(idx),
-                                                 int(xyz_first), 3 + c, L.ptr(out), L.stream()), "sa_group_concat")
+                                                 int(xyz_first), ld, L.ptr(out), L.stream()), "sa_group_concat")
         ctx.save_for_backward(idx)
-        ctx.dims = (b, n, c, m, ns, int(xyz_first))
+        ctx.dims = (b, n, c, m, ns, int(xyz_first), ld)
         return out
 
     @staticmethod
     def backward(ctx, g):
         (idx,) = ctx.saved_tensors
-        b, n, c, m, ns, xyz_first = ctx.dims
+        b, n, c, m, ns, xyz_first, ld = ctx.dims
         gp = None
         if c > 0 and ctx.needs_input_grad[2]:
             g = g.contiguous()
             gp = torch.empty((b, n, c), dtype=torch.float32, device=g.device)
             with torch.cuda.device(g.device):
-                L.check(L.lib().gspn_sa_group_concat_grad(b, n, c, m, ns, L.ptr(idx), xyz_first, 3 + c, L.ptr(g), L.ptr(gp), L.stream()),
+                L.check(L.lib().gspn_sa_group_concat_grad(b, n, c, m, ns, L.ptr(idx), xyz_first, ld, L.ptr(g), L.ptr(gp), L.stream()),
                         "sa_group_concat_grad")
         return None, None, gp, None, None
 
@@ -107,8 +108,8 @@ def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_al
         if fused:
             new_xyz = gather_point(xyz, farthest_point_sample(npoint, xyz))
             idx, pts_cnt = query_ball_point(radius, nsample, xyz, new_xyz)
-            rows = group_concat(xyz, new_xyz, points, idx, xyz_first=True)
-            cin = rows.shape[1]
+            rows = group_concat(xyz, new_xyz, points, idx, xyz_first=True)      # (b*npoint*nsample, pitch >= 3+c)
+            cin = 3 + (0 if points is None else points.shape[2])
             layers = _mlp_layers(mlp, cin, 'conv', bn)
             pooled = mlp_stack(rows, cin, layers, bool(is_training), bn_decay, pool_ns=nsample)     # (b*npoint, mlp[-1])
             new_points = pooled.view(b, npoint, 1, mlp[-1])
@@ -162,5 +163,8 @@ def pointnet_fp_module(xyz1, xyz2, points1, points2, mlp, is_training, bn_decay,
             return new_points1
         b, n1, cin = new_points1.shape
         layers = _mlp_layers(mlp, cin, 'conv_', bn)
-        out = mlp_stack(new_points1.reshape(b * n1, cin), cin, layers, bool(is_training), bn_decay, pool_ns=None)
+        x2d = new_points1.reshape(b * n1, cin)
+        if cin % 4:                        # 16-byte row pitch for the float4 staging path
+            x2d = torch.nn.functional.pad(x2d, (0, 4 - cin % 4))
+        out = mlp_stack(x2d, cin, layers, bool(is_training), bn_decay, pool_ns=None)
         return out.view(b, n1, mlp[-1])

@@ -126,18 +126,20 @@ int gspn_sa_group_concat_grad(int b, int n, int c, int m, int nsample, const int
  * gspn_mlp_fwd:  Y(rows,ldy)[:, :cout] = act(X)(rows,ldx)[:, :cin] . W(cin,cout) + bias
  *   act(X) = X                           if in_scale == NULL
  *          = relu(X*in_scale+in_shift)   otherwise (per input channel: the previous layer's BN+ReLU)
- *   stats (2*cout DOUBLES, may be NULL): column sums of Y and Y^2 are atomically added (the caller
- *   zeroes it); they feed training-mode BN.
+ *   stats (may be NULL; gspn_mlp_fwd_stats_bytes(rows,cout) bytes, need not be zeroed): every row-block writes its own
+ *   partial column sums of Y and Y^2 (no hot-spot atomics); gspn_bn_finalize adds the partials in double.
  */
 int gspn_mlp_fwd(long rows, int cin, int cout, const float* X, int ldx, const float* in_scale, const float* in_shift,
-                 const float* W, const float* bias, float* Y, int ldy, double* stats, void* stream);
+                 const float* W, const float* bias, float* Y, int ldy, float* stats, void* stream);
+/* bytes of the `stats` workspace for a (rows, cout) layer */
+long gspn_mlp_fwd_stats_bytes(long rows, int cout);
 
 /* BN finalize (tf.contrib.layers.batch_norm, tf_util.py:529-534): from stats = (sum, sumsq) over
  * `rows` rows produce the batch mean / biased variance (saved for backward), scale = gamma*rsqrt(var+eps),
  * shift = beta - mean*scale, and update the moving averages in place
- * (moving = moving*decay + batch*(1-decay)).  is_training==0: scale/shift come from the moving
+ * (moving = moving*decay + batch*(1-decay)).  `stats` is the workspace gspn_mlp_fwd filled for the same (rows, c).  is_training==0: scale/shift come from the moving
  * statistics, mean/var are set to them and nothing is updated (stats may be NULL). */
-int gspn_bn_finalize(long rows, int c, const double* stats, const float* gamma, const float* beta, float eps, float decay,
+int gspn_bn_finalize(long rows, int c, const float* stats, const float* gamma, const float* beta, float eps, float decay,
                      int is_training, float* moving_mean, float* moving_var, float* mean, float* var,
                      float* scale, float* shift, void* stream);
 
@@ -154,8 +156,7 @@ int gspn_bnrelu_apply(long rows, int c, const float* Y, int ldy, const float* sc
  *      dyh = dz * [s*y+t > 0]
  *      dY  = cA*dyh + cB*y + cC                     (per output channel coefficients)
  * which covers BN-training (cA=gamma*rstd, cB/cC from the two batch reductions), BN-inference
- * (cA=scale, cB=cC=0) and no-BN (cA=1).  dY is never materialised: the reduction kernel and both
- * GEMMs rebuild it on the fly from (Y, dz) while staging their operands. */
+ * (cA=scale, cB=cC=0) and no-BN (cA=1).  dY is never materialised. */
 typedef struct gspn_dy_args {
     const float* Y;        /* (rows, ldy) pre-BN output saved by the forward pass */
     int ldy;
@@ -166,25 +167,28 @@ typedef struct gspn_dy_args {
     int ns;
     const float* scale;    /* c : forward scale/shift (relu mask) */
     const float* shift;
-    const float* cA;       /* c each: coefficients written by gspn_bn_bwd_coeffs */
+    const float* cA;       /* c each: coefficients written by gspn_mlp_bwd_wgrad (read by gspn_mlp_bwd_data only) */
     const float* cB;
     const float* cC;
 } gspn_dy_args;
 
-/* red (2c doubles, caller zeroes): red[0:c] += sum(dyh), red[c:2c] += sum(dyh * (y-mean)*rstd) */
-int gspn_bn_bwd_reduce(long rows, int c, const gspn_dy_args* a, const float* mean, const float* var, float eps, double* red, void* stream);
-/* per-channel coefficients + parameter gradients from the reductions:
- *   use_bn && is_training : cA=g*rstd, cB=-g*rstd^2*r1/R, cC=-g*rstd*(r0/R - mean*rstd*r1/R); dgamma=r1, dbeta=r0
- *   use_bn && !is_training: cA=g*rstd(moving), cB=cC=0; dgamma=r1, dbeta=r0
- *   !use_bn               : cA=1, cB=cC=0
- * dbias = sum(dY) = cA*r0 + cB*sum(y) + cC*R   (sum(y) = mean*R).  Any output pointer may be NULL. */
-int gspn_bn_bwd_coeffs(long rows, int c, const double* red, const float* mean, const float* var, const float* gamma, float eps,
-                       int use_bn, int is_training, float* cA, float* cB, float* cC, float* dgamma, float* dbeta, float* dbias, void* stream);
-/* dX(rows,ldx)[:, :cin] = dY . W^T */
+/* Pass A -- ONE read of (X, Y, dz):  the BN reductions r0 = sum(dyh), r1 = sum(dyh*xhat) and the raw
+ * weight-gradient products G1 = act(X)^T.dyh, Gx = act(X)^T.xhat, g3 = act(X)^T.1 are accumulated into
+ * per-row-chunk partials in `work` (gspn_mlp_bwd_work_bytes(rows,cin,cout) bytes; no hot-spot atomics, deterministic
+ * second-stage sum in double), then finalised on the device into
+ *   dW(cin,cout) = cA (.) (G1 - r0/R g3 1^T - r1/R (.) Gx)            (training-mode BN)
+ *                = cA (.) G1                                           (BN on moving statistics, or no BN)
+ *   cA=gamma*rstd (1 without BN), cB=-gamma*rstd^2*r1/R, cC=-gamma*rstd*(r0/R - mean*rstd*r1/R)   (0 outside training)
+ *   dgamma=r1, dbeta=r0 (under BN), dbias=sum(dY).
+ * mean/var are the statistics the forward pass normalised with (batch, or moving when !is_training).
+ * Any of cA..dbias may be NULL. */
+int gspn_mlp_bwd_wgrad(long rows, int cin, int cout, const gspn_dy_args* a, const float* X, int ldx,
+                       const float* in_scale, const float* in_shift, const float* mean, const float* var, const float* gamma,
+                       float eps, int use_bn, int is_training, float* work, float* cA, float* cB, float* cC,
+                       float* dgamma, float* dbeta, float* dbias, float* dW, void* stream);
+long gspn_mlp_bwd_work_bytes(long rows, int cin, int cout);
+/* Pass B -- dX(rows,ldx)[:, :cin] = dY . W^T with dY = cA*dyh + cB*y + cC rebuilt on the fly */
 int gspn_mlp_bwd_data(long rows, int cin, int cout, const gspn_dy_args* a, const float* W, float* dX, int ldx, void* stream);
-/* dW(cin,cout) = act(X)^T . dY   (zeroed here, then accumulated with fp32 atomics over row chunks) */
-int gspn_mlp_bwd_weight(long rows, int cin, int cout, const gspn_dy_args* a, const float* X, int ldx,
-                        const float* in_scale, const float* in_shift, float* dW, void* stream);
 
 int gspn_fill_zero(void* ptr, long bytes, void* stream);
 
