@@ -29,6 +29,8 @@ SIGNATURES = {
     "gspn_dist_policy": [],
     "gspn_abi_version": [],
     "gspn_farthestpointsampling": [_I, _I, _I, _P, _P, _P, _P],
+    "gspn_fps_cells": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
+    "gspn_farthestpointsampling_cells": [_I, _I, _I, _P, _P, _P, _P],
     "gspn_gatherpoint": [_I, _I, _I, _P, _P, _P, _P],
     "gspn_scatteraddpoint": [_I, _I, _I, _P, _P, _P, _P],
     "gspn_probsample": [_I, _I, _I, _P, _P, _P, _P, _P],
@@ -79,6 +81,8 @@ def lib():
         h.gspn_mlp_bwd_work_bytes.restype = _L
         h.gspn_mlp_fwd_stats_bytes.argtypes = [_L, _I]
         h.gspn_mlp_fwd_stats_bytes.restype = _L
+        h.gspn_fps_cells_ws_bytes.argtypes = [_I, _I]
+        h.gspn_fps_cells_ws_bytes.restype = _L
         _lib = h
     return _lib
 

@@ -70,26 +70,23 @@ __global__ __launch_bounds__(FPS_T) void fps_resident_kernel(int n, int m, const
 
     const int t = threadIdx.x;
     const int lane = t & 63;
-    const int wave = t >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);     // provably wave-uniform (keeps loop state in SGPRs)
     const int rho = t >> 1;                       // residue class k mod 512 of this thread
     const int kbase = (t & 1) * P * 512 + rho;    // slot p holds point kbase + p*512
     const float* xyz = inp + (size_t)blockIdx.x * n * 3;
     int* o = out + (size_t)blockIdx.x * m;
 
     v2f x[P / 2], y[P / 2], z[ZLDS ? 1 : P / 2], td[P / 2];
+    // clamped, unconditional loads first (all in flight together), masking afterwards
 #pragma unroll
     for (int p = 0; p < P; ++p) {
         const int k = kbase + p * 512;
-        float px = 0.f, py = 0.f, pz = 0.f;
-        float d0 = -1.0f;                         // padding never wins (real candidates are >= 0)
-        if (k < n) {
-            px = xyz[k * 3 + 0];
-            py = xyz[k * 3 + 1];
-            pz = xyz[k * 3 + 2];
-            d0 = 1e38f;                           // :117-119
-        }
+        const int kc = k < n ? k : n - 1;
+        float px = xyz[kc * 3 + 0], py = xyz[kc * 3 + 1], pz = xyz[kc * 3 + 2];
+        const float d0 = k < n ? 1e38f : -1.0f;   // :117-119; padding never wins (real candidates are >= 0)
+        px = k < n ? px : 0.f; py = k < n ? py : 0.f; pz = k < n ? pz : 0.f;
         // detach x/y/z from the dwordx3 load tuple so the allocator may place them independently
-        asm volatile("" : "+v"(px), "+v"(py), "+v"(pz));
+        asm("" : "+v"(px), "+v"(py), "+v"(pz));
         x[p >> 1][p & 1] = px;
         y[p >> 1][p & 1] = py;
         td[p >> 1][p & 1] = d0;
@@ -211,6 +208,381 @@ __global__ __launch_bounds__(FPS_T) void fps_resident_kernel(int n, int m, const
 #endif
 }
 
+// ============================================================================================
+// Cell-based FPS: same result as fps_resident_kernel, far fewer serial rounds.
+//
+// Host pre-pass (gspn_amd/tf_sampling.py): the scene is sorted into 16 spatial cells of equal size
+// (Morton order), and inside a cell by the reference tie rank (k mod 512, k).  Wave w owns cell w;
+// lane l / slot p hold the cell's (l*P+p)-th point, so "lowest (lane, slot)" is still the reference
+// tie order inside a wave, and waves are compared through rank(k) of their candidates.
+//
+// Two exact shortcuts on top of the resident design:
+//   * culling  -- a wave skips a new centre c entirely when its bounding box is farther from c than
+//     its current max min-distance: no point of it can change (conservative fp32 margin);
+//   * batching -- one synchronisation round publishes every wave's best point and an upper bound on
+//     its runner-up; all waves then accept the longest prefix c1 > c2 > ... (by key) such that each
+//     c_i beats the runner-up bounds of the accepted waves and its min-distance is untouched by the
+//     earlier picks of the round (dist2(c_i, c_j) >= td[c_i], evaluated exactly as the update would).
+//     Those are provably the next picks of the sequential algorithm, so several picks cost one
+//     barrier.  The degenerate tail (max min-distance == 0: every point already chosen or a
+//     duplicate of one) repeats the rank-minimal point, like the reference.
+// ============================================================================================
+#define FPS_AMAX 6        // max picks accepted per round
+#ifdef FPS_PROFILE
+__device__ long long g_cell_prof[32];
+#define CELL_TICK(i) do { const long long _n = clock64(); cprof[i] += _n - ctprev; ctprev = _n; } while (0)
+#else
+#define CELL_TICK(i) do {} while (0)
+#endif
+
+template <int P, bool ZLDS>
+__global__ __launch_bounds__(FPS_T) void fps_cell_kernel(int n, int m, int csz, const float* __restrict__ sxyz, const int* __restrict__ perm,
+                                                         const float* __restrict__ inp0, int inp0_stride, int* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // [0,1024)   : candidates, 2 buffers x 16 waves x {int4 {v bits, x, y, z}, int4 {sorted position, bound bits, -, -}}
+    // [1024,1040): batch record written by wave 0
+    // [1536,1536+64*P): per-wave row for the winning lane's min-distances (refresh)
+    // [4096,..)  : z plane, float4 [P/4][1024]   (ZLDS only)
+    int4* s_cand = reinterpret_cast<int4*>(smem);
+    float* s_trow = reinterpret_cast<float*>(smem + 1536);
+    v4f* s_z = reinterpret_cast<v4f*>(smem + 4096);
+    constexpr int G = FpsGroup<P>::G;
+    constexpr int NG = FpsGroup<P>::NG;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);     // provably wave-uniform (keeps loop state in SGPRs)
+    const float* xyz = sxyz + (size_t)blockIdx.x * n * 3;
+    const int* pm = perm + (size_t)blockIdx.x * n;
+    int* o = out + (size_t)blockIdx.x * m;
+    const int cbase = wave * csz;                         // first sorted position of this wave's cell
+
+    v2f x[P / 2], y[P / 2], z[ZLDS ? 1 : P / 2], td[P / 2];
+    float bx0 = 3e38f, bx1 = -3e38f, by0 = 3e38f, by1 = -3e38f, bz0 = 3e38f, bz1 = -3e38f;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const int q = lane * P + p;
+        const int pos = cbase + q;
+        const bool live = q < csz && pos < n;
+        const int pc = live ? pos : 0;           // clamped, unconditional loads: all in flight together
+        float px = xyz[pc * 3 + 0], py = xyz[pc * 3 + 1], pz = xyz[pc * 3 + 2];
+        // branch-free masking keeps the prologue one basic block, so the scheduler can issue all loads before the first use
+        bx0 = fminf(bx0, live ? px : 3e38f); bx1 = fmaxf(bx1, live ? px : -3e38f);
+        by0 = fminf(by0, live ? py : 3e38f); by1 = fmaxf(by1, live ? py : -3e38f);
+        bz0 = fminf(bz0, live ? pz : 3e38f); bz1 = fmaxf(bz1, live ? pz : -3e38f);
+        const float d0 = live ? 1e38f : -1.0f;
+        px = live ? px : 0.f; py = live ? py : 0.f; pz = live ? pz : 0.f;
+        asm("" : "+v"(px), "+v"(py), "+v"(pz));
+        x[p >> 1][p & 1] = px;
+        y[p >> 1][p & 1] = py;
+        td[p >> 1][p & 1] = d0;
+        if (ZLDS) reinterpret_cast<float*>(s_z)[((p >> 2) * FPS_T + t) * 4 + (p & 3)] = pz;
+        else z[p >> 1][p & 1] = pz;
+    }
+    // wave bounding box (uniform)
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        bx0 = fminf(bx0, __shfl_xor(bx0, s, 64)); bx1 = fmaxf(bx1, __shfl_xor(bx1, s, 64));
+        by0 = fminf(by0, __shfl_xor(by0, s, 64)); by1 = fmaxf(by1, __shfl_xor(by1, s, 64));
+        bz0 = fminf(bz0, __shfl_xor(bz0, s, 64)); bz1 = fmaxf(bz1, __shfl_xor(bz1, s, 64));
+    }
+    bx0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(bx0))); bx1 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(bx1)));
+    by0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(by0))); by1 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(by1)));
+    bz0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(bz0))); bz1 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(bz1)));
+    if (t == 0) o[0] = 0;                                          // tf_sampling_g.cu:114-116
+    __syncthreads();
+
+    // Centres to apply at the top of a round are NOT kept in registers (VGPR budget): they are re-read from the candidate
+    // records of the previous exchange.  acc_list packs the accepted wave ids (4 bits each), abuf is that exchange's buffer.
+    // Round 0 applies original point 0, parked in record 0 of buffer 1.
+    const float* p0 = inp0 + (size_t)blockIdx.x * inp0_stride;
+    if (t == 0) s_cand[2 * FPS_W + 0] = make_int4(0, __float_as_int(p0[0]), __float_as_int(p0[1]), __float_as_int(p0[2]));
+    __syncthreads();
+    int acc_list = 0, abuf = 2 * FPS_W;
+    int nacc = 1;
+    int j = 1;                      // number of outputs written so far
+    int wmax = __float_as_int(1e38f);          // wave's current max min-distance (bits); padding-only waves settle at -1.0f
+    bool dirty = true;
+    // cached candidate of this wave
+    int cv = 0, ck = 0, cpos = 0, cbound = NEG_ONE_BITS;
+    float cfx = 0.f, cfy = 0.f, cfz = 0.f;
+    int round = 0;
+    int termk = 0;
+#ifdef FPS_PROFILE
+    long long cprof[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long ctprev = clock64();
+    int napplied = 0, nrefresh = 0;
+#endif
+
+    int4* s_batch = s_cand + 4 * FPS_W;       // batch record broadcast by wave 0: {nacc, acc_list, terminal, j_new}
+    while (j < m) {
+        // ---- apply the accepted centres (culled per wave) ----
+        // culling, all centres of the round at once: lane u (< nacc) tests centre u against this wave's bounding box.
+        // Conservative in fp32: every point of the wave has dist2 >= L*(1-1e-5); a wave whose max min-distance is below that cannot change.
+        unsigned todo;
+        {
+            const int u = lane < nacc ? lane : 0;
+            const int4 cc = s_cand[abuf + ((acc_list >> (4 * u)) & 15) * 2];
+            const float ccx = __int_as_float(cc.y), ccy = __int_as_float(cc.z), ccz = __int_as_float(cc.w);
+            const float ex = fmaxf(fmaxf(bx0 - ccx, ccx - bx1), 0.f);
+            const float ey = fmaxf(fmaxf(by0 - ccy, ccy - by1), 0.f);
+            const float ez = fmaxf(fmaxf(bz0 - ccz, ccz - bz1), 0.f);
+            const float L = (ex * ex + ey * ey + ez * ez) * 0.99999f;
+            todo = (unsigned)__ballot(lane < nacc && !(L > __int_as_float(wmax)) && wmax >= 0);
+        }
+        while (todo) {
+            const int ci = __builtin_ctz(todo);
+            todo &= todo - 1;
+            const int4 cc = s_cand[abuf + ((acc_list >> (4 * ci)) & 15) * 2];          // uniform address: LDS broadcast
+            const float cx = __int_as_float(__builtin_amdgcn_readfirstlane(cc.y));
+            const float cy = __int_as_float(__builtin_amdgcn_readfirstlane(cc.z));
+            const float cz = __int_as_float(__builtin_amdgcn_readfirstlane(cc.w));
+            if constexpr (ZLDS) {
+                // z quads are double-buffered: the ds_read_b128 of quad i+1 is issued before quad i is consumed, otherwise
+                // a lone active wave exposes the full LDS latency 8 times per pass
+                v4f zq = s_z[t];
+#pragma unroll
+                for (int qd = 0; qd < P / 4; ++qd) {
+                    v4f zn = zq;
+                    if (qd + 1 < P / 4) zn = s_z[(qd + 1) * FPS_T + t];
+                    asm("" : "+v"(zq));
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int pp = qd * 2 + h;
+                        const v2f zz = h == 0 ? zq.xy : zq.zw;
+                        const v2f dx = x[pp] - cx, dy = y[pp] - cy, dz = zz - cz;
+                        v2f d = dy * dy;                                   // dist2_cuda, GSPN_DIST_POLICY 2
+                        d = __builtin_elementwise_fma(dx, dx, d);
+                        d = __builtin_elementwise_fma(dz, dz, d);
+                        td[pp][0] = vmin_f32(d[0], td[pp][0]);
+                        td[pp][1] = vmin_f32(d[1], td[pp][1]);
+                    }
+                    zq = zn;
+                }
+            } else {
+#pragma unroll
+                for (int pp = 0; pp < P / 2; ++pp) {
+                    const v2f dx = x[pp] - cx, dy = y[pp] - cy, dz = z[pp] - cz;
+                    v2f d = dy * dy;                                       // dist2_cuda, GSPN_DIST_POLICY 2
+                    d = __builtin_elementwise_fma(dx, dx, d);
+                    d = __builtin_elementwise_fma(dz, dz, d);
+                    td[pp][0] = vmin_f32(d[0], td[pp][0]);
+                    td[pp][1] = vmin_f32(d[1], td[pp][1]);
+                }
+            }
+            dirty = true;
+#ifdef FPS_PROFILE
+            ++napplied;
+#endif
+        }
+        CELL_TICK(0);
+
+        // ---- refresh this wave's candidate (best point + runner-up bound) if anything changed ----
+        if (dirty) {
+            int best = NEG_ONE_BITS;             // per-lane max over its slots (only dirty waves pay for this)
+#pragma unroll
+            for (int pp = 0; pp < P / 2; ++pp) best = vmax3_i32(best, __float_as_int(td[pp][0]), __float_as_int(td[pp][1]));
+            wmax = wave_max_i32(best);
+            const int lw = __builtin_ctzll(__ballot(best == wmax));
+            // runner-up bound, part 1: best of the other lanes
+            const int s1 = wave_max_i32(lane == lw ? NEG_ONE_BITS : best);
+            // The winning lane spills its P min-distances to a per-wave LDS row; the wave then finds the winning slot (lowest
+            // slot on ties) and the runner-up inside that lane with one value per lane -- no per-lane compare chains, which
+            // the 128-VGPR budget of P=32 cannot afford.
+            float* trow = s_trow + wave * P;
+            if (lane == lw) {
+#pragma unroll
+                for (int p = 0; p < P; p += 2) *reinterpret_cast<v2f*>(trow + p) = td[p >> 1];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            const int tv = lane < P ? __float_as_int(trow[lane]) : NEG_ONE_BITS;
+            const int fp = __builtin_ctzll(__ballot(tv == wmax));
+            const int s2 = wave_max_i32(lane == fp ? NEG_ONE_BITS : tv);
+            const int qw = fp / G, iw = fp % G;
+            float fx = 0.f, fy = 0.f, fz = 0.f;
+#pragma unroll
+            for (int q = 0; q < NG; ++q) {
+                if (qw == q) {
+#pragma unroll
+                    for (int i = 0; i < G; ++i) {
+                        if (iw == i) {
+                            const int p = q * G + i;
+                            fx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x[p >> 1][p & 1]), lw));
+                            fy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y[p >> 1][p & 1]), lw));
+                            if (!ZLDS) fz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(z[ZLDS ? 0 : (p >> 1)][p & 1]), lw));
+                        }
+                    }
+                }
+            }
+            if (ZLDS) fz = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(
+                        reinterpret_cast<const float*>(s_z)[((fp >> 2) * FPS_T + wave * 64 + lw) * 4 + (fp & 3)])));
+            const int pos = cbase + lw * P + fp;
+            cv = wmax;
+            cpos = (wmax >= 0 && pos < n) ? pos : 0;
+            {
+                // a VECTOR load on purpose: a uniform address would be scalarised to s_load, whose completion is counted on
+                // lgkmcnt together with every LDS access -- each ds_read/ds_write wait below would then also wait for HBM
+                int voff = 0;
+                asm volatile("" : "+v"(voff));
+                ck = pm[cpos + voff];      // original index: consumed only when this candidate is accepted (latency hidden behind the exchange)
+            }
+            cbound = max(s1, s2);
+            cfx = fx; cfy = fy; cfz = fz;
+            dirty = false;
+#ifdef FPS_PROFILE
+            ++nrefresh;
+#endif
+        }
+        CELL_TICK(1);
+        const int buf = (round & 1) * 2 * FPS_W;
+        ++round;
+        if (lane == 0) {
+            s_cand[buf + wave * 2 + 0] = make_int4(cv, __float_as_int(cfx), __float_as_int(cfy), __float_as_int(cfz));
+            s_cand[buf + wave * 2 + 1] = make_int4(cpos, cbound, 0, 0);
+        }
+        __syncthreads();
+        CELL_TICK(2);
+
+        // ---- batch selection, distributed: every wave ranks ITS OWN candidate (how many candidates beat it) and finds which
+        //      candidates would spoil it (dist2(own, other) < own min-distance), publishes those two words, and after a second
+        //      barrier the accept scan is a handful of scalar bit operations per pick, done redundantly by every wave ----
+        int2* s_info = reinterpret_cast<int2*>(smem + 1280) + (round & 1) * FPS_W;
+        const int l15 = lane & 15;
+        const int4 mine = s_cand[buf + l15 * 2];                  // candidate l15: {v, x, y, z}
+        {
+            const unsigned better = (unsigned)(__ballot(mine.x > cv) & 0xFFFFull);
+            const unsigned equal = (unsigned)(__ballot(mine.x == cv && l15 != wave) & 0xFFFFull);
+            // dist2(point = own candidate, centre = candidate l15), exactly as the update would evaluate it
+            const float dd = dist2_cuda(cfx - __int_as_float(mine.y), cfy - __int_as_float(mine.z), cfz - __int_as_float(mine.w));
+            const unsigned conf = (unsigned)(__ballot(l15 != wave && mine.x >= 0 && dd < __int_as_float(cv)) & 0xFFFFull);
+            int cnt = __builtin_popcount(better);
+            if (cv < 0) cnt = 64;                                 // empty / padding-only waves never rank
+            if (lane == 0) s_info[wave] = make_int2(cnt | ((equal != 0u && cv >= 0) ? 256 : 0), (int)conf);
+        }
+        __syncthreads();
+        CELL_TICK(4);
+        const int2 info = s_info[l15];
+        const int bnd_l = s_cand[buf + l15 * 2 + 1].y;
+        const bool slow = __ballot((info.x & 256) && (info.x & 255) < FPS_AMAX) != 0ull;    // equal values among the leaders (rare)
+        if (!slow) {
+            // accept scan, redundantly in every wave: a few scalar bit operations per pick
+            int na = 0, alist = 0, term = 0;
+            unsigned acc_mask = 0;
+            int bmax = NEG_ONE_BITS;
+            bool go = true;
+#pragma unroll
+            for (int p = 0; p < FPS_AMAX; ++p) {
+                const unsigned mk = (unsigned)(__ballot((info.x & 255) == p) & 0xFFFFull);
+                if (go && mk != 0u && (j + p) < m) {
+                    const int w = __builtin_ctz(mk);
+                    const int vw = __builtin_amdgcn_readlane(mine.x, w);
+                    const unsigned cf = (unsigned)__builtin_amdgcn_readlane(info.y, w);
+                    if (p == 0 && vw == 0) {                      // everything is covered: the sequential algorithm repeats this pick forever
+                        int voff = 0;
+                        asm volatile("" : "+v"(voff));
+                        term = 1 + __builtin_amdgcn_readfirstlane(pm[__builtin_amdgcn_readlane(s_cand[buf + l15 * 2 + 1].x, w) + voff]);
+                        go = false;
+                    } else if (p == 0 || ((cf & acc_mask) == 0u && vw > bmax)) {
+                        acc_mask |= 1u << w;
+                        bmax = max(bmax, __builtin_amdgcn_readlane(bnd_l, w));
+                        alist |= w << (4 * p);
+                        ++na;
+                    } else {
+                        go = false;
+                    }
+                } else {
+                    go = false;
+                }
+            }
+            nacc = na;
+            acc_list = alist;
+            abuf = buf;
+            termk = term;
+            for (int u = 0; u < nacc; ++u)
+                if (((acc_list >> (4 * u)) & 15) == wave) {            // own candidate accepted as pick number j+u: write it, mark consumed
+                    if (lane == 0) o[j + u] = ck;
+                    dirty = true;
+                }
+            j += na;
+            CELL_TICK(3);
+            if (termk != 0) break;
+            continue;
+        }
+        // ---- slow path: wave 0 extracts serially with reference-rank tie-breaks, then broadcasts ----
+        if (wave == 0) {
+            int na = 0, alist = 0, term = 0, jn = j;
+            int remaining = mine.x;               // value bits; -1.0f once consumed
+            unsigned acc_mask = 0;                // bit w: wave w's candidate accepted this round
+            int bound = NEG_ONE_BITS;             // max runner-up bound among accepted waves
+#pragma unroll 1
+            for (int i = 0; i < FPS_AMAX && jn < m; ++i) {
+                const int M = __builtin_amdgcn_readfirstlane(row_max_i32(remaining));
+                if (M < 0) break;                                   // no candidate left
+                unsigned long long eq = __ballot(remaining == M) & 0xFFFFull;
+                int wsel = __builtin_ctzll(eq);
+                if (__builtin_popcountll(eq) > 1) {                 // equal values in several waves: lowest reference rank wins
+                    unsigned rmin = 0xFFFFFFFFu;
+#pragma unroll 1
+                    for (int w = 0; w < 16; ++w)
+                        if ((eq >> w) & 1ull) {
+                            const int kw = pm[__builtin_amdgcn_readfirstlane(s_cand[buf + w * 2 + 1].x)];
+                            const unsigned rw = ((unsigned)(kw & 511) << 22) | (unsigned)(kw >> 9);
+                            if (rw < rmin) { rmin = rw; wsel = w; }
+                        }
+                }
+                if (i == 0 && M == 0) {                             // everything is covered
+                    term = 1 + pm[__builtin_amdgcn_readfirstlane(s_cand[buf + wsel * 2 + 1].x)];
+                    break;
+                }
+                const int4 sa = s_cand[buf + wsel * 2];
+                const int sbound = s_cand[buf + wsel * 2 + 1].y;
+                if (i > 0) {
+                    if (!(M > bound)) break;
+                    const float dd = dist2_cuda(__int_as_float(sa.y) - __int_as_float(mine.y), __int_as_float(sa.z) - __int_as_float(mine.z),
+                                                __int_as_float(sa.w) - __int_as_float(mine.w));
+                    const bool hit = ((acc_mask >> l15) & 1u) && (dd < __int_as_float(M));
+                    if (__ballot(hit) != 0ull) break;
+                }
+                alist |= wsel << (4 * na);
+                ++na;
+                acc_mask |= 1u << wsel;
+                bound = max(bound, __builtin_amdgcn_readfirstlane(sbound));
+                remaining = (l15 == wsel) ? NEG_ONE_BITS : remaining;
+                ++jn;
+            }
+            if (lane == 0) *s_batch = make_int4(na, alist, term, jn);
+        }
+        __syncthreads();
+        {
+            const int4 br = *s_batch;
+            nacc = __builtin_amdgcn_readfirstlane(br.x);
+            acc_list = __builtin_amdgcn_readfirstlane(br.y);
+            abuf = buf;
+            termk = __builtin_amdgcn_readfirstlane(br.z);
+            const int jnew = __builtin_amdgcn_readfirstlane(br.w);
+            for (int u = 0; u < nacc; ++u)
+                if (((acc_list >> (4 * u)) & 15) == wave) {
+                    if (lane == 0) o[j + u] = ck;
+                    dirty = true;
+                }
+            j = jnew;
+            CELL_TICK(3);
+            if (termk != 0) break;
+        }
+    }
+    // degenerate tail (max min-distance == 0): the reference keeps returning the rank-minimal covered point
+    if (termk != 0)
+        for (int jj = j + t; jj < m; jj += FPS_T) o[jj] = termk - 1;
+#ifdef FPS_PROFILE
+    if (blockIdx.x == 0 && (t == 0 || t == FPS_T - 64)) {
+        long long* d = g_cell_prof + (t ? 16 : 0);
+        for (int i = 0; i < 4; ++i) d[i] = cprof[i];
+        d[4] = round; d[5] = napplied; d[6] = nrefresh;
+        for (int i = 4; i < 10; ++i) d[4 + i] = cprof[i];
+    }
+#endif
+}
+
 // Fallback for scenes that do not fit one CU (n > 32768): one 1024-thread workgroup per scene
 // slot, min-dist in the caller's scratch (L2 resident), 64-bit (dist, tie-rank) keys.
 // Thread t visits k = t, t+1024, ... so k mod 512 == t mod 512 for all of its points.
@@ -277,6 +649,171 @@ static int launch_fps_resident(int b, int n, int m, const float* inp, int* out, 
     }
     hipLaunchKernelGGL((fps_resident_kernel<P, ZLDS>), dim3(b), dim3(FPS_T), lds, st, n, m, inp, out);
     return gspn_launch_status();
+}
+
+// ============================================================================================
+// Pre-pass of the cell-based FPS: spatial partition of every scene into 16 cells of csz = ceil(n/16)
+// points, reference tie rank (k mod 512, k) ascending inside a cell.  Any partition gives the same
+// FPS result (the kernel is exact for every assignment of points to cells); compact cells only make
+// culling and batching effective.
+//   K1 fps_bin_kernel   (one 1024-thread workgroup per scene): bounding box -> 12-bit Morton voxel id
+//      (4 bits per axis) -> LDS histogram -> exclusive scan -> counting-sort scatter of the points'
+//      rank keys into voxel order (order inside a voxel is whatever the LDS atomics produce).
+//   K2 fps_cellsort_kernel (one workgroup per (cell, scene)): bitonic sort of the cell's <= 2048 rank
+//      keys in LDS, then perm[] (rank -> original index) and the gathered coordinates are written out.
+// ============================================================================================
+__device__ __forceinline__ unsigned spread4(unsigned v) { return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4) | ((v & 8u) << 6); }
+
+__global__ __launch_bounds__(1024) void fps_bin_kernel(int n, const float* __restrict__ inp, unsigned* __restrict__ keys) {
+    __shared__ int hist[4096];
+    __shared__ float red[6][16];
+    __shared__ int wsum[16];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const float* xyz = inp + (size_t)blockIdx.x * n * 3;
+    unsigned* out = keys + (size_t)blockIdx.x * n;
+    // ---- bounding box ----
+    float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f};
+    for (int k = t; k < n; k += 1024)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { const float v = xyz[k * 3 + a]; lo[a] = fminf(lo[a], v); hi[a] = fmaxf(hi[a], v); }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int s2 = 32; s2 >= 1; s2 >>= 1) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], s2, 64)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], s2, 64)); }
+        if (lane == 0) { red[a][wave] = lo[a]; red[3 + a][wave] = hi[a]; }
+    }
+    for (int i = t; i < 4096; i += 1024) hist[i] = 0;
+    __syncthreads();
+    float inv[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float l = red[a][0], h = red[3 + a][0];
+        for (int w = 1; w < 16; ++w) { l = fminf(l, red[a][w]); h = fmaxf(h, red[3 + a][w]); }
+        lo[a] = l;
+        inv[a] = (h > l) ? 16.0f / (h - l) : 0.0f;
+    }
+    auto voxel = [&](int k) {
+        unsigned q[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            int v = (int)((xyz[k * 3 + a] - lo[a]) * inv[a]);
+            q[a] = (unsigned)(v < 0 ? 0 : (v > 15 ? 15 : v));
+        }
+        return spread4(q[0]) | (spread4(q[1]) << 1) | (spread4(q[2]) << 2);
+    };
+    // ---- histogram ----
+    for (int k = t; k < n; k += 1024) atomicAdd(&hist[voxel(k)], 1);
+    __syncthreads();
+    // ---- exclusive scan of 4096 bins: 4 bins per thread, wave scan, 16 wave totals ----
+    int c0 = hist[4 * t], c1 = hist[4 * t + 1], c2 = hist[4 * t + 2], c3 = hist[4 * t + 3];
+    const int tot = c0 + c1 + c2 + c3;
+    int incl = tot;
+#pragma unroll
+    for (int s2 = 1; s2 < 64; s2 <<= 1) { const int o = __shfl_up(incl, s2, 64); if (lane >= s2) incl += o; }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+    const int excl = base + incl - tot;
+    hist[4 * t] = excl; hist[4 * t + 1] = excl + c0; hist[4 * t + 2] = excl + c0 + c1; hist[4 * t + 3] = excl + c0 + c1 + c2;
+    __syncthreads();
+    // ---- scatter the reference tie ranks into voxel order ----
+    for (int k = t; k < n; k += 1024) {
+        const int pos = atomicAdd(&hist[voxel(k)], 1);
+        out[pos] = ((unsigned)(k & 511) << 22) | (unsigned)(k >> 9);
+    }
+}
+
+template <int SZ>      // SZ = power of two >= csz, <= 2048; block = SZ/2 threads
+__global__ void fps_cellsort_kernel(int n, int csz, const float* __restrict__ inp, const unsigned* __restrict__ keys,
+                                    float* __restrict__ sxyz, int* __restrict__ perm) {
+    __shared__ unsigned sk[SZ];
+    const int cell = blockIdx.x, scene = blockIdx.y;
+    const int t = threadIdx.x;
+    const int begin = cell * csz;
+    const int cnt = min(csz, n - begin) > 0 ? min(csz, n - begin) : 0;
+    const unsigned* src = keys + (size_t)scene * n + begin;
+    for (int i = t; i < SZ; i += SZ / 2) sk[i] = i < cnt ? src[i] : 0xFFFFFFFFu;
+    __syncthreads();
+    for (int k = 2; k <= SZ; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));       // lower index of the t-th pair at distance j
+            const int p = i | j;
+            const bool up = (i & k) == 0;
+            const unsigned a = sk[i], b2 = sk[p];
+            if ((a > b2) == up) { sk[i] = b2; sk[p] = a; }
+            __syncthreads();
+        }
+    }
+    const float* xyz = inp + (size_t)scene * n * 3;
+    for (int i = t; i < cnt; i += SZ / 2) {
+        const unsigned r = sk[i];
+        const int k = (int)(((r & 0x3FFFFFu) << 9) | (r >> 22));
+        const size_t pos = (size_t)scene * n + begin + i;
+        perm[pos] = k;
+        sxyz[pos * 3 + 0] = xyz[k * 3 + 0];
+        sxyz[pos * 3 + 1] = xyz[k * 3 + 1];
+        sxyz[pos * 3 + 2] = xyz[k * 3 + 2];
+    }
+}
+
+template <int P, bool ZLDS>
+static int launch_fps_cell(int b, int n, int m, int csz, const float* sxyz, const int* perm, const float* inp0, int stride0, int* out, hipStream_t st) {
+    const size_t lds = 4096 + (ZLDS ? (size_t)P * FPS_T * sizeof(float) : 0);
+    if (ZLDS) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fps_cell_kernel<P, ZLDS>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL((fps_cell_kernel<P, ZLDS>), dim3(b), dim3(FPS_T), lds, st, n, m, csz, sxyz, perm, inp0, stride0, out);
+    return gspn_launch_status();
+}
+// FPS on a spatially pre-sorted scene (see fps_cell_kernel): sxyz (b,n,3) = inp gathered by perm (b,n) [sorted position -> original
+// index]; the sort is 16 equal cells of csz = ceil(n/16) points in Morton order, reference tie rank (k mod 512, k) inside a cell;
+// inp0 (b,3) = coordinates of original point 0 of every scene.  Same output as gspn_farthestpointsampling.
+static int gspn_fps_cells_strided(int b, int n, int m, int csz, const float* sxyz, const int* perm, const float* inp0, int stride0, int* out, void* stream) {
+    if (b < 0 || n <= 0 || m <= 0 || csz <= 0 || (long long)csz * 16 < n) return GSPN_ERR_ARG;
+    if (b == 0) return 0;
+    if (!sxyz || !perm || !inp0 || !out) return GSPN_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (csz <= 64 * 2) return launch_fps_cell<2, false>(b, n, m, csz, sxyz, perm, inp0, stride0, out, st);
+    if (csz <= 64 * 4) return launch_fps_cell<4, false>(b, n, m, csz, sxyz, perm, inp0, stride0, out, st);
+    if (csz <= 64 * 8) return launch_fps_cell<8, false>(b, n, m, csz, sxyz, perm, inp0, stride0, out, st);
+    if (csz <= 64 * 16) return launch_fps_cell<16, false>(b, n, m, csz, sxyz, perm, inp0, stride0, out, st);
+    if (csz <= 64 * 32) return launch_fps_cell<32, true>(b, n, m, csz, sxyz, perm, inp0, stride0, out, st);
+    return GSPN_ERR_UNSUPPORTED;
+}
+extern "C" int gspn_fps_cells(int b, int n, int m, int csz, const float* sxyz, const int* perm, const float* inp0, int* out, void* stream) {
+    return gspn_fps_cells_strided(b, n, m, csz, sxyz, perm, inp0, 3, out, stream);
+}
+
+// workspace of gspn_farthestpointsampling_cells: [keys: b*n u32][perm: b*n i32][sxyz: b*n*3 f32]
+extern "C" long gspn_fps_cells_ws_bytes(int b, int n) {
+    if (b < 0 || n <= 0) return GSPN_ERR_ARG;
+    return (long)b * n * (4 + 4 + 12);
+}
+// Drop-in for gspn_farthestpointsampling (identical output) for 64 <= n <= 32768: pre-pass + fps_cell_kernel, all on `stream`.
+extern "C" int gspn_farthestpointsampling_cells(int b, int n, int m, const float* inp, void* ws, int* out, void* stream) {
+    if (b < 0 || n <= 0 || m <= 0) return GSPN_ERR_ARG;
+    if (b == 0) return 0;
+    if (!inp || !ws || !out) return GSPN_ERR_ARG;
+    if (n > GSPN_FPS_RESIDENT_MAX || b > 65535) return GSPN_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned* keys = reinterpret_cast<unsigned*>(ws);
+    int* perm = reinterpret_cast<int*>(keys + (size_t)b * n);
+    float* sxyz = reinterpret_cast<float*>(perm + (size_t)b * n);
+    const int csz = (n + 15) / 16;
+    hipLaunchKernelGGL(fps_bin_kernel, dim3(b), dim3(1024), 0, st, n, inp, keys);
+    const dim3 g2(16, b);
+    if (csz <= 128) hipLaunchKernelGGL(fps_cellsort_kernel<128>, g2, dim3(64), 0, st, n, csz, inp, keys, sxyz, perm);
+    else if (csz <= 256) hipLaunchKernelGGL(fps_cellsort_kernel<256>, g2, dim3(128), 0, st, n, csz, inp, keys, sxyz, perm);
+    else if (csz <= 512) hipLaunchKernelGGL(fps_cellsort_kernel<512>, g2, dim3(256), 0, st, n, csz, inp, keys, sxyz, perm);
+    else if (csz <= 1024) hipLaunchKernelGGL(fps_cellsort_kernel<1024>, g2, dim3(512), 0, st, n, csz, inp, keys, sxyz, perm);
+    else hipLaunchKernelGGL(fps_cellsort_kernel<2048>, g2, dim3(1024), 0, st, n, csz, inp, keys, sxyz, perm);
+    int rc = gspn_launch_status();
+    if (rc) return rc;
+    // original point 0 of scene i is inp[i*n*3 ..]: a strided view, the kernel only needs a pointer + stride -> pass inp with stride n*3
+    return gspn_fps_cells_strided(b, n, m, csz, sxyz, perm, inp, n * 3, out, stream);
 }
 
 extern "C" int gspn_farthestpointsampling(int b, int n, int m, const float* inp, float* temp, int* out, void* stream) {

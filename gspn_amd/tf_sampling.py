@@ -1,5 +1,7 @@
 """Drop-in for tf_ops/sampling/tf_sampling.py: same function names, argument order and
 gradients, over torch tensors on a ROCm device."""
+import os
+
 import torch
 
 from . import _lib as L
@@ -7,6 +9,38 @@ from . import _lib as L
 # bench.py sets this to a list to collect (start_event, end_event, b, n, m) around every FPS launch,
 # recorded on the stream the kernel is launched on (roofline.achieved is measured live from these)
 PROFILE = None
+
+
+# 'cells' (default): HIP spatial pre-pass + fps_cell_kernel (batched, culled; identical output) for n >= FPS_CELLS_MIN_N;
+# 'resident': always the plain on-chip kernel; 'cells_torch': cell kernel on a torch-side pre-sort (tests: arbitrary partitions)
+FPS_MODE = os.environ.get("GSPN_FPS_MODE", "cells")
+FPS_CELLS_MIN_N = int(os.environ.get("GSPN_FPS_CELLS_MIN_N", "8192"))
+
+
+def _spread10(v):
+    v = (v | (v << 16)) & 0x030000FF
+    v = (v | (v << 8)) & 0x0300F00F
+    v = (v | (v << 4)) & 0x030C30C3
+    v = (v | (v << 2)) & 0x09249249
+    return v
+
+
+def _cell_prepass(inp):
+    """Sort every scene into 16 equal Morton cells, reference tie rank (k mod 512, k) inside a cell.
+    Returns sxyz (b,n,3), perm (b,n) int32 [sorted position -> original index], csz."""
+    b, n, _ = inp.shape
+    lo = inp.amin(dim=1, keepdim=True)
+    ext = (inp.amax(dim=1, keepdim=True) - lo).clamp_min(1e-30)
+    q = ((inp - lo) / ext * 1024.0).to(torch.int64).clamp_(0, 1023)
+    code = _spread10(q[..., 0]) | (_spread10(q[..., 1]) << 1) | (_spread10(q[..., 2]) << 2)
+    order = torch.argsort(code, dim=1, stable=True)
+    csz = (n + 15) // 16
+    cell = (torch.arange(n, device=inp.device, dtype=torch.int64) // csz).unsqueeze(0)
+    rank = ((order & 511) << 22) | (order >> 9)
+    o2 = torch.argsort((cell << 32) | rank, dim=1)
+    perm = torch.gather(order, 1, o2)
+    sxyz = torch.gather(inp, 1, perm.unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    return sxyz, perm.to(torch.int32).contiguous(), csz
 
 
 def farthest_point_sample(npoint, inp):
@@ -28,8 +62,18 @@ def farthest_point_sample(npoint, inp):
         if PROFILE is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        L.check(L.lib().gspn_farthestpointsampling(b, n, npoint, L.ptr(inp), L.ptr(temp), L.ptr(out), L.stream()),
-                "farthest_point_sample")
+        if FPS_MODE == "cells" and FPS_CELLS_MIN_N <= n <= 32768:
+            ws = torch.empty(int(L.lib().gspn_fps_cells_ws_bytes(b, n)) // 4, dtype=torch.float32, device=inp.device)
+            L.check(L.lib().gspn_farthestpointsampling_cells(b, n, npoint, L.ptr(inp), L.ptr(ws), L.ptr(out), L.stream()),
+                    "farthest_point_sample(cells)")
+        elif FPS_MODE == "cells_torch" and 64 <= n <= 32768:
+            sxyz, perm, csz = _cell_prepass(inp)
+            inp0 = inp[:, 0, :].contiguous()
+            L.check(L.lib().gspn_fps_cells(b, n, npoint, csz, L.ptr(sxyz), L.ptr(perm), L.ptr(inp0), L.ptr(out), L.stream()),
+                    "farthest_point_sample(cells)")
+        else:
+            L.check(L.lib().gspn_farthestpointsampling(b, n, npoint, L.ptr(inp), L.ptr(temp), L.ptr(out), L.stream()),
+                    "farthest_point_sample")
         if ev is not None:
             ev[1].record()
             PROFILE.append((ev[0], ev[1], b, n, npoint))

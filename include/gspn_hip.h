@@ -40,6 +40,17 @@ int gspn_abi_version(void);
 #define GSPN_FPS_RESIDENT_MAX 32768
 int gspn_farthestpointsampling(int b, int n, int m, const float* inp, float* temp, int* out, void* stream);
 
+/* Same result as gspn_farthestpointsampling, several times fewer serial rounds: FPS on a scene that the caller has sorted into
+ * 16 spatial cells (csz = ceil(n/16) points each, Morton order; inside a cell by the reference tie rank (k mod 512, k)):
+ *   sxyz (b,n,3) = inp gathered by perm;  perm (b,n) i32: sorted position -> original index;  inp0 (b,3) = original point 0.
+ * One wave per cell; exact wave culling by bounding box and several provably-sequential picks per barrier
+ * (gspn_amd/csrc/sampling.hip: fps_cell_kernel).  Requires csz <= 2048 (n <= 32768). */
+int gspn_fps_cells(int b, int n, int m, int csz, const float* sxyz, const int* perm, const float* inp0, int* out, void* stream);
+/* Drop-in for gspn_farthestpointsampling with identical output (n <= 32768): runs the spatial pre-pass (voxel counting sort +
+ * per-cell rank sort, two small kernels) and the cell kernel on `stream`.  ws: gspn_fps_cells_ws_bytes(b,n) bytes of scratch. */
+long gspn_fps_cells_ws_bytes(int b, int n);
+int gspn_farthestpointsampling_cells(int b, int n, int m, const float* inp, void* ws, int* out, void* stream);
+
 /* gatherpointLauncher(b,n,m,inp,idx,out)  tf_sampling.cpp:125, tf_sampling_g.cu:206-208 */
 int gspn_gatherpoint(int b, int n, int m, const float* inp, const int* idx, float* out, void* stream);
 

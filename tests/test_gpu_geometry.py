@@ -30,6 +30,20 @@ def test_fps_matches_oracle(kind, b, n, m):
     np.testing.assert_array_equal(got, ref)
 
 
+@pytest.mark.parametrize("mode,min_n", [("cells", 64), ("cells_torch", 64), ("resident", 0)])
+@pytest.mark.parametrize("kind,b,n,m", [("U", 2, 4096, 700), ("D", 2, 9000, 1200), ("S", 1, 20000, 900), ("D", 1, 32768, 1500),
+                                        ("U", 3, 1000, 1100), ("D", 2, 300, 64), ("U", 1, 64, 64)])
+def test_fps_all_kernels_agree_with_oracle(mode, min_n, kind, b, n, m, monkeypatch):
+    """the cell kernel (HIP pre-pass or an arbitrary torch-side partition) and the resident kernel return the same indices"""
+    from gspn_amd import tf_sampling
+    monkeypatch.setattr(tf_sampling, "FPS_MODE", mode)
+    monkeypatch.setattr(tf_sampling, "FPS_CELLS_MIN_N", min_n)
+    xyz = D.batch(kind, b, n, 3)
+    ref = O.farthest_point_sample(m, xyz)
+    got = tf_sampling.farthest_point_sample(m, dev(xyz)).cpu().numpy()
+    np.testing.assert_array_equal(got, ref)
+
+
 def test_fps_streaming_large_n():
     from gspn_amd.tf_sampling import farthest_point_sample
     xyz = D.batch("D", 2, 40000)
