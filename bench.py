@@ -63,7 +63,7 @@ def main():
         out = pn2_fea_extractor(xyz, col, 'fea', True, 0.5)
         loss = (out * gout).sum() * (1.0 / out.numel())
         if state["opt"] is not None:
-            state["opt"].zero_grad(set_to_none=False)
+            state["opt"].zero_grad(set_to_none=True)      # backward assigns fresh grads; the bucket re-points them at its slices
         loss.backward()
         if state["bucket"] is None:
             params = store.parameters()

@@ -443,7 +443,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_wgrad_kernel(long rows, int cin, 
                                                             const float* __restrict__ in_scale, const float* __restrict__ in_shift,
                                                             const float* __restrict__ mean, const float* __restrict__ var, float eps,
                                                             float* __restrict__ RP, float* __restrict__ GP, float* __restrict__ PP,
-                                                            long rows_per_chunk) {
+                                                            long rows_per_chunk, int nslots) {
     // per-chunk partial outputs (no hot-spot atomics; summed by the finalize kernels):
     //   RP[chunk][2][cout] = (sum dyh, sum dyh*xhat)   GP[chunk][cin] = column sums of A   PP[chunk][2][cin][cout] = (A^T.dyh, A^T.xhat)
     constexpr int BM = 32 * MT, BN = 32 * NTT;
@@ -584,40 +584,24 @@ __global__ __launch_bounds__(256) void mlp_bwd_wgrad_kernel(long rows, int cin, 
         __syncthreads();
     }
     // ---- epilogue: this chunk's partial tiles / sums ----
-    float* P1 = PP + (size_t)blockIdx.x * 2 * cin * cout;
+    float* P1 = PP + (size_t)(blockIdx.x % nslots) * 2 * cin * cout;      // shared by nch/nslots chunks: zeroed by the launcher
     float* Px = P1 + (size_t)cin * cout;
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
         const int slot = wave + 4 * i;
         if (slot < T * WK) {
-            const int tile = slot % T, kp = slot / T;
+            const int tile = slot % T;
             const int tm = tile % MT, tn = tile / MT;
             const int col = n0 + tn * 32 + (lane & 31);
-            if (WK == 1) {
-                if (col < cout) {
+            if (col < cout) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int m = m0 + tm * 32 + c_row(r, lane);
-                        if (m < cin) {
-                            P1[(size_t)m * cout + col] = acc1[i][r];
-                            if (WANT_GX) Px[(size_t)m * cout + col] = accx[i][r];
-                        }
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + tm * 32 + c_row(r, lane);
+                    if (m < cin) {
+                        atomicAdd(P1 + (size_t)m * cout + col, acc1[i][r]);
+                        if (WANT_GX) atomicAdd(Px + (size_t)m * cout + col, accx[i][r]);
                     }
                 }
-            } else {
-                // WK waves own K-slices of the same 32x32 tile: the chunk's partial is their sum -> plain float atomics into
-                // THIS chunk's private (zeroed) tile: at most 4-way, no cross-workgroup contention
-                if (col < cout) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int m = m0 + tm * 32 + c_row(r, lane);
-                        if (m < cin) {
-                            atomicAdd(P1 + (size_t)m * cout + col, acc1[i][r]);
-                            if (WANT_GX) atomicAdd(Px + (size_t)m * cout + col, accx[i][r]);
-                        }
-                    }
-                }
-                (void)kp;
             }
         }
     }
@@ -645,7 +629,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_wgrad_kernel(long rows, int cin, 
 }
 
 // ---- second stage: sum the per-chunk partials (double), then coefficients / parameter gradients / dW ----
-struct WgradPlan { int MTs, NTs, nrow, ncol, TKW; long rpc, nch; };
+struct WgradPlan { int MTs, NTs, nrow, ncol, TKW; long rpc, nch, nslots; };
 static WgradPlan wgrad_plan(long rows, int cin, int cout) {
     WgradPlan p;
     const int mt = (cin + 31) / 32, nt = (cout + 31) / 32;
@@ -657,14 +641,17 @@ static WgradPlan wgrad_plan(long rows, int cin, int cout) {
     static const int tkw[4][3] = {{128, 64, 32}, {64, 64, 32}, {64, 32, 32}, {64, 32, 32}};     // [MT-1][NT: 1,2,4]
     p.TKW = tkw[p.MTs - 1][p.NTs == 1 ? 0 : (p.NTs == 2 ? 1 : 2)];
     long chunks = (256L * 3) / (p.ncol * p.nrow);
-    const long cap = (12L << 20) / (8L * cin * cout);        // keep the partial-tile workspace <= ~12 MB
-    if (chunks > cap) chunks = cap;
     if (chunks < 1) chunks = 1;
     long rpc = (rows + chunks - 1) / chunks;
     if (rpc < 4L * p.TKW) rpc = 4L * p.TKW;
     p.rpc = (rpc + p.TKW - 1) / p.TKW * p.TKW;
     p.nch = (rows + p.rpc - 1) / p.rpc;
     if (p.nch < 1) p.nch = 1;
+    // partial-tile slots: chunk c accumulates into slot c % nslots (fp32 atomics, contention <= nch/nslots); the slot count keeps
+    // the workspace around <= 12 MB while the chunk count stays high enough to fill the chip
+    long cap = (12L << 20) / (8L * cin * cout);
+    if (cap < 8) cap = 8;
+    p.nslots = p.nch < cap ? p.nch : cap;
     return p;
 }
 // workspace: [red: 2*cout doubles][g3: cin floats, padded to 4][RP: nch*2*cout][GP: nch*cin][PP: nch*2*cin*cout]
@@ -672,10 +659,11 @@ static size_t ws_off_g3(int cout) { return sizeof(double) * 2 * (size_t)cout; }
 static size_t ws_off_rp(int cin, int cout) { return ws_off_g3(cout) + sizeof(float) * (size_t)((cin + 3) / 4 * 4); }
 static size_t ws_off_gp(long nch, int cin, int cout) { return ws_off_rp(cin, cout) + sizeof(float) * (size_t)nch * 2 * cout; }
 static size_t ws_off_pp(long nch, int cin, int cout) { return (ws_off_gp(nch, cin, cout) + sizeof(float) * (size_t)nch * cin + 15) / 16 * 16; }
-static size_t ws_total(long nch, int cin, int cout) { return ws_off_pp(nch, cin, cout) + sizeof(float) * (size_t)nch * 2 * cin * cout; }
+static size_t ws_total(long nch, long nslots, int cin, int cout) { return ws_off_pp(nch, cin, cout) + sizeof(float) * (size_t)nslots * 2 * cin * cout; }
 extern "C" long gspn_mlp_bwd_work_bytes(long rows, int cin, int cout) {
     if (rows <= 0 || cin <= 0 || cout <= 0) return GSPN_ERR_ARG;
-    return (long)ws_total(wgrad_plan(rows, cin, cout).nch, cin, cout);
+    const WgradPlan p = wgrad_plan(rows, cin, cout);
+    return (long)ws_total(p.nch, p.nslots, cin, cout);
 }
 
 // one WAVE per channel index n in [0, max(cin,cout)): r0, r1 (and g3[n]) summed over chunks in double -> coefficients etc.
@@ -720,7 +708,7 @@ __global__ __launch_bounds__(256) void wgrad_small_reduce_kernel(long rows, int 
 }
 // dW[m][n] = cA[n] * (sum_chunks G1 - r0/R * g3[m] - r1/R * sum_chunks Gx)
 // block 256 = 64 consecutive outputs x 4 chunk-slices (coalesced 256-B rows of the partial tiles, 4-way chunk parallelism)
-__global__ __launch_bounds__(256) void wgrad_dw_kernel(long rows, int cin, int cout, int nch, const float* __restrict__ PP, const double* __restrict__ red,
+__global__ __launch_bounds__(256) void wgrad_dw_kernel(long rows, int cin, int cout, int nch /* = partial slots */, const float* __restrict__ PP, const double* __restrict__ red,
                                                        const float* __restrict__ g3, const float* __restrict__ var, const float* __restrict__ gamma, float eps,
                                                        int use_bn, int is_training, float* __restrict__ dW) {
     __shared__ double s1[4][64], sx[4][64];
@@ -779,9 +767,8 @@ extern "C" int gspn_mlp_bwd_wgrad(long rows, int cin, int cout, const gspn_dy_ar
     float* PP = reinterpret_cast<float*>(wb + ws_off_pp(p.nch, cin, cout));
     const bool tr = use_bn && is_training;
     const bool v = vec_ok(X, ldx) && vec_ok(a->Y, a->ldy);
-    const int T = p.MTs * p.NTs;
-    if (T < 4 && T != 3) {      // K-split tiles accumulate with (uncontended) atomics into their chunk's tile: zero it first
-        hipError_t e = hipMemsetAsync(PP, 0, sizeof(float) * (size_t)p.nch * 2 * cin * cout, st);
+    {
+        hipError_t e = hipMemsetAsync(PP, 0, sizeof(float) * (size_t)p.nslots * 2 * cin * cout, st);
         if (e != hipSuccess) return (int)e;
     }
     const float* mu = use_bn ? mean : nullptr;
@@ -790,10 +777,10 @@ extern "C" int gspn_mlp_bwd_wgrad(long rows, int cin, int cout, const gspn_dy_ar
     int launched = 0;
 #define WG_TRY(MT_, NT_, TKW_)                                                                                                          \
     if (!launched && p.MTs == MT_ && p.NTs == NT_ && p.TKW == TKW_) {                                                                  \
-        if (v) { if (tr) hipLaunchKernelGGL((mlp_bwd_wgrad_kernel<MT_, NT_, TKW_, true, true>), grid, dim3(256), 0, st, rows, cin, cout, *a, X, ldx, in_scale, in_shift, mu, vr, eps, RP, GP, PP, p.rpc); \
-                 else    hipLaunchKernelGGL((mlp_bwd_wgrad_kernel<MT_, NT_, TKW_, true, false>), grid, dim3(256), 0, st, rows, cin, cout, *a, X, ldx, in_scale, in_shift, mu, vr, eps, RP, GP, PP, p.rpc); } \
-        else   { if (tr) hipLaunchKernelGGL((mlp_bwd_wgrad_kernel<MT_, NT_, TKW_, false, true>), grid, dim3(256), 0, st, rows, cin, cout, *a, X, ldx, in_scale, in_shift, mu, vr, eps, RP, GP, PP, p.rpc); \
-                 else    hipLaunchKernelGGL((mlp_bwd_wgrad_kernel<MT_, NT_, TKW_, false, false>), grid, dim3(256), 0, st, rows, cin, cout, *a, X, ldx, in_scale, in_shift, mu, vr, eps, RP, GP, PP, p.rpc); } \
+        if (v) { if (tr) hipLaunchKernelGGL((mlp_bwd_wgrad_kernel<MT_, NT_, TKW_, true, true>), grid, dim3(256), 0, st, rows, cin, cout, *a, X, ldx, in_scale, in_shift, mu, vr, eps, RP, GP, PP, p.rpc, (int)p.nslots); \
+                 else    hipLaunchKernelGGL((mlp_bwd_wgrad_kernel<MT_, NT_, TKW_, true, false>), grid, dim3(256), 0, st, rows, cin, cout, *a, X, ldx, in_scale, in_shift, mu, vr, eps, RP, GP, PP, p.rpc, (int)p.nslots); } \
+        else   { if (tr) hipLaunchKernelGGL((mlp_bwd_wgrad_kernel<MT_, NT_, TKW_, false, true>), grid, dim3(256), 0, st, rows, cin, cout, *a, X, ldx, in_scale, in_shift, mu, vr, eps, RP, GP, PP, p.rpc, (int)p.nslots); \
+                 else    hipLaunchKernelGGL((mlp_bwd_wgrad_kernel<MT_, NT_, TKW_, false, false>), grid, dim3(256), 0, st, rows, cin, cout, *a, X, ldx, in_scale, in_shift, mu, vr, eps, RP, GP, PP, p.rpc, (int)p.nslots); } \
         launched = 1;                                                                                                                  \
     }
     WG_TRY(1, 1, 128) WG_TRY(1, 2, 64) WG_TRY(1, 4, 32)
@@ -805,7 +792,7 @@ extern "C" int gspn_mlp_bwd_wgrad(long rows, int cin, int cout, const gspn_dy_ar
     const int cmax = cin > cout ? cin : cout;
     hipLaunchKernelGGL(wgrad_small_reduce_kernel, dim3((cmax + 3) / 4), dim3(256), 0, st, rows, cin, cout, (int)p.nch, RP, GP, red, g3, mean, var, gamma, eps,
                        use_bn, is_training, cA, cB, cC, dgamma, dbeta, dbias);
-    hipLaunchKernelGGL(wgrad_dw_kernel, dim3((unsigned)(((long)cin * cout + 63) / 64)), dim3(256), 0, st, rows, cin, cout, (int)p.nch, PP, red, g3, var, gamma, eps,
+    hipLaunchKernelGGL(wgrad_dw_kernel, dim3((unsigned)(((long)cin * cout + 63) / 64)), dim3(256), 0, st, rows, cin, cout, (int)p.nslots, PP, red, g3, var, gamma, eps,
                        use_bn, is_training, dW);
     return gspn_launch_status();
 }

@@ -30,39 +30,23 @@ def shard_range(total, rank, world):
 
 
 class FlatGradBucket:
-    """Flat fp32 bucket over a fixed parameter list: pack grads -> one all_reduce(SUM) -> /world -> unpack."""
+    """Flat fp32 bucket over a fixed parameter list.  One `cat` gathers the fresh gradients, ONE all_reduce(SUM) averages them
+    over ranks, and every p.grad is then re-pointed at its slice of the bucket (views, no copies back).  Use with
+    optimizer.zero_grad(set_to_none=True) so backward assigns gradients instead of accumulating into the views."""
 
     def __init__(self, params):
         self.params = [p for p in params]
         self.sizes = [p.numel() for p in self.params]
-        n = sum(self.sizes)
-        dev = self.params[0].device if self.params else torch.device("cpu")
-        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
-
-    def pack(self):
-        off = 0
-        for p, s in zip(self.params, self.sizes):
-            if p.grad is None:
-                self.flat[off:off + s].zero_()
-            else:
-                self.flat[off:off + s].copy_(p.grad.reshape(-1))
-            off += s
-        return self.flat
-
-    def unpack(self):
-        off = 0
-        for p, s in zip(self.params, self.sizes):
-            g = self.flat[off:off + s].view_as(p)
-            if p.grad is None:
-                p.grad = g.clone()
-            else:
-                p.grad.copy_(g)
-            off += s
+        self.flat = None
 
     def all_reduce_mean(self):
-        self.pack()
+        grads = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.params]
+        self.flat = torch.cat(grads) if grads else torch.zeros(0)
         if dist.is_initialized() and dist.get_world_size() > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
             self.flat.div_(dist.get_world_size())
-        self.unpack()
+        off = 0
+        for p, s in zip(self.params, self.sizes):
+            p.grad = self.flat[off:off + s].view_as(p)
+            off += s
         return self.flat
