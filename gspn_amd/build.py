@@ -41,7 +41,7 @@ def build(force=False, verbose=False, policy=None):
     os.makedirs(LIBDIR, exist_ok=True)
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     hdrs = sorted(glob.glob(os.path.join(CSRC, "*.h"))) + sorted(glob.glob(os.path.join(HERE, "..", "include", "*.h")))
-    flags = list(FLAGS)
+    flags = list(FLAGS) + os.environ.get("GSPN_EXTRA_HIPCC_FLAGS", "").split()
     if policy is not None:
         flags.append("-DGSPN_DIST_POLICY=%d" % policy)
     hipcc = _hipcc()

@@ -20,6 +20,7 @@
 // MFMA 32x32x2 f32 fragment layout (wave64):  A: lane l holds A[i=l&31][k=l>>5];  B: lane l holds
 // B[k=l>>5][j=l&31];  C/D: 16 registers, reg r -> row (r&3)+8*(r>>2)+4*(l>>5), col l&31.
 #include "common.h"
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -94,27 +95,30 @@ __device__ __forceinline__ float4 act4(float4 v, bool act, const Chan4& c, int k
     return mask4(v, k, kvalid, live);
 }
 
-// raw dz for (row, 4 channels): dense load, or (pooled) the arg-max offsets + pooled gradient; resolved by dz4_resolve
+// raw dz for (row, 4 channels): dense load, or (POOLED) the arg-max offsets + pooled gradient; resolved by dz4_resolve.
+// Dense vs pooled is a template parameter: a runtime switch would leave the pooled path's integer division in every kernel
+// and split the load burst into basic blocks with waits in between.
 struct DzRaw { float4 v; int4 arg; };
-template <bool VEC>
+template <bool VEC, bool POOLED>
 __device__ __forceinline__ DzRaw dz4_raw(const gspn_dy_args& a, long row, int col, int c) {
     DzRaw r;
     r.arg = make_int4(0, 0, 0, 0);
-    if (a.dZ) {                                              // wave-uniform
+    if constexpr (!POOLED) {
         r.v = load4_raw<VEC>(a.dZ, row, a.ldz, col, c);
-        return r;
+    } else {
+        const int g = (int)row / a.ns;                       // rows < 2^31 (checked by the launcher)
+        const int last = c - 1;
+        const int* ar = a.pool_arg + (size_t)g * c;
+        const float* dp = a.dPool + (size_t)g * c;
+        r.arg = make_int4(ar[min(col + 0, last)], ar[min(col + 1, last)], ar[min(col + 2, last)], ar[min(col + 3, last)]);
+        r.v = make_float4(dp[min(col + 0, last)], dp[min(col + 1, last)], dp[min(col + 2, last)], dp[min(col + 3, last)]);
     }
-    const long g = row / a.ns;
-    const int last = c - 1;
-    const int* ar = a.pool_arg + g * c;
-    const float* dp = a.dPool + g * c;
-    r.arg = make_int4(ar[min(col + 0, last)], ar[min(col + 1, last)], ar[min(col + 2, last)], ar[min(col + 3, last)]);
-    r.v = make_float4(dp[min(col + 0, last)], dp[min(col + 1, last)], dp[min(col + 2, last)], dp[min(col + 3, last)]);
     return r;
 }
+template <bool POOLED>
 __device__ __forceinline__ float4 dz4_resolve(const gspn_dy_args& a, const DzRaw& r, long row) {
-    if (a.dZ) return r.v;
-    const int off = (int)(row % a.ns);
+    if constexpr (!POOLED) return r.v;
+    const int off = (int)row % a.ns;
     float4 v;
     v.x = r.arg.x == off ? r.v.x : 0.f;
     v.y = r.arg.y == off ? r.v.y : 0.f;
@@ -438,7 +442,7 @@ extern "C" int gspn_bnrelu_apply(long rows, int c, const float* Y, int ldy, cons
 // no MFMA is spent on padding.  T = MT*NTT tiles are dealt round-robin to the 4 waves; when T < 4 the spare waves
 // split K instead (each takes a slice of the staged rows) so all four SIMDs work.  TKW rows are staged per
 // iteration (more for narrow layers, to keep ~25-50 KB in flight per workgroup).
-template <int MT, int NTT, int TKW, bool VEC, bool WANT_GX>
+template <int MT, int NTT, int TKW, bool VEC, bool WANT_GX, bool POOLED>
 __global__ __launch_bounds__(256) void mlp_bwd_wgrad_kernel(long rows, int cin, int cout, gspn_dy_args a, const float* __restrict__ X, int ldx,
                                                             const float* __restrict__ in_scale, const float* __restrict__ in_shift,
                                                             const float* __restrict__ mean, const float* __restrict__ var, float eps,
@@ -457,6 +461,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_wgrad_kernel(long rows, int cin, 
     constexpr int NBV = (TKW * BQ + 255) / 256;   // B float4 per thread per chunk
     constexpr int ASTEP = 256 / AQ, BSTEP = 256 / BQ;   // row stride between a thread's consecutive quads (256 % AQ == 0 needs AQ | 256)
     static_assert(256 % AQ == 0 || MT == 3, "A quad mapping");
+    static_assert((TKW * AQ) % 256 == 0 && (TKW * BQ) % 256 == 0, "every thread stages whole quads: no bounds check on the staged row");
     __shared__ __attribute__((aligned(16))) float sA[TKW * LDAW];     // [k=row][m=cin]
     __shared__ __attribute__((aligned(16))) float sB[TKW * LDB];      // [k=row][n=cout]  dyh
     __shared__ __attribute__((aligned(16))) float sX[WANT_GX ? TKW * LDB : 4];   // [k=row][n=cout]  xhat
@@ -469,8 +474,6 @@ __global__ __launch_bounds__(256) void mlp_bwd_wgrad_kernel(long rows, int cin, 
     __syncthreads();
     const long r_begin = blockIdx.x * rows_per_chunk;
     const long r_end = r_begin + rows_per_chunk < rows ? r_begin + rows_per_chunk : rows;
-    const bool dzvec = VEC && a.dZ && (a.ldz % 4 == 0) && (((uintptr_t)a.dZ) % 16 == 0);
-
     // quad mapping: item f = t + 256*i -> row f / Q, quad f % Q.  When Q divides 256 the quad is fixed per thread.
     constexpr bool AFIX = (256 % AQ) == 0, BFIX = (256 % BQ) == 0;
     static_assert(BFIX, "BN must be 32, 64 or 128");
@@ -511,7 +514,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_wgrad_kernel(long rows, int cin, 
             const long row = k0 + b_kk0 + BSTEP * i;
             const long rc = row < r_end ? row : r_last;
             ry[i] = load4_raw<VEC>(a.Y, rc, a.ldy, n0 + b_nq, cout);
-            rz[i] = dzvec ? dz4_raw<true>(a, rc, n0 + b_nq, cout) : dz4_raw<false>(a, rc, n0 + b_nq, cout);
+            rz[i] = dz4_raw<VEC, POOLED>(a, rc, n0 + b_nq, cout);
         }
     };
     auto commit = [&](long k0) {
@@ -519,21 +522,19 @@ __global__ __launch_bounds__(256) void mlp_bwd_wgrad_kernel(long rows, int cin, 
         for (int i = 0; i < NA; ++i) {
             const int f = t + 256 * i;
             const int kk = f / AQ, mq = (f - kk * AQ) * 4;
-            if (kk < TKW) {
-                Chan4 cha;
-                cha.sc = lds4(sSc, m0 + mq);
-                cha.sh = lds4(sSh, m0 + mq);
-                *reinterpret_cast<float4*>(sA + kk * LDAW + mq) = act4(ra[i], act, cha, m0 + mq, cin, (k0 + kk) < r_end);
-            }
+            Chan4 cha;
+            cha.sc = lds4(sSc, m0 + mq);
+            cha.sh = lds4(sSh, m0 + mq);
+            *reinterpret_cast<float4*>(sA + kk * LDAW + mq) = act4(ra[i], act, cha, m0 + mq, cin, (k0 + kk) < r_end);
         }
 #pragma unroll
         for (int i = 0; i < NBV; ++i) {
             const int kk = b_kk0 + BSTEP * i;
-            if (kk < TKW) {
+            {
                 const long row = k0 + kk;
                 const bool live = row < r_end;
                 const float4 y = mask4(ry[i], n0 + b_nq, cout, live);
-                const float4 dz = mask4(dz4_resolve(a, rz[i], row < r_end ? row : r_last), n0 + b_nq, cout, live);
+                const float4 dz = mask4(dz4_resolve<POOLED>(a, rz[i], row < r_end ? row : r_last), n0 + b_nq, cout, live);
                 float4 dyh, xh;
                 dyh.x = (y.x * bsc.x + bsh.x) > 0.f ? dz.x : 0.f;
                 dyh.y = (y.y * bsc.y + bsh.y) > 0.f ? dz.y : 0.f;
@@ -628,33 +629,335 @@ __global__ __launch_bounds__(256) void mlp_bwd_wgrad_kernel(long rows, int cin, 
     }
 }
 
+
+// ---- pass A, streaming variant (the one used whenever rows are 16-byte aligned) -------------------------------------
+// The staged operands go HBM -> LDS directly (global_load_lds_dwordx4: no VGPR round trip, no per-element VALU in the
+// staging path) as RAW x / y / dz rows, double buffered: stage s+1 is in flight while stage s is consumed, one barrier per
+// stage.  BN+ReLU of the input, the ReLU mask dyh = dz*[scale*y+shift > 0] and xhat = (y-mean)*rstd are applied when a wave
+// reads its MFMA operands (~10 VALU per pair of 32x32x2 MFMAs, hidden under the 128 matrix-pipe cycles of the pair), where
+// the column sums r0 = sum dyh, r1 = sum dyh*xhat (tiles with tm == 0) and g3 = sum A (tiles with tn == 0) are also taken.
+// LDS image of one stage: [A: TKW x BM][Y: TKW x BN][dZ: TKW x BN (dense only)], linear (a wave-load writes 1 KiB contiguous).
+// A max-pooled upstream gradient (POOLED) is never expanded: per stage a lane fetches the arg-max offset and the pooled
+// gradient of its column for the <= NGMAX pool groups the stage covers, and dz = (arg == row % ns) ? dPool : 0.
+__device__ __forceinline__ void glds16(const float* g, float* l) {        // 64 lanes x 16 B -> 1 KiB of LDS at l (wave-uniform)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+template <int MT, int NTT, int TKW, bool WANT_GX, bool POOLED>
+__global__ __launch_bounds__(256) void wgrad_stream_kernel(int rows, int cin, int cout, gspn_dy_args a, const float* __restrict__ X, int ldx,
+                                                           const float* __restrict__ in_scale, const float* __restrict__ in_shift,
+                                                           const float* __restrict__ mean, const float* __restrict__ var, float eps,
+                                                           float* __restrict__ RP, float* __restrict__ GP, float* __restrict__ PP,
+                                                           int rows_per_chunk, int nslots, int shared, int nch, int nrow, int ncol) {
+    constexpr int BM = 32 * MT, BN = 32 * NTT, T = MT * NTT;
+    constexpr int WK = (T % 4 == 0) ? 1 : ((T % 2 == 0) ? 2 : 4);     // K split so that every wave owns T*WK/4 (tile, k-part) slots
+    constexpr int TPW = T * WK / 4;
+    constexpr int KPER = TKW / WK;
+    static_assert(KPER % 2 == 0 && KPER >= 2, "k-part must hold whole MFMA k-pairs");
+    constexpr int AQ = BM / 4, BQ = BN / 4;
+    constexpr int PA = TKW * AQ / 64, PB = TKW * BQ / 64;             // 1-KiB pieces per array
+    static_assert((TKW * AQ) % 64 == 0 && (TKW * BQ) % 64 == 0, "whole pieces");
+    constexpr int SF = TKW * (BM + BN + (POOLED ? 0 : BN));           // floats per stage
+    constexpr int NGMAX = POOLED ? (TKW >= 16 ? TKW / 16 : 1) : 1;    // pool groups per stage (ns >= 16)
+    constexpr int JA = (PA + 3) / 4, JB = (PB + 3) / 4;
+    __shared__ __attribute__((aligned(16))) float sbuf[2 * SF];
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+
+    // block -> (chunk, tile): the tiles of one chunk are adjacent in launch order AND on the same XCD (id % 8), so the rows they
+    // share are fetched from HBM once per XCD L2
+    const int ntile = nrow * ncol;
+    const int bid = blockIdx.x;
+    const int rest = bid >> 3;
+    const int tile_id = rest % ntile;
+    const int chunk = (rest / ntile) * 8 + (bid & 7);
+    if (chunk >= nch) return;
+    const int ty = tile_id % nrow, tz = tile_id / nrow;
+    const int m0 = ty * BM, n0 = tz * BN;
+    const int r_begin = chunk * rows_per_chunk;
+    const int r_end = min(r_begin + rows_per_chunk, rows);
+    const int nloc = r_end - r_begin;                                  // rows of this chunk (> 0)
+    const int nit = (nloc + TKW - 1) / TKW;
+    const int lrmax = nloc - 1;
+
+    // ---- per-lane piece descriptors (loop invariant): row-in-stage and clamped column of the lane's quad ----
+    int a_kk[JA], a_col[JA], b_kk[JB], b_col[JB];
+#pragma unroll
+    for (int j = 0; j < JA; ++j) {
+        const int f = (wave + 4 * j) * 64 + lane;
+        a_kk[j] = f / AQ;
+        a_col[j] = min(m0 + (f - a_kk[j] * AQ) * 4, ldx - 4);
+    }
+#pragma unroll
+    for (int j = 0; j < JB; ++j) {
+        const int f = (wave + 4 * j) * 64 + lane;
+        b_kk[j] = f / BQ;
+        b_col[j] = min(n0 + (f - b_kk[j] * BQ) * 4, cout - 4);
+    }
+    const float* Xc = X + (size_t)r_begin * ldx;
+    const float* Yc = a.Y + (size_t)r_begin * a.ldy;
+    const float* Zc = POOLED ? nullptr : a.dZ + (size_t)r_begin * a.ldz;
+    auto issue = [&](int s) {
+        float* dst = sbuf + (s & 1) * SF;
+        const int k0 = s * TKW;
+#pragma unroll
+        for (int j = 0; j < JA; ++j) {
+            if (PA % 4 == 0 || wave + 4 * j < PA)
+                glds16(Xc + (size_t)(min(k0 + a_kk[j], lrmax) * ldx + a_col[j]), dst + (wave + 4 * j) * 256);
+        }
+#pragma unroll
+        for (int j = 0; j < JB; ++j) {
+            if (PB % 4 == 0 || wave + 4 * j < PB) {
+                const int lr = min(k0 + b_kk[j], lrmax);
+                glds16(Yc + (size_t)(lr * a.ldy + b_col[j]), dst + TKW * BM + (wave + 4 * j) * 256);
+                if constexpr (!POOLED) glds16(Zc + (size_t)(lr * a.ldz + b_col[j]), dst + TKW * (BM + BN) + (wave + 4 * j) * 256);
+            }
+        }
+    };
+
+    // ---- per-slot constants ----
+    int s_tm[TPW], s_tn[TPW], s_kp[TPW];
+    float isc[TPW], ish[TPW], bsc[TPW], bsh[TPW], bmu[TPW], brs[TPW];
+    const float lo = in_scale ? 0.f : -__builtin_inff();               // relu floor (none for a raw first-layer input)
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int slot = wave + 4 * i;
+        const int tile = slot % T;
+        s_kp[i] = slot / T;
+        s_tm[i] = tile % MT;
+        s_tn[i] = tile / MT;
+        const int m = min(m0 + s_tm[i] * 32 + l31, cin - 1);
+        const int n = min(n0 + s_tn[i] * 32 + l31, cout - 1);
+        isc[i] = in_scale ? in_scale[m] : 1.f;
+        ish[i] = in_scale ? in_shift[m] : 0.f;
+        bsc[i] = a.scale[n];
+        bsh[i] = a.shift[n];
+        bmu[i] = mean ? mean[n] : 0.f;
+        brs[i] = var ? (float)(1.0 / sqrt((double)var[n] + (double)eps)) : 1.f;
+    }
+    // ---- pooled gradient: per (slot, group-in-stage) arg-max offset and pooled gradient of the lane's column ----
+    const int ns = POOLED ? a.ns : TKW;
+    const int gs = min(ns, TKW);                      // rows of one pool group inside a stage
+    const int ng = TKW / gs;                          // groups per stage (<= NGMAX)
+    const int ngroups = POOLED ? rows / ns : 0;
+    int g_next = POOLED ? r_begin / ns : 0;           // first group / row offset within it of the NEXT stage to prefetch
+    int off_next = POOLED ? r_begin - g_next * ns : 0;
+    int p_arg[TPW][NGMAX], n_arg[TPW][NGMAX];
+    float p_dp[TPW][NGMAX], n_dp[TPW][NGMAX];
+    bool n_ok[TPW][NGMAX];
+    int off_cur = 0, off_nxt = 0;
+    auto pool_fetch = [&]() {                          // loads for the stage (g_next, off_next) into n_*; advances the cursor
+        if constexpr (POOLED) {
+            off_nxt = off_next;
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) {
+                const int n = min(n0 + s_tn[i] * 32 + l31, cout - 1);
+#pragma unroll
+                for (int gl = 0; gl < NGMAX; ++gl) {
+                    const int g = g_next + gl;
+                    const size_t at = (size_t)min(g, ngroups - 1) * cout + n;
+                    n_arg[i][gl] = a.pool_arg[at];
+                    n_dp[i][gl] = a.dPool[at];
+                    n_ok[i][gl] = g < ngroups && gl < ng;                   // rows past the end / unused slots never match
+                    // (the select is applied when the values are consumed, one stage later: selecting here would make hipcc wait
+                    //  for these loads -- and with them for the stage's LDS-DMA pieces -- right after issuing them)
+                }
+            }
+            off_next += TKW;
+            if (off_next >= ns) { off_next = 0; g_next += ng; }
+        }
+    };
+
+    f32x16 acc1[TPW], accx[WANT_GX ? TPW : 1];
+    float r0a[TPW], r1a[TPW], g3a[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        r0a[i] = r1a[i] = g3a[i] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc1[i][r] = 0.f; if (WANT_GX) accx[i][r] = 0.f; }
+    }
+
+    pool_fetch();
+    issue(0);
+    for (int s = 0; s < nit; ++s) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of stage s have landed ...
+        __syncthreads();                                        // ... and so have everyone else's; stage s-1 is fully consumed
+        const float* buf = sbuf + (s & 1) * SF;
+        if constexpr (POOLED) {
+#pragma unroll
+            for (int i = 0; i < TPW; ++i)
+#pragma unroll
+                for (int gl = 0; gl < NGMAX; ++gl) { p_arg[i][gl] = n_ok[i][gl] ? n_arg[i][gl] : -1; p_dp[i][gl] = n_dp[i][gl]; }
+            off_cur = off_nxt;
+        }
+        if (s + 1 < nit) { pool_fetch(); issue(s + 1); }
+        const float* sA = buf;
+        const float* sY = buf + TKW * BM;
+        const float* sZ = buf + TKW * (BM + BN);
+        const int live = nloc - s * TKW;                        // < TKW only in a ragged last stage (clamped duplicate rows follow)
+        auto compute = [&](auto tail_c) {
+            constexpr bool TAIL = decltype(tail_c)::value;
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) {
+                const int ao = s_tm[i] * 32 + l31, bo = s_tn[i] * 32 + l31;
+                auto pair = [&](int r, float dz) {              // r = this lane's row within the stage
+                    // (no inline asm here: hipcc's hazard recogniser does not see an asm VALU write feeding an MFMA operand)
+                    float av = __builtin_fmaxf(sA[r * BM + ao] * isc[i] + ish[i], lo);
+                    const float y = sY[r * BN + bo];
+                    if (TAIL) { av = r < live ? av : 0.f; dz = r < live ? dz : 0.f; }
+                    const float dyh = (y * bsc[i] + bsh[i]) > 0.f ? dz : 0.f;
+                    const float xh = (y - bmu[i]) * brs[i];
+                    acc1[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, dyh, acc1[i], 0, 0, 0);
+                    if (WANT_GX) accx[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xh, accx[i], 0, 0, 0);
+                    r0a[i] += dyh;
+                    r1a[i] += dyh * xh;
+                    g3a[i] += av;
+                };
+                const int k_lo = s_kp[i] * KPER;
+                if constexpr (!POOLED) {
+#pragma unroll 4
+                    for (int kk = 0; kk < KPER; kk += 2) {
+                        const int r = k_lo + kk + half;
+                        pair(r, sZ[r * BN + bo]);
+                    }
+                } else if constexpr (NGMAX == 1) {
+#pragma unroll 4
+                    for (int kk = 0; kk < KPER; kk += 2) {
+                        const int r = k_lo + kk + half;
+                        pair(r, p_arg[i][0] == off_cur + r ? p_dp[i][0] : 0.f);
+                    }
+                } else {
+#pragma unroll
+                    for (int gl = 0; gl < NGMAX; ++gl) {
+                        if (gl < ng) {
+                            const int lo_k = max(k_lo, gl * gs), hi_k = min(k_lo + KPER, (gl + 1) * gs);
+                            for (int kk = lo_k; kk < hi_k; kk += 2) {
+                                const int r = kk + half;
+                                pair(r, p_arg[i][gl] == off_cur + r - gl * gs ? p_dp[i][gl] : 0.f);
+                            }
+                        }
+                    }
+                }
+            }
+        };
+        if (live >= TKW) compute(std::false_type{});
+        else compute(std::true_type{});
+    }
+    // ---- epilogue: this chunk's partial tiles / sums ----
+    // shared == 0: every (chunk, k-part) owns a partial-tile slot -> plain stores; else chunks share zero-filled slots (fp32 atomics)
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int slot = shared ? chunk % nslots : chunk * WK + s_kp[i];
+        float* P1 = PP + (size_t)slot * 2 * cin * cout;
+        float* Px = P1 + (size_t)cin * cout;
+        const int col = n0 + s_tn[i] * 32 + l31;
+        if (col < cout) {
+            if (shared) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + s_tm[i] * 32 + c_row(r, lane);
+                    if (m < cin) {
+                        atomicAdd(P1 + (size_t)m * cout + col, acc1[i][r]);
+                        if (WANT_GX) atomicAdd(Px + (size_t)m * cout + col, accx[i][r]);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + s_tm[i] * 32 + c_row(r, lane);
+                    if (m < cin) {
+                        P1[(size_t)m * cout + col] = acc1[i][r];
+                        if (WANT_GX) Px[(size_t)m * cout + col] = accx[i][r];
+                    }
+                }
+            }
+        }
+    }
+    // column sums: one LDS cell per (k-part, lane half, column), summed in a fixed order
+    __syncthreads();
+    float* sR = sbuf;                                   // [WK*2][2][BN]
+    float* sG = sbuf + WK * 2 * 2 * BN;                 // [WK*2][BM]
+    static_assert(WK * 2 * (2 * BN + BM) <= 2 * SF, "reduction scratch fits the stage buffers");
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int part = s_kp[i] * 2 + half;
+        if (s_tm[i] == 0) {
+            sR[(part * 2 + 0) * BN + s_tn[i] * 32 + l31] = r0a[i];
+            sR[(part * 2 + 1) * BN + s_tn[i] * 32 + l31] = r1a[i];
+        }
+        if (s_tn[i] == 0) sG[part * BM + s_tm[i] * 32 + l31] = g3a[i];
+    }
+    __syncthreads();
+    if (ty == 0) {
+        for (int j = t; j < BN; j += 256) {
+            const int n = n0 + j;
+            if (n < cout) {
+                float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+                for (int p = 0; p < WK * 2; ++p) { v0 += sR[(p * 2 + 0) * BN + j]; v1 += sR[(p * 2 + 1) * BN + j]; }
+                RP[(size_t)chunk * 2 * cout + n] = v0;
+                RP[(size_t)chunk * 2 * cout + cout + n] = v1;
+            }
+        }
+    }
+    if (tz == 0) {
+        for (int j = t; j < BM; j += 256) {
+            const int m = m0 + j;
+            if (m < cin) {
+                float v = 0.f;
+#pragma unroll
+                for (int p = 0; p < WK * 2; ++p) v += sG[p * BM + j];
+                GP[(size_t)chunk * cin + m] = v;
+            }
+        }
+    }
+}
+
 // ---- second stage: sum the per-chunk partials (double), then coefficients / parameter gradients / dW ----
-struct WgradPlan { int MTs, NTs, nrow, ncol, TKW; long rpc, nch, nslots; };
-static WgradPlan wgrad_plan(long rows, int cin, int cout) {
+// Plan: tile shape per workgroup, rows per chunk, number of partial-tile slots.
+//   * chunks: ~3 workgroups per CU when the layer is long enough, but a chunk always reads at least ~2x the bytes of the partial
+//     tile it writes (rpc_min), as long as that still leaves one workgroup per CU;
+//   * slots: when nch * WK partial tiles fit in 64 MB every (chunk, k-part) owns a slot and the main kernel uses plain stores
+//     (shared == 0: no zero fill, no atomics); otherwise chunks share `nslots` zero-filled slots through fp32 atomics.
+struct WgradPlan { int MTs, NTs, nrow, ncol, TKW, WK, shared; long rpc, nch, nslots; };
+static WgradPlan wgrad_plan(long rows, int cin, int cout, bool generic = false) {
     WgradPlan p;
     const int mt = (cin + 31) / 32, nt = (cout + 31) / 32;
     p.nrow = (mt + 3) / 4; p.ncol = (nt + 3) / 4;
     p.MTs = (mt + p.nrow - 1) / p.nrow;
     p.NTs = (nt + p.ncol - 1) / p.ncol;
     if (p.NTs == 3) p.NTs = 4;                              // BN in {32, 64, 128}
-    // rows staged per iteration: more for narrow layers (keeps ~25-50 KB in flight per workgroup, <= 56 KB of LDS)
-    static const int tkw[4][3] = {{128, 64, 32}, {64, 64, 32}, {64, 32, 32}, {64, 32, 32}};     // [MT-1][NT: 1,2,4]
+    // rows staged per iteration (streaming kernel): one stage is 14-24 KB of LDS, two stages per workgroup, 3 workgroups per CU
+    static const int tkw[4][3] = {{64, 32, 16}, {32, 32, 16}, {32, 16, 16}, {32, 16, 16}};      // [MT-1][NT: 1,2,4]
     p.TKW = tkw[p.MTs - 1][p.NTs == 1 ? 0 : (p.NTs == 2 ? 1 : 2)];
-    long chunks = (256L * 3) / (p.ncol * p.nrow);
+    if (generic) { p.nrow = (cin + 127) / 128; p.ncol = (cout + 127) / 128; p.MTs = 4; p.NTs = 4; p.TKW = 32; }
+    const int T = p.MTs * p.NTs;
+    p.WK = generic ? 1 : ((T % 4 == 0) ? 1 : ((T % 2 == 0) ? 2 : 4));
+    const long ntile = (long)p.ncol * p.nrow;
+    const long BM = 32L * p.MTs, BN = 32L * p.NTs;
+    long rpc_min = 4 * BM * BN / (BM + 2 * BN);            // input bytes of a chunk >= 2 x its partial-tile bytes
+    if (rpc_min < 4L * p.TKW) rpc_min = 4L * p.TKW;
+    long chunks = (256L * 3) / ntile;                       // upper target: 3 workgroups per CU
     if (chunks < 1) chunks = 1;
+    const long by_size = rows / rpc_min;                    // chunks allowed by the size rule
+    long floor_ch = 256 / ntile;                            // but never fewer than one workgroup per CU (if the layer has the rows)
+    if (floor_ch < 1) floor_ch = 1;
+    if (chunks > by_size) chunks = by_size > floor_ch ? by_size : floor_ch;
     long rpc = (rows + chunks - 1) / chunks;
     if (rpc < 4L * p.TKW) rpc = 4L * p.TKW;
     p.rpc = (rpc + p.TKW - 1) / p.TKW * p.TKW;
     p.nch = (rows + p.rpc - 1) / p.rpc;
     if (p.nch < 1) p.nch = 1;
-    // partial-tile slots: chunk c accumulates into slot c % nslots (fp32 atomics, contention <= nch/nslots); the slot count keeps
-    // the workspace around <= 12 MB while the chunk count stays high enough to fill the chip
-    long cap = (12L << 20) / (8L * cin * cout);
-    if (cap < 8) cap = 8;
-    p.nslots = p.nch < cap ? p.nch : cap;
+    const long tile_bytes = 8L * cin * cout;
+    if (!generic && p.nch * p.WK * tile_bytes <= (64L << 20)) { p.shared = 0; p.nslots = p.nch * p.WK; }
+    else {
+        long cap = (12L << 20) / tile_bytes;
+        if (cap < 8) cap = 8;
+        p.shared = 1;
+        p.nslots = p.nch < cap ? p.nch : cap;
+    }
     return p;
 }
-// workspace: [red: 2*cout doubles][g3: cin floats, padded to 4][RP: nch*2*cout][GP: nch*cin][PP: nch*2*cin*cout]
+// workspace: [red: 2*cout doubles][g3: cin floats, padded to 4][RP: nch*2*cout][GP: nch*cin][PP: nslots*2*cin*cout]
 static size_t ws_off_g3(int cout) { return sizeof(double) * 2 * (size_t)cout; }
 static size_t ws_off_rp(int cin, int cout) { return ws_off_g3(cout) + sizeof(float) * (size_t)((cin + 3) / 4 * 4); }
 static size_t ws_off_gp(long nch, int cin, int cout) { return ws_off_rp(cin, cout) + sizeof(float) * (size_t)nch * 2 * cout; }
@@ -662,26 +965,32 @@ static size_t ws_off_pp(long nch, int cin, int cout) { return (ws_off_gp(nch, ci
 static size_t ws_total(long nch, long nslots, int cin, int cout) { return ws_off_pp(nch, cin, cout) + sizeof(float) * (size_t)nslots * 2 * cin * cout; }
 extern "C" long gspn_mlp_bwd_work_bytes(long rows, int cin, int cout) {
     if (rows <= 0 || cin <= 0 || cout <= 0) return GSPN_ERR_ARG;
-    const WgradPlan p = wgrad_plan(rows, cin, cout);
-    return (long)ws_total(p.nch, p.nslots, cin, cout);
+    const WgradPlan p = wgrad_plan(rows, cin, cout), q = wgrad_plan(rows, cin, cout, true);
+    const size_t a = ws_total(p.nch, p.nslots, cin, cout), b = ws_total(q.nch, q.nslots, cin, cout);
+    return (long)(a > b ? a : b);
 }
 
-// one WAVE per channel index n in [0, max(cin,cout)): r0, r1 (and g3[n]) summed over chunks in double -> coefficients etc.
+// one WORKGROUP per channel index n in [0, max(cin,cout)): r0, r1 (and g3[n]) summed over chunks in double -> coefficients etc.
 __global__ __launch_bounds__(256) void wgrad_small_reduce_kernel(long rows, int cin, int cout, int nch, const float* __restrict__ RP, const float* __restrict__ GP,
                                                                  double* __restrict__ red, float* __restrict__ g3, const float* __restrict__ mean,
                                                                  const float* __restrict__ var, const float* __restrict__ gamma, float eps, int use_bn, int is_training,
                                                                  float* __restrict__ cA, float* __restrict__ cB, float* __restrict__ cC,
                                                                  float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dbias) {
-    const int lane = threadIdx.x & 63;
-    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (n >= cin && n >= cout) return;
+    __shared__ double sh[3][4];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int n = blockIdx.x;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-    for (int p = lane; p < nch; p += 64) {
+    for (int p = t; p < nch; p += 256) {
         if (n < cout) { a0 += (double)RP[(size_t)p * 2 * cout + n]; a1 += (double)RP[(size_t)p * 2 * cout + cout + n]; }
         if (n < cin) a2 += (double)GP[(size_t)p * cin + n];
     }
-    const double r0 = wave_sum_f64(a0), r1 = wave_sum_f64(a1), gg = wave_sum_f64(a2);
-    if (lane != 0) return;
+    a0 = wave_sum_f64(a0); a1 = wave_sum_f64(a1); a2 = wave_sum_f64(a2);
+    if (lane == 0) { sh[0][wave] = a0; sh[1][wave] = a1; sh[2][wave] = a2; }
+    __syncthreads();
+    if (t != 0) return;
+    const double r0 = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
+    const double r1 = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
+    const double gg = (sh[2][0] + sh[2][1]) + (sh[2][2] + sh[2][3]);
     if (n < cin) g3[n] = (float)gg;
     if (n >= cout) return;
     red[n] = r0;
@@ -706,41 +1015,51 @@ __global__ __launch_bounds__(256) void wgrad_small_reduce_kernel(long rows, int 
     if (cC) cC[n] = (float)C;
     if (dbias) dbias[n] = (float)(tr ? 0.0 : A * r0);      // sum(dY): exactly 0 under batch statistics
 }
-// dW[m][n] = cA[n] * (sum_chunks G1 - r0/R * g3[m] - r1/R * sum_chunks Gx)
-// block 256 = 64 consecutive outputs x 4 chunk-slices (coalesced 256-B rows of the partial tiles, 4-way chunk parallelism)
-__global__ __launch_bounds__(256) void wgrad_dw_kernel(long rows, int cin, int cout, int nch /* = partial slots */, const float* __restrict__ PP, const double* __restrict__ red,
-                                                       const float* __restrict__ g3, const float* __restrict__ var, const float* __restrict__ gamma, float eps,
-                                                       int use_bn, int is_training, float* __restrict__ dW) {
-    __shared__ double s1[4][64], sx[4][64];
+// dW[m][n] = cA[n] * (sum_slots G1 - r0/R * g3[m] - r1/R * sum_slots Gx)
+// block 1024 = 16 consecutive outputs x 64 interleaved slot slices: cin*cout/16 workgroups of 16 waves keep the whole chip streaming the
+// partial tiles (64-byte segments, 8 loads in flight per thread); double accumulation, fixed summation order.
+#define DW_OX 16
+#define DW_SL 64
+__global__ __launch_bounds__(1024) void wgrad_dw_kernel(long rows, int cin, int cout, int nslots, const float* __restrict__ PP, const double* __restrict__ red,
+                                                        const float* __restrict__ g3, const float* __restrict__ var, const float* __restrict__ gamma, float eps,
+                                                        int use_bn, int is_training, float* __restrict__ dW) {
+    __shared__ double s1[DW_SL][DW_OX + 1], sx[DW_SL][DW_OX + 1];
     const long total = (long)cin * cout;
     const double R = (double)rows;
     const bool tr = use_bn && is_training;
-    const int ox = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const long i = blockIdx.x * 64L + ox;
+    const int ox = threadIdx.x % DW_OX, sl = threadIdx.x / DW_OX;
+    const long i = blockIdx.x * (long)DW_OX + ox;
     double w1 = 0.0, wx = 0.0;
     if (i < total) {
         const float* p1 = PP + i;
+        const size_t st = 2 * (size_t)total;
         int p = sl;
-        for (; p + 12 < nch; p += 16) {             // 4 independent loads in flight per accumulator
-            const float v0 = p1[(size_t)p * 2 * total], v1 = p1[(size_t)(p + 4) * 2 * total], v2 = p1[(size_t)(p + 8) * 2 * total], v3 = p1[(size_t)(p + 12) * 2 * total];
-            w1 += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+        for (; p + 3 * DW_SL < nslots; p += 4 * DW_SL) {
+            const float v0 = p1[(size_t)p * st], v1 = p1[(size_t)(p + DW_SL) * st], v2 = p1[(size_t)(p + 2 * DW_SL) * st], v3 = p1[(size_t)(p + 3 * DW_SL) * st];
+            float u0 = 0.f, u1 = 0.f, u2 = 0.f, u3 = 0.f;
             if (tr) {
-                const float u0 = p1[(size_t)p * 2 * total + total], u1 = p1[(size_t)(p + 4) * 2 * total + total];
-                const float u2 = p1[(size_t)(p + 8) * 2 * total + total], u3 = p1[(size_t)(p + 12) * 2 * total + total];
-                wx += ((double)u0 + (double)u1) + ((double)u2 + (double)u3);
+                u0 = p1[(size_t)p * st + total]; u1 = p1[(size_t)(p + DW_SL) * st + total];
+                u2 = p1[(size_t)(p + 2 * DW_SL) * st + total]; u3 = p1[(size_t)(p + 3 * DW_SL) * st + total];
             }
+            w1 += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+            wx += ((double)u0 + (double)u1) + ((double)u2 + (double)u3);
         }
-        for (; p < nch; p += 4) {
-            w1 += (double)p1[(size_t)p * 2 * total];
-            if (tr) wx += (double)p1[(size_t)p * 2 * total + total];
+        for (; p < nslots; p += DW_SL) {
+            w1 += (double)p1[(size_t)p * st];
+            if (tr) wx += (double)p1[(size_t)p * st + total];
         }
     }
     s1[sl][ox] = w1;
     sx[sl][ox] = wx;
     __syncthreads();
+    // 64 slices -> 1: four rounds of pairwise adds (fixed tree)
+    for (int h = DW_SL / 2; h >= 1; h >>= 1) {
+        if (sl < h) { s1[sl][ox] += s1[sl + h][ox]; sx[sl][ox] += sx[sl + h][ox]; }
+        __syncthreads();
+    }
     if (sl != 0 || i >= total) return;
-    w1 = (s1[0][ox] + s1[1][ox]) + (s1[2][ox] + s1[3][ox]);
-    wx = (sx[0][ox] + sx[1][ox]) + (sx[2][ox] + sx[3][ox]);
+    w1 = s1[0][ox];
+    wx = sx[0][ox];
     const int n = (int)(i % cout), m = (int)(i / cout);
     double A = 1.0;
     if (use_bn) A = (gamma ? (double)gamma[n] : 1.0) / sqrt((double)var[n] + (double)eps);
@@ -758,42 +1077,65 @@ extern "C" int gspn_mlp_bwd_wgrad(long rows, int cin, int cout, const gspn_dy_ar
     if (use_bn && (!mean || !var)) return GSPN_ERR_ARG;
     if (cin > MAXCH || cout > MAXCH) return GSPN_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    const WgradPlan p = wgrad_plan(rows, cin, cout);
+    if (rows >= (1L << 31)) return GSPN_ERR_UNSUPPORTED;
+    const bool pooled = a->dZ == nullptr;
+    const bool tr = use_bn && is_training;
+    // streaming kernel: 16-byte aligned rows, 32-bit in-chunk offsets, pool groups that tile the stage
+    bool use_stream = vec_ok(X, ldx) && vec_ok(a->Y, a->ldy) && (pooled || vec_ok(a->dZ, a->ldz)) && ldx >= 4 && cout >= 4;
+    WgradPlan p = wgrad_plan(rows, cin, cout, false);
+    if (use_stream) {
+        const long ldmax = ldx > a->ldy ? (ldx > a->ldz ? ldx : a->ldz) : (a->ldy > a->ldz ? a->ldy : a->ldz);
+        if (p.rpc * ldmax >= (1L << 31)) use_stream = false;
+        if (pooled && !(a->ns >= 16 && a->ns % 2 == 0 && (a->ns % p.TKW == 0 || p.TKW % a->ns == 0) && rows % a->ns == 0)) use_stream = false;
+    }
+    if (!use_stream) p = wgrad_plan(rows, cin, cout, true);
     char* wb = reinterpret_cast<char*>(work);
+    if (reinterpret_cast<uintptr_t>(wb) % 16) return GSPN_ERR_ARG;
     double* red = reinterpret_cast<double*>(wb);
     float* g3 = reinterpret_cast<float*>(wb + ws_off_g3(cout));
     float* RP = reinterpret_cast<float*>(wb + ws_off_rp(cin, cout));
     float* GP = reinterpret_cast<float*>(wb + ws_off_gp(p.nch, cin, cout));
     float* PP = reinterpret_cast<float*>(wb + ws_off_pp(p.nch, cin, cout));
-    const bool tr = use_bn && is_training;
-    const bool v = vec_ok(X, ldx) && vec_ok(a->Y, a->ldy);
-    {
+    if (p.shared) {
         hipError_t e = hipMemsetAsync(PP, 0, sizeof(float) * (size_t)p.nslots * 2 * cin * cout, st);
         if (e != hipSuccess) return (int)e;
     }
     const float* mu = use_bn ? mean : nullptr;
     const float* vr = use_bn ? var : nullptr;
-    const dim3 grid((unsigned)p.nch, p.nrow, p.ncol);
-    int launched = 0;
-#define WG_TRY(MT_, NT_, TKW_)                                                                                                          \
-    if (!launched && p.MTs == MT_ && p.NTs == NT_ && p.TKW == TKW_) {                                                                  \
-        if (v) { if (tr) hipLaunchKernelGGL((mlp_bwd_wgrad_kernel<MT_, NT_, TKW_, true, true>), grid, dim3(256), 0, st, rows, cin, cout, *a, X, ldx, in_scale, in_shift, mu, vr, eps, RP, GP, PP, p.rpc, (int)p.nslots); \
-                 else    hipLaunchKernelGGL((mlp_bwd_wgrad_kernel<MT_, NT_, TKW_, true, false>), grid, dim3(256), 0, st, rows, cin, cout, *a, X, ldx, in_scale, in_shift, mu, vr, eps, RP, GP, PP, p.rpc, (int)p.nslots); } \
-        else   { if (tr) hipLaunchKernelGGL((mlp_bwd_wgrad_kernel<MT_, NT_, TKW_, false, true>), grid, dim3(256), 0, st, rows, cin, cout, *a, X, ldx, in_scale, in_shift, mu, vr, eps, RP, GP, PP, p.rpc, (int)p.nslots); \
-                 else    hipLaunchKernelGGL((mlp_bwd_wgrad_kernel<MT_, NT_, TKW_, false, false>), grid, dim3(256), 0, st, rows, cin, cout, *a, X, ldx, in_scale, in_shift, mu, vr, eps, RP, GP, PP, p.rpc, (int)p.nslots); } \
-        launched = 1;                                                                                                                  \
+    if (use_stream) {
+        int launched = 0;
+        const dim3 grid((unsigned)((p.nch + 7) / 8 * 8 * p.nrow * p.ncol));
+#define WS_ARGS (int)rows, cin, cout, *a, X, ldx, in_scale, in_shift, mu, vr, eps, RP, GP, PP, (int)p.rpc, (int)p.nslots, p.shared, (int)p.nch, p.nrow, p.ncol
+#define WS_GO(MT_, NT_, TKW_, G_, P_) hipLaunchKernelGGL((wgrad_stream_kernel<MT_, NT_, TKW_, G_, P_>), grid, dim3(256), 0, st, WS_ARGS)
+#define WS_TRY(MT_, NT_, TKW_)                                                                   \
+        if (!launched && p.MTs == MT_ && p.NTs == NT_ && p.TKW == TKW_) {                       \
+            if (tr) { if (pooled) WS_GO(MT_, NT_, TKW_, true, true); else WS_GO(MT_, NT_, TKW_, true, false); }     \
+            else    { if (pooled) WS_GO(MT_, NT_, TKW_, false, true); else WS_GO(MT_, NT_, TKW_, false, false); }   \
+            launched = 1;                                                                       \
+        }
+        WS_TRY(1, 1, 64) WS_TRY(1, 2, 32) WS_TRY(1, 4, 16)
+        WS_TRY(2, 1, 32) WS_TRY(2, 2, 32) WS_TRY(2, 4, 16)
+        WS_TRY(3, 1, 32) WS_TRY(3, 2, 16) WS_TRY(3, 4, 16)
+        WS_TRY(4, 1, 32) WS_TRY(4, 2, 16) WS_TRY(4, 4, 16)
+#undef WS_TRY
+#undef WS_GO
+#undef WS_ARGS
+        if (!launched) return GSPN_ERR_UNSUPPORTED;
+    } else {
+        // any alignment / pool size: register-staged kernel with scalar loads, 128x128 tiles
+        const dim3 grid((unsigned)p.nch, p.nrow, p.ncol);
+#define WG_ARGS rows, cin, cout, *a, X, ldx, in_scale, in_shift, mu, vr, eps, RP, GP, PP, p.rpc, (int)p.nslots
+#define WG_GO(G_, P_) hipLaunchKernelGGL((mlp_bwd_wgrad_kernel<4, 4, 32, false, G_, P_>), grid, dim3(256), 0, st, WG_ARGS)
+        if (tr) { if (pooled) WG_GO(true, true); else WG_GO(true, false); }
+        else    { if (pooled) WG_GO(false, true); else WG_GO(false, false); }
+#undef WG_GO
+#undef WG_ARGS
     }
-    WG_TRY(1, 1, 128) WG_TRY(1, 2, 64) WG_TRY(1, 4, 32)
-    WG_TRY(2, 1, 64)  WG_TRY(2, 2, 64) WG_TRY(2, 4, 32)
-    WG_TRY(3, 1, 64)  WG_TRY(3, 2, 32) WG_TRY(3, 4, 32)
-    WG_TRY(4, 1, 64)  WG_TRY(4, 2, 32) WG_TRY(4, 4, 32)
-#undef WG_TRY
-    if (!launched) return GSPN_ERR_UNSUPPORTED;
     const int cmax = cin > cout ? cin : cout;
-    hipLaunchKernelGGL(wgrad_small_reduce_kernel, dim3((cmax + 3) / 4), dim3(256), 0, st, rows, cin, cout, (int)p.nch, RP, GP, red, g3, mean, var, gamma, eps,
+    hipLaunchKernelGGL(wgrad_small_reduce_kernel, dim3(cmax), dim3(256), 0, st, rows, cin, cout, (int)p.nch, RP, GP, red, g3, mean, var, gamma, eps,
                        use_bn, is_training, cA, cB, cC, dgamma, dbeta, dbias);
-    hipLaunchKernelGGL(wgrad_dw_kernel, dim3((unsigned)(((long)cin * cout + 63) / 64)), dim3(256), 0, st, rows, cin, cout, (int)p.nslots, PP, red, g3, var, gamma, eps,
-                       use_bn, is_training, dW);
+    hipLaunchKernelGGL(wgrad_dw_kernel, dim3((unsigned)(((long)cin * cout + DW_OX - 1) / DW_OX)), dim3(1024), 0, st, rows, cin, cout, (int)p.nslots, PP, red, g3,
+                       var, gamma, eps, use_bn, is_training, dW);
     return gspn_launch_status();
 }
 
@@ -801,7 +1143,7 @@ extern "C" int gspn_mlp_bwd_wgrad(long rows, int cin, int cout, const gspn_dy_ar
 // Backward pass B:  dX(rows, cin) = dY(rows, cout) . W^T      (M = rows, K = cout, N = cin)
 // A = dY rebuilt on the fly (dY = cA*dyh + cB*y + cC) while staging; B[k][n] = W[n][k] staged transposed.
 // ============================================================================================
-template <int BN, bool VEC>
+template <int BN, bool VEC, bool POOLED>
 __global__ __launch_bounds__(256) void mlp_bwd_data_kernel(long rows, int cin, int cout, gspn_dy_args a, const float* __restrict__ W,
                                                            float* __restrict__ dX, int ldx) {
     constexpr int NT = BN / 32;
@@ -822,8 +1164,6 @@ __global__ __launch_bounds__(256) void mlp_bwd_data_kernel(long rows, int cin, i
     __syncthreads();
     const int kq = (t & 7) * 4;
     const int arow = t >> 3;
-    const bool dzvec = VEC && a.dZ && (a.ldz % 4 == 0) && (((uintptr_t)a.dZ) % 16 == 0);
-
     float4 ry[4], rb[NB];
     DzRaw rz[4];
     long f_tile = 0;
@@ -837,7 +1177,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_data_kernel(long rows, int cin, i
             const long row = m0 + arow + 32 * i;
             const long rc = row < rows ? row : rows - 1;
             ry[i] = load4_raw<VEC>(a.Y, rc, a.ldy, k, cout);
-            rz[i] = dzvec ? dz4_raw<true>(a, rc, k, cout) : dz4_raw<false>(a, rc, k, cout);
+            rz[i] = dz4_raw<VEC, POOLED>(a, rc, k, cout);
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
@@ -857,7 +1197,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_data_kernel(long rows, int cin, i
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const long row = m0 + arow + 32 * i;
-            const float4 dzv = dz4_resolve(a, rz[i], row < rows ? row : rows - 1);
+            const float4 dzv = dz4_resolve<POOLED>(a, rz[i], row < rows ? row : rows - 1);
             const float yv[4] = {ry[i].x, ry[i].y, ry[i].z, ry[i].w};
             const float zv[4] = {dzv.x, dzv.y, dzv.z, dzv.w};
             float* d = sA + kq * LDT + arow + 32 * i;
@@ -933,9 +1273,14 @@ extern "C" int gspn_mlp_bwd_data(long rows, int cin, int cout, const gspn_dy_arg
     if (cin > MAXCH || cout > MAXCH) return GSPN_ERR_UNSUPPORTED;
     if (rows == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    const bool v = vec_ok(a->Y, a->ldy) && vec_ok(W, cout);
-#define BD_LAUNCH(BN_, V_, YT_) \
-    hipLaunchKernelGGL((mlp_bwd_data_kernel<BN_, V_>), dim3(row_grid(rows, YT_, 4), YT_), dim3(256), 0, st, rows, cin, cout, *a, W, dX, ldx)
+    if (rows >= (1L << 31)) return GSPN_ERR_UNSUPPORTED;
+    const bool pooled = a->dZ == nullptr;
+    const bool v = vec_ok(a->Y, a->ldy) && vec_ok(W, cout) && (pooled || vec_ok(a->dZ, a->ldz));
+#define BD_LAUNCH(BN_, V_, YT_)                                                                                                        \
+    do {                                                                                                                               \
+        if (pooled) hipLaunchKernelGGL((mlp_bwd_data_kernel<BN_, V_, true>), dim3(row_grid(rows, YT_, 4), YT_), dim3(256), 0, st, rows, cin, cout, *a, W, dX, ldx); \
+        else        hipLaunchKernelGGL((mlp_bwd_data_kernel<BN_, V_, false>), dim3(row_grid(rows, YT_, 4), YT_), dim3(256), 0, st, rows, cin, cout, *a, W, dX, ldx); \
+    } while (0)
     if (cin <= 32) { if (v) BD_LAUNCH(32, true, 1); else BD_LAUNCH(32, false, 1); }
     else if (cin <= 64) { if (v) BD_LAUNCH(64, true, 1); else BD_LAUNCH(64, false, 1); }
     else { const int yt = (cin + 127) / 128; if (v) BD_LAUNCH(128, true, yt); else BD_LAUNCH(128, false, yt); }
