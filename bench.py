@@ -6,6 +6,14 @@ Workload (BASELINE.json configs[2], the one `metric` is quoted on): per GPU a ba
 (pn2_fea_extractor, models/model_rpointnet.py:209-233), gradient all-reduce over RCCL when N>1, Adam update.
 Weak scaling: every rank owns 8 scenes.  Prints ONE JSON line on rank 0.
 
+Schedule: the coordinate-only part of a step (3 x FPS + ball query, 3 x 3-NN: gspn_amd/geometry.py) is computed two
+batches ahead on two side HIP streams while the MFMA layers of batch k run -- FPS is sequential in npoint and holds one
+CU per scene, so it overlaps instead of serialising.  Every timed step still executes one full geometry pass and one full
+fwd+bwd+update; three distinct synthetic batches rotate, nothing is cached across steps.  The ~200 launches of the
+layers' fwd+bwd are captured once into a hipGraph and replayed (gspn_amd/graph.py); the geometry stream, the gradient
+all-reduce and the Adam update stay eager.  --no-overlap runs the geometry inline on the main stream, --no-graph
+enqueues kernel by kernel (same kernels, same results either way).
+
   python bench.py --gpus 1 --steps 20 --warmup 3
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 """
@@ -39,10 +47,14 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="geometry inline on the main stream instead of prefetched on a side stream")
+    ap.add_argument("--no-graph", action="store_true", help="enqueue the layers kernel by kernel instead of replaying a captured hipGraph")
     args = ap.parse_args()
 
     from gspn_amd import parallel, tf_sampling, tf_util
-    from gspn_amd.fea_extractor import pn2_fea_extractor
+    from gspn_amd.fea_extractor import pn2_fea_extractor, pn2_geometry
+    from gspn_amd.geometry import GeometryStream
+    from gspn_amd.graph import CapturedStep, copy_into
 
     rank, local, world = parallel.init_from_env()
     if world != args.gpus and world > 1:
@@ -50,28 +62,81 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
-    # inputs resident in HBM before the timed region; rank r owns scenes [8r, 8r+8) of the global batch
-    xyz_np, col_np = synth(SCENES_PER_GPU, NPOINTS, seed0=rank * SCENES_PER_GPU)
-    xyz = torch.from_numpy(xyz_np).to(dev)
-    col = torch.from_numpy(col_np).to(dev)
+    # inputs resident in HBM before the timed region; rank r owns scenes [8r, 8r+8) of the global batch; NB distinct batches rotate
+    # (NB = 3 slots: the layers of step i read slot i%3 while the geometry of steps i+1 and i+2 is being written into the other two)
+    NB = 3
+    DEPTH = 2                   # geometry runs this many steps ahead, on DEPTH side streams (FPS throughput: one CU per scene per stream)
+    batches = []
+    for k in range(NB):
+        xyz_np, col_np = synth(SCENES_PER_GPU, NPOINTS, seed0=(k * 1000 + rank) * SCENES_PER_GPU)
+        batches.append((torch.from_numpy(xyz_np).to(dev), torch.from_numpy(col_np).to(dev)))
+        if k == 0:
+            xyz_np0, col_np0 = xyz_np, col_np
     gout = torch.from_numpy(np.random.default_rng(777).standard_normal((SCENES_PER_GPU, NPOINTS, 64)).astype(np.float32)).to(dev)
 
     store = tf_util.set_variable_store(tf_util.VariableStore(device=dev, seed=1234))   # same weights on every rank
-    state = {"bucket": None, "opt": None}
+    state = {"bucket": None, "opt": None, "i": 0, "pend": None}
+    geo = None if args.no_overlap else [GeometryStream(dev) for _ in range(DEPTH)]
+    use_graph = geo is not None and not args.no_graph
+    pend = {}                   # step index -> PendingGeometry
 
-    def step():
-        out = pn2_fea_extractor(xyz, col, 'fea', True, 0.5)
+    def fwd_bwd(k, g):
+        """forward + loss + backward of batch k with geometry g, gradients gathered into the flat bucket"""
+        xyz, col = batches[k]
+        out = pn2_fea_extractor(xyz, col, 'fea', True, 0.5, geometry=g)
         loss = (out * gout).sum() * (1.0 / out.numel())
-        if state["opt"] is not None:
-            state["opt"].zero_grad(set_to_none=True)      # backward assigns fresh grads; the bucket re-points them at its slices
         loss.backward()
         if state["bucket"] is None:
             params = store.parameters()
             state["bucket"] = parallel.FlatGradBucket(params)
             state["opt"] = torch.optim.Adam(params, lr=1e-3, foreach=True)
-        state["bucket"].all_reduce_mean()            # one flat RCCL all-reduce (no-op at world 1)
-        state["opt"].step()
+        state["bucket"].flatten()
         return loss
+
+    def finish():
+        state["bucket"].all_reduce()                 # one flat RCCL all-reduce (no-op at world 1)
+        state["opt"].step()
+
+    graphs = None
+    if use_graph:
+        # persistent geometry buffers per batch slot (the captured layers read these; the geometry stream refills them every step)
+        G = [pn2_geometry(batches[k][0]) for k in range(NB)]
+        fwd_bwd(0, G[0])                             # creates the variables, the bucket and the optimiser
+        finish()
+        graphs = []
+        def captured(k):
+            state["opt"].zero_grad(set_to_none=True)          # host-side only: the captured backward ASSIGNS fresh gradients, flatten() re-points them
+            return fwd_bwd(k, G[k])
+        for k in range(NB):
+            graphs.append(CapturedStep(lambda k=k: captured(k), pool=graphs[0].pool() if graphs else None))
+
+    def submit_geometry(j):
+        """geometry of step j (batch slot j % NB) on side stream j % DEPTH"""
+        kj = j % NB
+        if use_graph:
+            pend[j] = geo[j % DEPTH].submit(lambda x: copy_into(G[kj], pn2_geometry(x)), batches[kj][0])
+        else:
+            pend[j] = geo[j % DEPTH].submit(pn2_geometry, batches[kj][0])
+
+    if geo is not None:
+        for j in range(DEPTH):
+            submit_geometry(j)
+
+    def step():
+        i = state["i"]
+        state["i"] = i + 1
+        k = i % NB
+        g = None
+        if geo is not None:
+            g = pend.pop(i).get()                             # geometry of THIS step (submitted DEPTH steps ago)
+            submit_geometry(i + DEPTH)                        # runs under the layers of steps i .. i+DEPTH-1
+        if use_graph:
+            graphs[k].replay()
+        else:
+            if state["opt"] is not None:
+                state["opt"].zero_grad(set_to_none=True)      # backward assigns fresh grads; the bucket re-points them at its slices
+            fwd_bwd(k, g)
+        finish()
 
     for _ in range(args.warmup):
         step()
@@ -86,6 +151,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    t_host = time.perf_counter() - t0                  # host time to enqueue the K steps (launch-bound if close to dt)
     sync()
     dt = time.perf_counter() - t0
     prof = tf_sampling.PROFILE
@@ -126,13 +192,16 @@ def main():
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]: batch 8 x 32768-pt scenes per GPU, 3-level SA + 3-level FP (three_nn/interpolate) fwd+bwd, "
                                    "pn2_fea_extractor layer spec, BN training mode, Adam step", "scenes_per_gpu": SCENES_PER_GPU,
+                       "schedule": "geometry inline" if args.no_overlap else ("geometry of batches k+1, k+2 on two side streams under the layers of batch k"
+                                                                               + ("; fwd+bwd replayed from a hipGraph" if use_graph else "")),
                        "global_batch": global_batch, "npoints": NPOINTS, "parallelism": "dp%d (scenes sharded, one flat RCCL grad all-reduce)" % world},
-            "roofline": {"bound": "hbm", "kernel": "fps_resident_kernel<32,true> (SA1: 8 x 32768 -> 2048)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "fps_cell_kernel<32,true> + its sort pre-pass (SA1: 8 x 32768 -> 2048)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_ms": fps_avg_ms, "launches_timed": len(fps_ms)},
+            "host_enqueue_ms_per_step": t_host / args.steps * 1e3,
         }
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(xyz_np, col_np)
+            res["cpu_baseline"] = cpu_baseline(xyz_np0, col_np0)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
@@ -145,15 +214,15 @@ def cpu_baseline(xyz_np, col_np):
     nthr = torch.get_num_threads()
     torch.set_num_threads(1)
     try:
-        sample = 2
-        t1 = cpu_pipeline.run_step(xyz_np[:sample], col_np[:sample], mt=False)
+        sample, reps = 8, 2
+        t1 = min(cpu_pipeline.run_step(xyz_np[:sample], col_np[:sample], mt=False) for _ in range(reps))
     finally:
         torch.set_num_threads(nthr)
     cores = os.cpu_count() or 1
     tall = cpu_pipeline.run_step(xyz_np, col_np, mt=True)
     return {"value": sample / t1, "unit": "scenes/s", "cores": 1, "kind": "port",
-            "sample": "%d of the 8 scenes (32768 pts each), one full fwd+bwd step, single thread: C oracle for FPS/ball/group/3-NN/interp, "
-                      "torch-CPU fp32 stand-in for the TensorFlow MLP; %.1f s" % (sample, t1),
+            "sample": "one full fwd+bwd step on the %d scenes of one batch (32768 pts each), best of %d, single thread: C oracle for "
+                      "FPS/ball/group/3-NN/interp, torch-CPU fp32 stand-in for the TensorFlow MLP; %.1f s per step" % (sample, reps, t1),
             "all_cores": {"value": xyz_np.shape[0] / tall, "cores": cores,
                           "note": "same step on all 8 scenes: OpenMP over scenes for FPS/ball query (<=8 threads), torch intra-op threads for the MLP; %.1f s" % tall}}
 

@@ -1,0 +1,109 @@
+"""The weight-independent half of the set-abstraction graph, and a side stream to run it ahead of time.
+
+Everything `pointnet_sa_module` / `pointnet_fp_module` compute from coordinates alone -- farthest point
+sampling, the gather of the sampled centres, the ball query (utils/pointnet_util.py:38-40) and the 3-NN
+search with its inverse-distance weights (:155-160) -- depends on `xyz` only, never on a weight or a
+feature.  FPS is also the one kernel that cannot fill the chip: it is sequential in `npoint` and one
+scene lives on one CU (8 scenes -> 8 of 256 CUs for 2.5 ms at 8 x 32768 -> 2048).  So the geometry of
+batch k+1 is computed on its own HIP stream while the MFMA layers of batch k own the other CUs:
+
+    geo = GeometryStream(device)
+    pend = geo.submit(pn2_geometry, xyz_next)          # side stream, returns immediately
+    out = pn2_fea_extractor(xyz, feats, 'fea', True, bn_decay, geometry=pend_prev.get())
+
+Results are identical to the inline path (same kernels, same inputs); only the schedule changes.
+"""
+import torch
+
+from .tf_grouping import knn_point, query_ball_point
+from .tf_interpolate import three_nn
+from .tf_sampling import farthest_point_sample, gather_point
+
+
+class SAGeometry:
+    """new_xyz (b,npoint,3), idx (b,npoint,nsample) int32, pts_cnt (b,npoint) int32 or None (knn)"""
+    __slots__ = ("new_xyz", "idx", "pts_cnt", "npoint", "nsample")
+
+    def __init__(self, new_xyz, idx, pts_cnt, npoint, nsample):
+        self.new_xyz, self.idx, self.pts_cnt, self.npoint, self.nsample = new_xyz, idx, pts_cnt, npoint, nsample
+
+    def tensors(self):
+        return [t for t in (self.new_xyz, self.idx, self.pts_cnt) if t is not None]
+
+
+class FPGeometry:
+    """idx (b,n1,3) int32 and weight (b,n1,3) float32 of pointnet_util.py:155-160"""
+    __slots__ = ("idx", "weight")
+
+    def __init__(self, idx, weight):
+        self.idx, self.weight = idx, weight
+
+    def tensors(self):
+        return [self.idx, self.weight]
+
+
+def sa_geometry(xyz, npoint, radius, nsample, knn=False):
+    """pointnet_util.py:38-40: centres by FPS, neighbours by ball query (or kNN)."""
+    xyz = xyz.detach()
+    new_xyz = gather_point(xyz, farthest_point_sample(npoint, xyz))
+    if knn:
+        _, idx = knn_point(nsample, xyz, new_xyz)
+        cnt = None
+    else:
+        idx, cnt = query_ball_point(radius, nsample, xyz, new_xyz)
+    return SAGeometry(new_xyz, idx, cnt, npoint, nsample)
+
+
+def fp_geometry(xyz1, xyz2):
+    """pointnet_util.py:155-160: three nearest sparse points of every dense point and their normalised 1/d weights."""
+    dist, idx = three_nn(xyz1.detach(), xyz2.detach())
+    dist = torch.clamp(dist, min=1e-10)                               # :157
+    norm = (1.0 / dist).sum(dim=2, keepdim=True)                      # :158
+    weight = (1.0 / dist) / norm                                      # :160
+    return FPGeometry(idx, weight)
+
+
+class PendingGeometry:
+    def __init__(self, value, event, stream):
+        self._value, self._event, self._stream = value, event, stream
+
+    def get(self):
+        """Make the consumer's current stream wait for the geometry and hand the tensors over to it."""
+        cur = torch.cuda.current_stream()
+        if cur != self._stream:
+            cur.wait_event(self._event)
+            for t in _tensors_of(self._value):
+                t.record_stream(cur)
+        return self._value
+
+
+def _tensors_of(v):
+    if isinstance(v, torch.Tensor):
+        return [v]
+    if hasattr(v, "tensors"):
+        return v.tensors()
+    if isinstance(v, dict):
+        return [t for x in v.values() for t in _tensors_of(x)]
+    if isinstance(v, (list, tuple)):
+        return [t for x in v for t in _tensors_of(x)]
+    return []
+
+
+class GeometryStream:
+    """A side HIP stream for coordinate-only work.  submit(fn, *tensors) runs fn on it after the tensors'
+    producer (the caller's current stream) and returns a PendingGeometry."""
+
+    def __init__(self, device=None, priority=0):
+        self.stream = torch.cuda.Stream(device=device, priority=priority)
+
+    def submit(self, fn, *args, **kwargs):
+        ready = torch.cuda.current_stream().record_event()
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(ready)
+            for a in args:
+                if isinstance(a, torch.Tensor):
+                    a.record_stream(self.stream)
+            with torch.no_grad():
+                value = fn(*args, **kwargs)
+            done = self.stream.record_event()
+        return PendingGeometry(value, done, self.stream)

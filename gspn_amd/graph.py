@@ -1,0 +1,53 @@
+"""hipGraph capture of the launch-bound part of a training step.
+
+One fwd+bwd of the set-abstraction stack is ~200 short kernels; enqueueing them from Python costs about as
+much wall time as the GPU needs to run them once the geometry is overlapped (geometry.py).  CapturedStep
+records the step once into a hipGraph (torch.cuda.CUDAGraph == hipGraph on ROCm: every C-ABI launch goes to
+the capturing stream, scratch comes from the graph's private pool) and replays it with one call.
+
+Contract: the captured callable reads its inputs from tensors whose storage does not change between
+replays (copy each new batch into them), and leaves its results (e.g. the flat gradient bucket) in
+persistent tensors.  Work that must stay observable per launch -- the geometry stream with its HIP events --
+stays outside the graph.
+"""
+import torch
+
+
+class CapturedStep:
+    def __init__(self, fn, warmup=2, pool=None):
+        """fn(): enqueue the step on the current stream, return a tensor (e.g. the loss) or None.  It is run `warmup`
+        times eagerly on a side stream (lazy initialisation, variable creation), then captured."""
+        self.graph = torch.cuda.CUDAGraph()
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                fn()
+        cur.wait_stream(side)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(self.graph, pool=pool):
+            self.result = fn()
+
+    def pool(self):
+        return self.graph.pool()
+
+    def replay(self):
+        self.graph.replay()
+        return self.result
+
+
+def copy_into(dst, src):
+    """Copy a (nested) geometry result into persistent buffers of the same structure (on the current stream)."""
+    if isinstance(dst, torch.Tensor):
+        dst.copy_(src, non_blocking=True)
+    elif isinstance(dst, dict):
+        for k in dst:
+            copy_into(dst[k], src[k])
+    elif isinstance(dst, (list, tuple)):
+        for d, s in zip(dst, src):
+            copy_into(d, s)
+    elif hasattr(dst, "tensors"):
+        for d, s in zip(dst.tensors(), src.tensors()):
+            d.copy_(s, non_blocking=True)
+    return dst

@@ -30,23 +30,44 @@ def shard_range(total, rank, world):
 
 
 class FlatGradBucket:
-    """Flat fp32 bucket over a fixed parameter list.  One `cat` gathers the fresh gradients, ONE all_reduce(SUM) averages them
-    over ranks, and every p.grad is then re-pointed at its slice of the bucket (views, no copies back).  Use with
-    optimizer.zero_grad(set_to_none=True) so backward assigns gradients instead of accumulating into the views."""
+    """Flat fp32 bucket over a fixed parameter list.  flatten(): one `cat` gathers the fresh gradients into the persistent bucket and
+    every p.grad is re-pointed at its slice (views, no copies back); all_reduce(): ONE all_reduce(SUM) + scale averages the bucket
+    over ranks.  Use with optimizer.zero_grad(set_to_none=True) so backward assigns gradients instead of accumulating into the views.
+    The bucket's storage never changes, so a captured step (graph.py) can end in flatten() and be replayed."""
 
     def __init__(self, params):
         self.params = [p for p in params]
         self.sizes = [p.numel() for p in self.params]
-        self.flat = None
+        dev = self.params[0].device if self.params else None
+        self.flat = torch.zeros(sum(self.sizes), dtype=torch.float32, device=dev)
+        self._views = []
+        off = 0
+        for p, s in zip(self.params, self.sizes):
+            self._views.append(self.flat[off:off + s].view_as(p))
+            off += s
 
-    def all_reduce_mean(self):
-        grads = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.params]
-        self.flat = torch.cat(grads) if grads else torch.zeros(0)
+    def flatten(self):
+        if not self.params:
+            return self.flat
+        grads = []
+        for p, v in zip(self.params, self._views):
+            g = p.grad
+            if g is None:
+                g = torch.zeros_like(p)
+            elif g.data_ptr() == v.data_ptr():
+                g = g.clone()                       # already a view of the bucket (no fresh gradient this step): cat must not alias `out`
+            grads.append(g.reshape(-1))
+        torch.cat(grads, out=self.flat)
+        for p, v in zip(self.params, self._views):
+            p.grad = v
+        return self.flat
+
+    def all_reduce(self):
         if dist.is_initialized() and dist.get_world_size() > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
             self.flat.div_(dist.get_world_size())
-        off = 0
-        for p, s in zip(self.params, self.sizes):
-            p.grad = self.flat[off:off + s].view_as(p)
-            off += s
         return self.flat
+
+    def all_reduce_mean(self):
+        self.flatten()
+        return self.all_reduce()

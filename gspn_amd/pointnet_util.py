@@ -10,6 +10,7 @@ import torch
 
 from . import _lib as L
 from . import tf_util
+from .geometry import fp_geometry, sa_geometry
 from .mlp import mlp_stack
 from .tf_grouping import group_point, knn_point, query_ball_point
 from .tf_interpolate import three_interpolate, three_nn
@@ -100,14 +101,19 @@ def _mlp_layers(channels, cin, prefix, bn):
 
 
 def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_all, is_training, bn_decay, scope, bn=True,
-                       pooling='max', tnet_spec=None, knn=False, use_xyz=True):
-    """pointnet_util.py:85-139.  Returns new_xyz (b,npoint,3), new_points (b,npoint,mlp[-1] or mlp2[-1]), idx (b,npoint,nsample)."""
+                       pooling='max', tnet_spec=None, knn=False, use_xyz=True, geometry=None):
+    """pointnet_util.py:85-139.  Returns new_xyz (b,npoint,3), new_points (b,npoint,mlp[-1] or mlp2[-1]), idx (b,npoint,nsample).
+    `geometry` (extension): an SAGeometry computed ahead of time for this xyz/npoint/radius/nsample (geometry.py);
+    None computes it inline, with identical results."""
     with tf_util.variable_scope(scope):
         b = xyz.shape[0]
         fused = (pooling == 'max') and not group_all and not knn and tnet_spec is None and len(mlp) > 0 and (points is None or use_xyz)
+        if geometry is not None and (not fused or geometry.npoint != npoint or geometry.nsample != nsample):
+            raise ValueError("pointnet_sa_module: precomputed geometry does not match this module")
         if fused:
-            new_xyz = gather_point(xyz, farthest_point_sample(npoint, xyz))
-            idx, pts_cnt = query_ball_point(radius, nsample, xyz, new_xyz)
+            if geometry is None:
+                geometry = sa_geometry(xyz, npoint, radius, nsample)
+            new_xyz, idx = geometry.new_xyz, geometry.idx
             rows = group_concat(xyz, new_xyz, points, idx, xyz_first=True)      # (b*npoint*nsample, pitch >= 3+c)
             cin = 3 + (0 if points is None else points.shape[2])
             layers = _mlp_layers(mlp, cin, 'conv', bn)
@@ -146,14 +152,14 @@ def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_al
         return new_xyz, new_points, idx
 
 
-def pointnet_fp_module(xyz1, xyz2, points1, points2, mlp, is_training, bn_decay, scope, bn=True, reuse=False):
+def pointnet_fp_module(xyz1, xyz2, points1, points2, mlp, is_training, bn_decay, scope, bn=True, reuse=False, geometry=None):
     """pointnet_util.py:142-174.  xyz1 (b,n1,3) dense, xyz2 (b,n2,3) sparse, points1 (b,n1,c1) or None,
-    points2 (b,n2,c2) -> (b,n1,mlp[-1])  (or the concatenated features when mlp == [])."""
+    points2 (b,n2,c2) -> (b,n1,mlp[-1])  (or the concatenated features when mlp == []).
+    `geometry` (extension): an FPGeometry (3-NN indices + weights, :155-160) computed ahead of time; None computes it inline."""
     with tf_util.variable_scope(scope, reuse=reuse):
-        dist, idx = three_nn(xyz1, xyz2)
-        dist = torch.clamp(dist, min=1e-10)                               # :157
-        norm = (1.0 / dist).sum(dim=2, keepdim=True)                      # :158
-        weight = (1.0 / dist) / norm                                      # :160
+        if geometry is None:
+            geometry = fp_geometry(xyz1, xyz2)
+        idx, weight = geometry.idx, geometry.weight
         interpolated_points = three_interpolate(points2, idx, weight)
         if points1 is not None:
             new_points1 = torch.cat([interpolated_points, points1], dim=2)   # :164 (interp FIRST)

@@ -133,3 +133,77 @@ def test_fea_extractor_runs_and_backprops():
     out.square().mean().backward()
     for name, p in store.named_parameters():
         assert p.grad is not None and torch.isfinite(p.grad).all(), name
+
+
+def test_prefetched_geometry_is_identical_to_inline():
+    """geometry.py: the coordinate-only half computed ahead on a side stream gives bit-identical outputs and gradients"""
+    from gspn_amd.fea_extractor import pn2_fea_extractor, pn2_geometry
+    from gspn_amd.geometry import GeometryStream
+    xyz = torch.from_numpy(D.batch("U", 2, 8192)).cuda()
+    col = torch.rand(2, 8192, 3, device="cuda")
+    outs, grads = [], []
+    for prefetch in (False, True):
+        store = fresh_store(7)
+        g = None
+        if prefetch:
+            gs = GeometryStream(xyz.device)
+            pend = gs.submit(pn2_geometry, xyz)
+            g = pend.get()
+            inline = pn2_geometry(xyz)
+            for a, b_ in zip(g["sa"], inline["sa"]):
+                assert torch.equal(a.idx, b_.idx) and torch.equal(a.new_xyz, b_.new_xyz) and torch.equal(a.pts_cnt, b_.pts_cnt)
+            for a, b_ in zip(g["fp"], inline["fp"]):
+                assert torch.equal(a.idx, b_.idx) and torch.equal(a.weight, b_.weight)
+        out = pn2_fea_extractor(xyz, col, 'fea', True, 0.5, geometry=g)
+        out.square().mean().backward()
+        outs.append(out.detach().clone())
+        grads.append({n: p.grad.detach().clone() for n, p in store.named_parameters()})
+    assert torch.equal(outs[0], outs[1])
+    # (weight gradients are summed with fp32 atomics only in the shared-slot fallback; these shapes use owned slots -> deterministic)
+    for n in grads[0]:
+        assert torch.allclose(grads[0][n], grads[1][n], rtol=1e-5, atol=1e-7), n
+
+
+def test_sa_module_rejects_mismatched_geometry():
+    from gspn_amd.geometry import sa_geometry
+    from gspn_amd.pointnet_util import pointnet_sa_module
+    fresh_store(3)
+    xyz = torch.from_numpy(D.batch("U", 1, 1024)).cuda()
+    g = sa_geometry(xyz, 128, 0.3, 16)
+    with pytest.raises(ValueError):
+        pointnet_sa_module(xyz, None, 64, 0.3, 16, [16], None, False, True, None, 'l', geometry=g)
+
+
+def test_captured_step_replays_the_eager_step():
+    """graph.py: a hipGraph replay of fwd+bwd+flatten leaves the same loss and flat gradient as the eager step"""
+    from gspn_amd import parallel
+    from gspn_amd.fea_extractor import pn2_fea_extractor, pn2_geometry
+    from gspn_amd.graph import CapturedStep
+    xyz = torch.from_numpy(D.batch("U", 2, 8192)).cuda()
+    col = torch.rand(2, 8192, 3, device="cuda")
+    store = fresh_store(11)
+    geo = pn2_geometry(xyz)
+    st = {}
+
+    def fwd_bwd():
+        for p in store.parameters():
+            p.grad = None
+        out = pn2_fea_extractor(xyz, col, 'fea', True, 0.5, geometry=geo)
+        loss = out.square().mean()
+        loss.backward()
+        if "bucket" not in st:
+            st["bucket"] = parallel.FlatGradBucket(store.parameters())
+        st["bucket"].flatten()
+        return loss
+
+    loss0 = fwd_bwd().detach().clone()
+    flat0 = st["bucket"].flat.clone()
+    cap = CapturedStep(fwd_bwd)
+    st["bucket"].flat.zero_()
+    loss1 = cap.replay()
+    torch.cuda.synchronize()
+    assert torch.allclose(loss1, loss0, rtol=1e-6)
+    assert torch.allclose(st["bucket"].flat, flat0, rtol=1e-4, atol=1e-7)
+    # parameters' .grad are views of the bucket: an optimiser sees the replayed gradients
+    p0 = store.parameters()[0]
+    assert p0.grad.data_ptr() == st["bucket"].flat.data_ptr()
