@@ -642,15 +642,27 @@ __global__ __launch_bounds__(256) void mlp_bwd_wgrad_kernel(long rows, int cin, 
 __device__ __forceinline__ void glds16(const float* g, float* l) {        // 64 lanes x 16 B -> 1 KiB of LDS at l (wave-uniform)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
+// Work split inside a workgroup: the T = MT*NTT tiles and WK k-parts are dealt to the 4 waves as a (GM x GN) grid of wave groups
+// times WK k-parts (GM*GN*WK == 4).  Wave (gm, gn, kp) owns the AM x BNW block of tiles {tm = gm + GM*a} x {tn = gn + GN*b} over
+// the rows of k-part kp: one k-loop with all its accumulators live, A operands shared along b and B operands along a.
+template <int MT, int NTT> struct WgradSplit {
+    static constexpr int T = MT * NTT;
+    static constexpr int WK = (T % 4 == 0) ? 1 : ((T % 2 == 0) ? 2 : 4);
+    static constexpr int G = 4 / WK;
+    static constexpr int GM = G == 4 ? ((MT % 2 == 0 && NTT % 2 == 0) ? 2 : (MT % 4 == 0 ? 4 : 1)) : (G == 2 ? (NTT % 2 == 0 ? 1 : 2) : 1);
+    static constexpr int GN = G / GM;
+    static constexpr int AM = MT / GM, BNW = NTT / GN;
+    static_assert(MT % GM == 0 && NTT % GN == 0, "wave groups tile the block");
+};
 template <int MT, int NTT, int TKW, bool WANT_GX, bool POOLED>
-__global__ __launch_bounds__(256) void wgrad_stream_kernel(int rows, int cin, int cout, gspn_dy_args a, const float* __restrict__ X, int ldx,
+__global__ __launch_bounds__(256, ((WgradSplit<MT, NTT>::AM * WgradSplit<MT, NTT>::BNW * (WANT_GX ? 2 : 1) >= 4 || (POOLED && TKW >= 32)) ? 2 : 3)) void wgrad_stream_kernel(int rows, int cin, int cout, gspn_dy_args a, const float* __restrict__ X, int ldx,
                                                            const float* __restrict__ in_scale, const float* __restrict__ in_shift,
                                                            const float* __restrict__ mean, const float* __restrict__ var, float eps,
                                                            float* __restrict__ RP, float* __restrict__ GP, float* __restrict__ PP,
                                                            int rows_per_chunk, int nslots, int shared, int nch, int nrow, int ncol) {
-    constexpr int BM = 32 * MT, BN = 32 * NTT, T = MT * NTT;
-    constexpr int WK = (T % 4 == 0) ? 1 : ((T % 2 == 0) ? 2 : 4);     // K split so that every wave owns T*WK/4 (tile, k-part) slots
-    constexpr int TPW = T * WK / 4;
+    using SP = WgradSplit<MT, NTT>;
+    constexpr int BM = 32 * MT, BN = 32 * NTT;
+    constexpr int WK = SP::WK, GM = SP::GM, GN = SP::GN, AM = SP::AM, BNW = SP::BNW;
     constexpr int KPER = TKW / WK;
     static_assert(KPER % 2 == 0 && KPER >= 2, "k-part must hold whole MFMA k-pairs");
     constexpr int AQ = BM / 4, BQ = BN / 4;
@@ -662,6 +674,8 @@ __global__ __launch_bounds__(256) void wgrad_stream_kernel(int rows, int cin, in
     __shared__ __attribute__((aligned(16))) float sbuf[2 * SF];
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int l31 = lane & 31, half = lane >> 5;
+    const int kp = wave % WK, grp = wave / WK;
+    const int gm = grp % GM, gn = grp / GM;
 
     // block -> (chunk, tile): the tiles of one chunk are adjacent in launch order AND on the same XCD (id % 8), so the rows they
     // share are fetched from HBM once per XCD L2
@@ -714,50 +728,50 @@ __global__ __launch_bounds__(256) void wgrad_stream_kernel(int rows, int cin, in
         }
     };
 
-    // ---- per-slot constants ----
-    int s_tm[TPW], s_tn[TPW], s_kp[TPW];
-    float isc[TPW], ish[TPW], bsc[TPW], bsh[TPW], bmu[TPW], brs[TPW];
+    // ---- per-operand constants: AM input-channel columns, BNW output-channel columns per lane ----
+    float isc[AM], ish[AM], bsc[BNW], bsh[BNW], bmu[BNW], brs[BNW];
+    int ao[AM], bo[BNW];
     const float lo = in_scale ? 0.f : -__builtin_inff();               // relu floor (none for a raw first-layer input)
 #pragma unroll
-    for (int i = 0; i < TPW; ++i) {
-        const int slot = wave + 4 * i;
-        const int tile = slot % T;
-        s_kp[i] = slot / T;
-        s_tm[i] = tile % MT;
-        s_tn[i] = tile / MT;
-        const int m = min(m0 + s_tm[i] * 32 + l31, cin - 1);
-        const int n = min(n0 + s_tn[i] * 32 + l31, cout - 1);
-        isc[i] = in_scale ? in_scale[m] : 1.f;
-        ish[i] = in_scale ? in_shift[m] : 0.f;
-        bsc[i] = a.scale[n];
-        bsh[i] = a.shift[n];
-        bmu[i] = mean ? mean[n] : 0.f;
-        brs[i] = var ? (float)(1.0 / sqrt((double)var[n] + (double)eps)) : 1.f;
+    for (int x = 0; x < AM; ++x) {
+        ao[x] = (gm + GM * x) * 32 + l31;
+        const int m = min(m0 + ao[x], cin - 1);
+        isc[x] = in_scale ? in_scale[m] : 1.f;
+        ish[x] = in_scale ? in_shift[m] : 0.f;
     }
-    // ---- pooled gradient: per (slot, group-in-stage) arg-max offset and pooled gradient of the lane's column ----
+#pragma unroll
+    for (int y = 0; y < BNW; ++y) {
+        bo[y] = (gn + GN * y) * 32 + l31;
+        const int n = min(n0 + bo[y], cout - 1);
+        bsc[y] = a.scale[n];
+        bsh[y] = a.shift[n];
+        bmu[y] = mean ? mean[n] : 0.f;
+        brs[y] = var ? (float)(1.0 / sqrt((double)var[n] + (double)eps)) : 1.f;
+    }
+    // ---- pooled gradient: per (column tile, group-in-stage) arg-max offset and pooled gradient of the lane's column ----
     const int ns = POOLED ? a.ns : TKW;
     const int gs = min(ns, TKW);                      // rows of one pool group inside a stage
     const int ng = TKW / gs;                          // groups per stage (<= NGMAX)
     const int ngroups = POOLED ? rows / ns : 0;
     int g_next = POOLED ? r_begin / ns : 0;           // first group / row offset within it of the NEXT stage to prefetch
     int off_next = POOLED ? r_begin - g_next * ns : 0;
-    int p_arg[TPW][NGMAX], n_arg[TPW][NGMAX];
-    float p_dp[TPW][NGMAX], n_dp[TPW][NGMAX];
-    bool n_ok[TPW][NGMAX];
+    int p_arg[BNW][NGMAX], n_arg[BNW][NGMAX];
+    float p_dp[BNW][NGMAX], n_dp[BNW][NGMAX];
+    bool n_ok[BNW][NGMAX];
     int off_cur = 0, off_nxt = 0;
     auto pool_fetch = [&]() {                          // loads for the stage (g_next, off_next) into n_*; advances the cursor
         if constexpr (POOLED) {
             off_nxt = off_next;
 #pragma unroll
-            for (int i = 0; i < TPW; ++i) {
-                const int n = min(n0 + s_tn[i] * 32 + l31, cout - 1);
+            for (int y = 0; y < BNW; ++y) {
+                const int n = min(n0 + bo[y], cout - 1);
 #pragma unroll
                 for (int gl = 0; gl < NGMAX; ++gl) {
                     const int g = g_next + gl;
                     const size_t at = (size_t)min(g, ngroups - 1) * cout + n;
-                    n_arg[i][gl] = a.pool_arg[at];
-                    n_dp[i][gl] = a.dPool[at];
-                    n_ok[i][gl] = g < ngroups && gl < ng;                   // rows past the end / unused slots never match
+                    n_arg[y][gl] = a.pool_arg[at];
+                    n_dp[y][gl] = a.dPool[at];
+                    n_ok[y][gl] = g < ngroups && gl < ng;                   // rows past the end / unused slots never match
                     // (the select is applied when the values are consumed, one stage later: selecting here would make hipcc wait
                     //  for these loads -- and with them for the stage's LDS-DMA pieces -- right after issuing them)
                 }
@@ -767,14 +781,18 @@ __global__ __launch_bounds__(256) void wgrad_stream_kernel(int rows, int cin, in
         }
     };
 
-    f32x16 acc1[TPW], accx[WANT_GX ? TPW : 1];
-    float r0a[TPW], r1a[TPW], g3a[TPW];
+    f32x16 acc1[AM][BNW], accx[WANT_GX ? AM : 1][WANT_GX ? BNW : 1];
+    float r0a[BNW], r1a[BNW], g3a[AM];
 #pragma unroll
-    for (int i = 0; i < TPW; ++i) {
-        r0a[i] = r1a[i] = g3a[i] = 0.f;
+    for (int x = 0; x < AM; ++x) {
+        g3a[x] = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc1[i][r] = 0.f; if (WANT_GX) accx[i][r] = 0.f; }
+        for (int y = 0; y < BNW; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc1[x][y][r] = 0.f; if (WANT_GX) accx[x][y][r] = 0.f; }
     }
+#pragma unroll
+    for (int y = 0; y < BNW; ++y) r0a[y] = r1a[y] = 0.f;
 
     pool_fetch();
     issue(0);
@@ -784,9 +802,9 @@ __global__ __launch_bounds__(256) void wgrad_stream_kernel(int rows, int cin, in
         const float* buf = sbuf + (s & 1) * SF;
         if constexpr (POOLED) {
 #pragma unroll
-            for (int i = 0; i < TPW; ++i)
+            for (int y = 0; y < BNW; ++y)
 #pragma unroll
-                for (int gl = 0; gl < NGMAX; ++gl) { p_arg[i][gl] = n_ok[i][gl] ? n_arg[i][gl] : -1; p_dp[i][gl] = n_dp[i][gl]; }
+                for (int gl = 0; gl < NGMAX; ++gl) { p_arg[y][gl] = n_ok[y][gl] ? n_arg[y][gl] : -1; p_dp[y][gl] = n_dp[y][gl]; }
             off_cur = off_nxt;
         }
         if (s + 1 < nit) { pool_fetch(); issue(s + 1); }
@@ -796,46 +814,56 @@ __global__ __launch_bounds__(256) void wgrad_stream_kernel(int rows, int cin, in
         const int live = nloc - s * TKW;                        // < TKW only in a ragged last stage (clamped duplicate rows follow)
         auto compute = [&](auto tail_c) {
             constexpr bool TAIL = decltype(tail_c)::value;
+            // one MFMA k-pair: this lane's row r of the stage; gl = pool group of that row (compile-time when it matters)
+            auto step = [&](int r, int gl_rt) {
+                float av[AM], dyh[BNW], xh[BNW];
 #pragma unroll
-            for (int i = 0; i < TPW; ++i) {
-                const int ao = s_tm[i] * 32 + l31, bo = s_tn[i] * 32 + l31;
-                auto pair = [&](int r, float dz) {              // r = this lane's row within the stage
+                for (int x = 0; x < AM; ++x) {
                     // (no inline asm here: hipcc's hazard recogniser does not see an asm VALU write feeding an MFMA operand)
-                    float av = __builtin_fmaxf(sA[r * BM + ao] * isc[i] + ish[i], lo);
-                    const float y = sY[r * BN + bo];
-                    if (TAIL) { av = r < live ? av : 0.f; dz = r < live ? dz : 0.f; }
-                    const float dyh = (y * bsc[i] + bsh[i]) > 0.f ? dz : 0.f;
-                    const float xh = (y - bmu[i]) * brs[i];
-                    acc1[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, dyh, acc1[i], 0, 0, 0);
-                    if (WANT_GX) accx[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xh, accx[i], 0, 0, 0);
-                    r0a[i] += dyh;
-                    r1a[i] += dyh * xh;
-                    g3a[i] += av;
-                };
-                const int k_lo = s_kp[i] * KPER;
-                if constexpr (!POOLED) {
-#pragma unroll 4
-                    for (int kk = 0; kk < KPER; kk += 2) {
-                        const int r = k_lo + kk + half;
-                        pair(r, sZ[r * BN + bo]);
-                    }
-                } else if constexpr (NGMAX == 1) {
-#pragma unroll 4
-                    for (int kk = 0; kk < KPER; kk += 2) {
-                        const int r = k_lo + kk + half;
-                        pair(r, p_arg[i][0] == off_cur + r ? p_dp[i][0] : 0.f);
-                    }
-                } else {
+                    av[x] = __builtin_fmaxf(sA[r * BM + ao[x]] * isc[x] + ish[x], lo);
+                    if (TAIL) av[x] = r < live ? av[x] : 0.f;
+                }
 #pragma unroll
-                    for (int gl = 0; gl < NGMAX; ++gl) {
-                        if (gl < ng) {
-                            const int lo_k = max(k_lo, gl * gs), hi_k = min(k_lo + KPER, (gl + 1) * gs);
-                            for (int kk = lo_k; kk < hi_k; kk += 2) {
-                                const int r = kk + half;
-                                pair(r, p_arg[i][gl] == off_cur + r - gl * gs ? p_dp[i][gl] : 0.f);
-                            }
-                        }
+                for (int y = 0; y < BNW; ++y) {
+                    const float yv = sY[r * BN + bo[y]];
+                    float dz;
+                    if constexpr (!POOLED) dz = sZ[r * BN + bo[y]];
+                    else if constexpr (NGMAX == 1) dz = p_arg[y][0] == off_cur + r ? p_dp[y][0] : 0.f;
+                    else {
+                        dz = 0.f;
+#pragma unroll
+                        for (int gl = 0; gl < NGMAX; ++gl)
+                            if (gl == gl_rt) dz = p_arg[y][gl] == off_cur + r - gl * gs ? p_dp[y][gl] : 0.f;
                     }
+                    if (TAIL) dz = r < live ? dz : 0.f;
+                    dyh[y] = (yv * bsc[y] + bsh[y]) > 0.f ? dz : 0.f;
+                    xh[y] = (yv - bmu[y]) * brs[y];
+                    r0a[y] += dyh[y];
+                    r1a[y] += dyh[y] * xh[y];
+                }
+#pragma unroll
+                for (int x = 0; x < AM; ++x) {
+                    g3a[x] += av[x];
+#pragma unroll
+                    for (int y = 0; y < BNW; ++y) {
+                        acc1[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x], dyh[y], acc1[x][y], 0, 0, 0);
+                        if (WANT_GX) accx[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x], xh[y], accx[x][y], 0, 0, 0);
+                    }
+                }
+            };
+            const int k_lo = kp * KPER;
+            if constexpr ((!POOLED || NGMAX == 1) && AM * BNW * (WANT_GX ? 2 : 1) >= 4) {
+                // 64+ accumulator registers: no unrolling (the MFMAs of one step cover the LDS latency of the next wave's step)
+#pragma unroll 1
+                for (int kk = 0; kk < KPER; kk += 2) step(k_lo + kk + half, 0);
+            } else if constexpr (!POOLED || NGMAX == 1) {
+#pragma unroll 2
+                for (int kk = 0; kk < KPER; kk += 2) step(k_lo + kk + half, 0);
+            } else {
+                // rows of pool group gl inside the stage: [gl*gs, (gl+1)*gs); ns is even, so a k-pair never straddles two groups
+                for (int kk = 0; kk < KPER; kk += 2) {
+                    const int r = k_lo + kk + half;
+                    step(r, (k_lo + kk) / gs);
                 }
             }
         };
@@ -844,47 +872,51 @@ __global__ __launch_bounds__(256) void wgrad_stream_kernel(int rows, int cin, in
     }
     // ---- epilogue: this chunk's partial tiles / sums ----
     // shared == 0: every (chunk, k-part) owns a partial-tile slot -> plain stores; else chunks share zero-filled slots (fp32 atomics)
-#pragma unroll
-    for (int i = 0; i < TPW; ++i) {
-        const int slot = shared ? chunk % nslots : chunk * WK + s_kp[i];
+    {
+        const int slot = shared ? chunk % nslots : chunk * WK + kp;
         float* P1 = PP + (size_t)slot * 2 * cin * cout;
         float* Px = P1 + (size_t)cin * cout;
-        const int col = n0 + s_tn[i] * 32 + l31;
-        if (col < cout) {
-            if (shared) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + s_tm[i] * 32 + c_row(r, lane);
-                    if (m < cin) {
-                        atomicAdd(P1 + (size_t)m * cout + col, acc1[i][r]);
-                        if (WANT_GX) atomicAdd(Px + (size_t)m * cout + col, accx[i][r]);
-                    }
-                }
-            } else {
+        for (int x = 0; x < AM; ++x)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + s_tm[i] * 32 + c_row(r, lane);
-                    if (m < cin) {
-                        P1[(size_t)m * cout + col] = acc1[i][r];
-                        if (WANT_GX) Px[(size_t)m * cout + col] = accx[i][r];
+            for (int y = 0; y < BNW; ++y) {
+                const int col = n0 + bo[y];
+                if (col < cout) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = m0 + (gm + GM * x) * 32 + c_row(r, lane);
+                        if (m < cin) {
+                            if (shared) {
+                                atomicAdd(P1 + (size_t)m * cout + col, acc1[x][y][r]);
+                                if (WANT_GX) atomicAdd(Px + (size_t)m * cout + col, accx[x][y][r]);
+                            } else {
+                                P1[(size_t)m * cout + col] = acc1[x][y][r];
+                                if (WANT_GX) Px[(size_t)m * cout + col] = accx[x][y][r];
+                            }
+                        }
                     }
                 }
             }
-        }
     }
-    // column sums: one LDS cell per (k-part, lane half, column), summed in a fixed order
+    // column sums: one LDS cell per (k-part, lane half, column), summed in a fixed order.  Every column tile is seen by GM wave
+    // groups (only gm == 0 reports it), every row tile by GN (only gn == 0 reports it).
     __syncthreads();
     float* sR = sbuf;                                   // [WK*2][2][BN]
     float* sG = sbuf + WK * 2 * 2 * BN;                 // [WK*2][BM]
     static_assert(WK * 2 * (2 * BN + BM) <= 2 * SF, "reduction scratch fits the stage buffers");
+    {
+        const int part = kp * 2 + half;
+        if (gm == 0) {
 #pragma unroll
-    for (int i = 0; i < TPW; ++i) {
-        const int part = s_kp[i] * 2 + half;
-        if (s_tm[i] == 0) {
-            sR[(part * 2 + 0) * BN + s_tn[i] * 32 + l31] = r0a[i];
-            sR[(part * 2 + 1) * BN + s_tn[i] * 32 + l31] = r1a[i];
+            for (int y = 0; y < BNW; ++y) {
+                sR[(part * 2 + 0) * BN + bo[y]] = r0a[y];
+                sR[(part * 2 + 1) * BN + bo[y]] = r1a[y];
+            }
         }
-        if (s_tn[i] == 0) sG[part * BM + s_tm[i] * 32 + l31] = g3a[i];
+        if (gn == 0) {
+#pragma unroll
+            for (int x = 0; x < AM; ++x) sG[part * BM + ao[x]] = g3a[x];
+        }
     }
     __syncthreads();
     if (ty == 0) {
@@ -924,6 +956,7 @@ static WgradPlan wgrad_plan(long rows, int cin, int cout, bool generic = false) 
     const int mt = (cin + 31) / 32, nt = (cout + 31) / 32;
     p.nrow = (mt + 3) / 4; p.ncol = (nt + 3) / 4;
     p.MTs = (mt + p.nrow - 1) / p.nrow;
+    if (!generic && p.MTs >= 3) p.ncol = (nt + 1) / 2;      // at most 8 tiles (128 accumulator registers with Gx) per workgroup
     p.NTs = (nt + p.ncol - 1) / p.ncol;
     if (p.NTs == 3) p.NTs = 4;                              // BN in {32, 64, 128}
     // rows staged per iteration (streaming kernel): one stage is 14-24 KB of LDS, two stages per workgroup, 3 workgroups per CU
@@ -1115,8 +1148,8 @@ extern "C" int gspn_mlp_bwd_wgrad(long rows, int cin, int cout, const gspn_dy_ar
         }
         WS_TRY(1, 1, 64) WS_TRY(1, 2, 32) WS_TRY(1, 4, 16)
         WS_TRY(2, 1, 32) WS_TRY(2, 2, 32) WS_TRY(2, 4, 16)
-        WS_TRY(3, 1, 32) WS_TRY(3, 2, 16) WS_TRY(3, 4, 16)
-        WS_TRY(4, 1, 32) WS_TRY(4, 2, 16) WS_TRY(4, 4, 16)
+        WS_TRY(3, 1, 32) WS_TRY(3, 2, 16)
+        WS_TRY(4, 1, 32) WS_TRY(4, 2, 16)
 #undef WS_TRY
 #undef WS_GO
 #undef WS_ARGS
