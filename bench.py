@@ -89,7 +89,7 @@ def main():
         if state["bucket"] is None:
             params = store.parameters()
             state["bucket"] = parallel.FlatGradBucket(params)
-            state["opt"] = torch.optim.Adam(params, lr=1e-3, foreach=True)
+            state["opt"] = torch.optim.Adam(params, lr=1e-3, fused=True)     # one multi-tensor kernel for the whole update
         state["bucket"].flatten()
         return loss
 

@@ -21,6 +21,7 @@
 // B[k=l>>5][j=l&31];  C/D: 16 registers, reg r -> row (r&3)+8*(r>>2)+4*(l>>5), col l&31.
 #include "common.h"
 #include <type_traits>
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -297,6 +298,176 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(long rows, int cin, int co
     }
 }
 
+__device__ __forceinline__ void glds16(const float* g, float* l) {        // 64 lanes x 16 B -> 1 KiB of LDS at l (wave-uniform)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+// ---- forward, streaming variant (16-byte aligned rows, cin small enough for W + two row tiles to sit in LDS) ----
+// Raw X row tiles go HBM -> LDS directly (global_load_lds_dwordx4), double buffered, one barrier per row tile; W is resident in LDS for
+// the whole (persistent) workgroup.  The tile is row-major as in memory -- no transposition pass: lane (i, kh) of an MFMA reads its A
+// operand as ONE ds_read_b64 per two k-steps (k is assigned 4j+2kh+e, e = step parity; B is pre-arranged in LDS to match), BN+ReLU of
+// the previous layer is applied on that read with (scale, shift) pairs from LDS.  Quads of a row are XOR-swizzled by the row index on
+// the SOURCE side of the LDS-DMA (the LDS image itself must stay lane-linear), which spreads the 32 rows of an operand read over banks.
+// Waves: TRG row groups of 32 rows x (4/TRG) column groups.
+__device__ __forceinline__ int fwd_swz_key(int row, int qx) {            // qx a power of two >= 2, else no swizzle
+    if (qx & (qx - 1)) return 0;
+    return qx >= 16 ? (row & (qx - 1)) : ((row * qx) >> 4) & (qx - 1);
+}
+template <int BN, int TRG>
+__global__ __launch_bounds__(256) void mlp_fwd_stream_kernel(int rows, int cin, int cout, const float* __restrict__ X, int ldx,
+                                                             const float* __restrict__ in_scale, const float* __restrict__ in_shift,
+                                                             const float* __restrict__ W, const float* __restrict__ bias,
+                                                             float* __restrict__ Y, int ldy, float* __restrict__ stats, int nparts) {
+    constexpr int NT = BN / 32, CG = 4 / TRG, NTW = NT / CG, TR = 32 * TRG;
+    static_assert(NT % CG == 0 && NTW >= 1, "column groups tile the block");
+    constexpr int JPMAX = 8;                              // 1-KiB pieces per wave per row tile (TR * QX / 64 / 4 <= 8 by the launcher's LDS check)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int QX = (cin + 3) >> 2, KP = QX * 4;
+    float* sSS = smem;                                    // [KP][2]  (scale, shift) of the input channels
+    float* sW = sSS + KP * 2;                             // [QX][2][BN][2]  W[4j+2kh+e][n]
+    float* sXb = sW + KP * BN;                            // 2 x [TR][QX quads], quads swizzled
+    __shared__ float sRed[2 * TRG * BN];
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int rg = wave % TRG, cg = wave / TRG;
+    const int n0 = blockIdx.y * BN;
+    const float lo = in_scale ? 0.f : -__builtin_inff();
+    for (int k = t; k < KP; k += 256) {
+        sSS[2 * k] = (in_scale && k < cin) ? in_scale[k] : 1.f;
+        sSS[2 * k + 1] = (in_scale && k < cin) ? in_shift[k] : 0.f;
+    }
+    for (int f = t; f < KP * BN; f += 256) {
+        const int k = f / BN, n = f - k * BN;
+        const float w = (k < cin && n0 + n < cout) ? W[(size_t)k * cout + n0 + n] : 0.f;
+        const int j = k >> 2, h = (k >> 1) & 1, e = k & 1;
+        sW[(((j * 2 + h) * BN) + n) * 2 + e] = w;
+    }
+    const int ntiles = (rows + TR - 1) / TR;
+    const int npiece = TR * QX / 64;                       // whole pieces: TR is a multiple of 64 or QX is even (launcher)
+    int p_row[JPMAX], p_col[JPMAX];
+#pragma unroll
+    for (int j = 0; j < JPMAX; ++j) {
+        const int f = (wave + 4 * j) * 64 + lane;
+        const int row = f / QX, slot = f - row * QX;
+        p_row[j] = row;
+        p_col[j] = min((slot ^ fwd_swz_key(row, QX)) * 4, ldx - 4);
+    }
+    auto issue = [&](int tile, int buf) {
+        float* dst = sXb + buf * (TR * KP);
+        const int r0 = tile * TR;
+#pragma unroll
+        for (int j = 0; j < JPMAX; ++j)
+            if (wave + 4 * j < npiece)
+                glds16(X + ((size_t)min(r0 + p_row[j], rows - 1) * ldx + p_col[j]), dst + (wave + 4 * j) * 256);
+    };
+    float bv[NTW], csum[NTW], csq[NTW];
+#pragma unroll
+    for (int y = 0; y < NTW; ++y) {
+        const int col = n0 + (cg * NTW + y) * 32 + l31;
+        bv[y] = (bias && col < cout) ? bias[col] : 0.f;
+        csum[y] = csq[y] = 0.f;
+    }
+    const int arow = rg * 32 + l31;                         // this lane's row inside the tile (A operand)
+    const int akey = fwd_swz_key(arow, QX);
+    // epilogue of a finished tile: + bias, store, column statistics
+    auto epilogue = [&](int tile, const f32x16 (&acc)[NTW]) {
+        const int m0 = tile * TR + rg * 32;
+        const bool full = tile * TR + TR <= rows;           // uniform: full tiles store without per-row guards
+#pragma unroll
+        for (int y = 0; y < NTW; ++y) {
+            const int col = n0 + (cg * NTW + y) * 32 + l31;
+            if (col < cout) {
+                float* yp = Y + (size_t)(m0 + 4 * kh) * ldy + col;
+                if (full) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = acc[y][r] + bv[y];
+                        yp[(size_t)((r & 3) + 8 * (r >> 2)) * ldy] = v;
+                        csum[y] += v;
+                        csq[y] += v * v;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = m0 + c_row(r, lane);
+                        if (row < rows) {
+                            const float v = acc[y][r] + bv[y];
+                            Y[(size_t)row * ldy + col] = v;
+                            csum[y] += v;
+                            csq[y] += v * v;
+                        }
+                    }
+                }
+            }
+        }
+    };
+    f32x16 acc[NTW], pacc[NTW];
+    int it = 0, ptile = -1;
+    if ((int)blockIdx.x < ntiles) issue(blockIdx.x, 0);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                    // tile `it` has landed (and W / constants are visible the first time)
+        if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x, (it + 1) & 1);
+        // the previous tile's stores go out here, a whole compute phase before the next vmcnt(0): their latency is never waited on
+        if (ptile >= 0) epilogue(ptile, pacc);
+        const float* sx = sXb + (it & 1) * (TR * KP) + arow * KP;
+#pragma unroll
+        for (int y = 0; y < NTW; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[y][r] = 0.f;
+        auto kstep = [&](int j) {                           // 4 k's: operands of two MFMA steps per tile
+            const float2 a2 = *reinterpret_cast<const float2*>(sx + ((j ^ akey) << 2) + kh * 2);
+            const float4 ss = *reinterpret_cast<const float4*>(sSS + (4 * j + 2 * kh) * 2);
+            float2 b2[NTW];
+#pragma unroll
+            for (int y = 0; y < NTW; ++y)
+                b2[y] = *reinterpret_cast<const float2*>(sW + (((j * 2 + kh) * BN) + (cg * NTW + y) * 32 + l31) * 2);
+            const float a0 = __builtin_fmaxf(a2.x * ss.x + ss.y, lo);
+            const float a1 = __builtin_fmaxf(a2.y * ss.z + ss.w, lo);
+#pragma unroll
+            for (int y = 0; y < NTW; ++y) acc[y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b2[y].x, acc[y], 0, 0, 0);
+#pragma unroll
+            for (int y = 0; y < NTW; ++y) acc[y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b2[y].y, acc[y], 0, 0, 0);
+        };
+        int j = 0;
+        for (; j + 3 < QX; j += 4) { kstep(j); kstep(j + 1); kstep(j + 2); kstep(j + 3); }   // (hipcc will not partially unroll a loop of MFMAs itself)
+        for (; j < QX; ++j) kstep(j);
+#pragma unroll
+        for (int y = 0; y < NTW; ++y) pacc[y] = acc[y];
+        ptile = tile;
+    }
+    if (ptile >= 0) epilogue(ptile, pacc);
+    if (stats) {
+        __syncthreads();
+#pragma unroll
+        for (int y = 0; y < NTW; ++y) {
+            csum[y] += __shfl_xor(csum[y], 32, 64);
+            csq[y] += __shfl_xor(csq[y], 32, 64);
+            if (lane < 32) {
+                sRed[(rg * 2 + 0) * BN + (cg * NTW + y) * 32 + lane] = csum[y];
+                sRed[(rg * 2 + 1) * BN + (cg * NTW + y) * 32 + lane] = csq[y];
+            }
+        }
+        __syncthreads();
+        // per-block partial sums stats[part][2][cout]; parts this launch does not produce are zero-filled by workgroup 0
+        float* ws = stats + (size_t)blockIdx.x * 2 * cout;
+        for (int j = t; j < BN; j += 256) {
+            const int col = n0 + j;
+            if (col < cout) {
+                float sm = 0.f, q = 0.f;
+                for (int w = 0; w < TRG; ++w) { sm += sRed[(w * 2 + 0) * BN + j]; q += sRed[(w * 2 + 1) * BN + j]; }
+                ws[col] = sm;
+                ws[cout + col] = q;
+            }
+        }
+        if (blockIdx.x == 0)
+            for (long f = (long)gridDim.x * 2 * cout + t; f < (long)nparts * 2 * cout; f += 256) {
+                const int col = (int)(f % cout);
+                if (col >= n0 && col < n0 + BN) stats[f] = 0.f;
+            }
+    }
+}
+
 static inline unsigned row_grid(long rows, int ytiles, int per_cu) {
     const long ntiles = (rows + TM - 1) / TM;
     long cap = 256L * per_cu / (ytiles > 0 ? ytiles : 1);
@@ -318,6 +489,50 @@ extern "C" int gspn_mlp_fwd(long rows, int cin, int cout, const float* X, int ld
     if (cin > MAXCH || cout > MAXCH) return GSPN_ERR_UNSUPPORTED;
     if (rows == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
+    {
+        // streaming kernel: needs 16-byte rows, 32-bit offsets and W + two row tiles within 80 KB of LDS (>= 2 workgroups per CU)
+        const int BNs = cout <= 32 ? 32 : (cout <= 64 ? 64 : 128);
+        const int yt = (cout + BNs - 1) / BNs;
+        const int QX = (cin + 3) / 4;
+        const long lds4 = 16L * QX * (BNs + 64 * 4), lds2 = 16L * QX * (BNs + 64 * 2);      // bytes with TRG = 4 / 2 (+ 8*KP for the constants)
+        int trg = 0;
+        if (lds4 + 32L * QX <= 53 * 1024) trg = 4;
+        else if (BNs >= 64 && lds2 + 32L * QX <= 80 * 1024) trg = 2;
+        if (trg && (32 * trg * QX) % 64 != 0) trg = 0;
+        if (trg && 32 * trg * QX / 64 > 32) trg = 0;                                      // <= 8 pieces per wave
+        if (trg && vec_ok(X, ldx) && ldx >= 4 && rows < (1L << 31) && rows * (long)ldx < (1L << 31) && rows * (long)ldy < (1L << 31) &&
+            getenv("GSPN_FWD_NO_STREAM") == nullptr) {
+            const size_t dyn = (size_t)(trg == 4 ? lds4 : lds2) + 32u * QX;
+            const long ntiles = (rows + 32 * trg - 1) / (32 * trg);
+            long bpc = (160L * 1024) / (long)(dyn + 2 * trg * BNs * 4 + 512);
+            if (bpc > 4) bpc = 4;
+            if (bpc < 1) bpc = 1;
+            const unsigned nparts = fwd_blocks(rows, cout);
+            long gx = 256L * bpc / yt;
+            if (gx > ntiles) gx = ntiles;
+            if (gx > (long)nparts) gx = nparts;
+            if (gx < 1) gx = 1;
+#define FWDS_GO(BN_, TRG_)                                                                                                             \
+            do {                                                                                                                       \
+                static bool attr_done = false;                                                                                         \
+                if (!attr_done) {                                                                                                      \
+                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_stream_kernel<BN_, TRG_>),               \
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                         \
+                    if (e != hipSuccess) return (int)e;                                                                                \
+                    attr_done = true;                                                                                                  \
+                }                                                                                                                      \
+                hipLaunchKernelGGL((mlp_fwd_stream_kernel<BN_, TRG_>), dim3((unsigned)gx, yt), dim3(256), dyn, st, (int)rows, cin, cout, X, ldx, \
+                                   in_scale, in_shift, W, bias, Y, ldy, stats, (int)nparts);                                           \
+                return gspn_launch_status();                                                                                           \
+            } while (0)
+            if (BNs == 32 && trg == 4) FWDS_GO(32, 4);
+            if (BNs == 64 && trg == 4) FWDS_GO(64, 4);
+            if (BNs == 64 && trg == 2) FWDS_GO(64, 2);
+            if (BNs == 128 && trg == 4) FWDS_GO(128, 4);
+            if (BNs == 128 && trg == 2) FWDS_GO(128, 2);
+#undef FWDS_GO
+        }
+    }
     const bool v = vec_ok(X, ldx) && vec_ok(W, cout);
 #define FWD_LAUNCH(BN_, V_, YT_)                                                                                                   \
     hipLaunchKernelGGL((mlp_fwd_kernel<BN_, V_>), dim3(row_grid(rows, YT_, 4), YT_), dim3(256), 0, st, rows, cin, cout, X, ldx, \
@@ -338,20 +553,24 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
     for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s, 64);
     return v;
 }
-// one WAVE per channel: 64 lanes stride over the forward's per-block partials (double accumulation), then finalise
+// one WORKGROUP per channel: 256 threads stride over the forward's per-block partials (double accumulation), then finalise
 __global__ __launch_bounds__(256) void bn_finalize_kernel(long rows, int c, const float* __restrict__ stats, int nparts, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float eps, float decay, int is_training,
                                                           float* __restrict__ moving_mean, float* __restrict__ moving_var,
                                                           float* __restrict__ mean, float* __restrict__ var, float* __restrict__ scale, float* __restrict__ shift) {
-    const int lane = threadIdx.x & 63;
-    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (j >= c) return;
+    __shared__ double sh2[2][4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int j = blockIdx.x;
     double mu, v;
     if (is_training) {
         double a0 = 0.0, a1 = 0.0;
-        for (int p = lane; p < nparts; p += 64) { a0 += (double)stats[(size_t)p * 2 * c + j]; a1 += (double)stats[(size_t)p * 2 * c + c + j]; }
+        for (int p = threadIdx.x; p < nparts; p += 256) { a0 += (double)stats[(size_t)p * 2 * c + j]; a1 += (double)stats[(size_t)p * 2 * c + c + j]; }
         a0 = wave_sum_f64(a0);
         a1 = wave_sum_f64(a1);
+        if (lane == 0) { sh2[0][wv] = a0; sh2[1][wv] = a1; }
+        __syncthreads();
+        a0 = (sh2[0][0] + sh2[0][1]) + (sh2[0][2] + sh2[0][3]);
+        a1 = (sh2[1][0] + sh2[1][1]) + (sh2[1][2] + sh2[1][3]);
         mu = a0 / (double)rows;
         v = a1 / (double)rows - mu * mu;                   // biased variance (tf.nn.moments)
         if (v < 0.0) v = 0.0;
@@ -359,7 +578,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(long rows, int c, cons
         mu = moving_mean[j];
         v = moving_var[j];
     }
-    if (lane != 0) return;
+    if (threadIdx.x != 0) return;
     if (is_training) {
         if (moving_mean) moving_mean[j] = (float)((double)moving_mean[j] * decay + mu * (1.0 - (double)decay));
         if (moving_var) moving_var[j] = (float)((double)moving_var[j] * decay + v * (1.0 - (double)decay));
@@ -378,7 +597,7 @@ extern "C" int gspn_bn_finalize(long rows, int c, const float* stats, const floa
     if (rows <= 0 || c <= 0 || !mean || !var || !scale || !shift) return GSPN_ERR_ARG;
     if (is_training && !stats) return GSPN_ERR_ARG;
     if (!is_training && (!moving_mean || !moving_var)) return GSPN_ERR_ARG;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, (hipStream_t)stream, rows, c, stats, (int)fwd_blocks(rows, c), gamma, beta,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(c), dim3(256), 0, (hipStream_t)stream, rows, c, stats, (int)fwd_blocks(rows, c), gamma, beta,
                        eps, decay, is_training, moving_mean, moving_var, mean, var, scale, shift);
     return gspn_launch_status();
 }
@@ -639,9 +858,6 @@ __global__ __launch_bounds__(256) void mlp_bwd_wgrad_kernel(long rows, int cin, 
 // LDS image of one stage: [A: TKW x BM][Y: TKW x BN][dZ: TKW x BN (dense only)], linear (a wave-load writes 1 KiB contiguous).
 // A max-pooled upstream gradient (POOLED) is never expanded: per stage a lane fetches the arg-max offset and the pooled
 // gradient of its column for the <= NGMAX pool groups the stage covers, and dz = (arg == row % ns) ? dPool : 0.
-__device__ __forceinline__ void glds16(const float* g, float* l) {        // 64 lanes x 16 B -> 1 KiB of LDS at l (wave-uniform)
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
-}
 // Work split inside a workgroup: the T = MT*NTT tiles and WK k-parts are dealt to the 4 waves as a (GM x GN) grid of wave groups
 // times WK k-parts (GM*GN*WK == 4).  Wave (gm, gn, kp) owns the AM x BNW block of tiles {tm = gm + GM*a} x {tn = gn + GN*b} over
 // the rows of k-part kp: one k-loop with all its accumulators live, A operands shared along b and B operands along a.
@@ -871,9 +1087,43 @@ __global__ __launch_bounds__(256, ((WgradSplit<MT, NTT>::AM * WgradSplit<MT, NTT
         else compute(std::true_type{});
     }
     // ---- epilogue: this chunk's partial tiles / sums ----
-    // shared == 0: every (chunk, k-part) owns a partial-tile slot -> plain stores; else chunks share zero-filled slots (fp32 atomics)
-    {
-        const int slot = shared ? chunk % nslots : chunk * WK + kp;
+    // k-parts > 0 hand their accumulators to part 0 through LDS (fixed order), so ONE partial tile per chunk leaves the CU.
+    if constexpr (WK > 1) {
+        constexpr int TILEF = 16 * 64;                                    // floats of one 32x32 accumulator tile, [reg][lane]
+        static_assert((WK - 1) * SP::G * BNW * TILEF <= 2 * SF, "k-part exchange fits the stage buffers");
+#pragma unroll
+        for (int which = 0; which < (WANT_GX ? 2 : 1); ++which) {
+#pragma unroll
+            for (int x = 0; x < AM; ++x) {                                // one row of tiles per round (bounds the scratch)
+                __syncthreads();
+                if (kp > 0) {
+#pragma unroll
+                    for (int y = 0; y < BNW; ++y) {
+                        float* dst = sbuf + (size_t)(((kp - 1) * SP::G + grp) * BNW + y) * TILEF;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) dst[r * 64 + lane] = which ? accx[WANT_GX ? x : 0][WANT_GX ? y : 0][r] : acc1[x][y][r];
+                    }
+                }
+                __syncthreads();
+                if (kp == 0) {
+#pragma unroll
+                    for (int q = 1; q < WK; ++q)
+#pragma unroll
+                        for (int y = 0; y < BNW; ++y) {
+                            const float* src = sbuf + (size_t)(((q - 1) * SP::G + grp) * BNW + y) * TILEF;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                if (which) accx[WANT_GX ? x : 0][WANT_GX ? y : 0][r] += src[r * 64 + lane];
+                                else acc1[x][y][r] += src[r * 64 + lane];
+                            }
+                        }
+                }
+            }
+        }
+    }
+    // shared == 0: every chunk owns a partial-tile slot -> plain stores; else chunks share zero-filled slots (fp32 atomics)
+    if (kp == 0) {
+        const int slot = shared ? chunk % nslots : chunk;
         float* P1 = PP + (size_t)slot * 2 * cin * cout;
         float* Px = P1 + (size_t)cin * cout;
 #pragma unroll
@@ -948,7 +1198,7 @@ __global__ __launch_bounds__(256, ((WgradSplit<MT, NTT>::AM * WgradSplit<MT, NTT
 // Plan: tile shape per workgroup, rows per chunk, number of partial-tile slots.
 //   * chunks: ~3 workgroups per CU when the layer is long enough, but a chunk always reads at least ~2x the bytes of the partial
 //     tile it writes (rpc_min), as long as that still leaves one workgroup per CU;
-//   * slots: when nch * WK partial tiles fit in 64 MB every (chunk, k-part) owns a slot and the main kernel uses plain stores
+//   * slots: when nch partial tiles fit in 64 MB every chunk owns a slot and the main kernel uses plain stores
 //     (shared == 0: no zero fill, no atomics); otherwise chunks share `nslots` zero-filled slots through fp32 atomics.
 struct WgradPlan { int MTs, NTs, nrow, ncol, TKW, WK, shared; long rpc, nch, nslots; };
 static WgradPlan wgrad_plan(long rows, int cin, int cout, bool generic = false) {
@@ -981,7 +1231,7 @@ static WgradPlan wgrad_plan(long rows, int cin, int cout, bool generic = false) 
     p.nch = (rows + p.rpc - 1) / p.rpc;
     if (p.nch < 1) p.nch = 1;
     const long tile_bytes = 8L * cin * cout;
-    if (!generic && p.nch * p.WK * tile_bytes <= (64L << 20)) { p.shared = 0; p.nslots = p.nch * p.WK; }
+    if (!generic && p.nch * tile_bytes <= (64L << 20)) { p.shared = 0; p.nslots = p.nch; }
     else {
         long cap = (12L << 20) / tile_bytes;
         if (cap < 8) cap = 8;
@@ -1049,50 +1299,52 @@ __global__ __launch_bounds__(256) void wgrad_small_reduce_kernel(long rows, int 
     if (dbias) dbias[n] = (float)(tr ? 0.0 : A * r0);      // sum(dY): exactly 0 under batch statistics
 }
 // dW[m][n] = cA[n] * (sum_slots G1 - r0/R * g3[m] - r1/R * sum_slots Gx)
-// block 1024 = 16 consecutive outputs x 64 interleaved slot slices: cin*cout/16 workgroups of 16 waves keep the whole chip streaming the
-// partial tiles (64-byte segments, 8 loads in flight per thread); double accumulation, fixed summation order.
+// block 1024 = 16 consecutive outputs x 64 interleaved slot slices (a wave = 16 outputs x 4 slices: 64-byte segments): cin*cout/16
+// workgroups of 16 waves keep the whole chip streaming the partial tiles, up to 16 (+16) loads in flight per thread; the 64 slices are
+// summed in double, in a fixed order: 4 by lane shuffles, 16 through one LDS hop.
 #define DW_OX 16
 #define DW_SL 64
+#define DW_UN 8
 __global__ __launch_bounds__(1024) void wgrad_dw_kernel(long rows, int cin, int cout, int nslots, const float* __restrict__ PP, const double* __restrict__ red,
                                                         const float* __restrict__ g3, const float* __restrict__ var, const float* __restrict__ gamma, float eps,
                                                         int use_bn, int is_training, float* __restrict__ dW) {
-    __shared__ double s1[DW_SL][DW_OX + 1], sx[DW_SL][DW_OX + 1];
+    __shared__ double s1[16][DW_OX], sx[16][DW_OX];
     const long total = (long)cin * cout;
     const double R = (double)rows;
     const bool tr = use_bn && is_training;
-    const int ox = threadIdx.x % DW_OX, sl = threadIdx.x / DW_OX;
+    const int ox = threadIdx.x % DW_OX, sl = threadIdx.x / DW_OX, wave = threadIdx.x >> 6;
     const long i = blockIdx.x * (long)DW_OX + ox;
+    const long ic = i < total ? i : total - 1;                   // clamped: every lane takes part in the shuffles
     double w1 = 0.0, wx = 0.0;
-    if (i < total) {
-        const float* p1 = PP + i;
+    {
+        const float* p1 = PP + ic;
         const size_t st = 2 * (size_t)total;
-        int p = sl;
-        for (; p + 3 * DW_SL < nslots; p += 4 * DW_SL) {
-            const float v0 = p1[(size_t)p * st], v1 = p1[(size_t)(p + DW_SL) * st], v2 = p1[(size_t)(p + 2 * DW_SL) * st], v3 = p1[(size_t)(p + 3 * DW_SL) * st];
-            float u0 = 0.f, u1 = 0.f, u2 = 0.f, u3 = 0.f;
-            if (tr) {
-                u0 = p1[(size_t)p * st + total]; u1 = p1[(size_t)(p + DW_SL) * st + total];
-                u2 = p1[(size_t)(p + 2 * DW_SL) * st + total]; u3 = p1[(size_t)(p + 3 * DW_SL) * st + total];
+        const int last = nslots - 1;
+        for (int p = sl; p < nslots; p += DW_UN * DW_SL) {
+            float v[DW_UN], u[DW_UN];
+#pragma unroll
+            for (int q = 0; q < DW_UN; ++q) {                    // clamped slot index: unconditional loads, masked below
+                const int pq = min(p + q * DW_SL, last);
+                v[q] = p1[(size_t)pq * st];
+                u[q] = tr ? p1[(size_t)pq * st + total] : 0.f;
             }
-            w1 += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
-            wx += ((double)u0 + (double)u1) + ((double)u2 + (double)u3);
-        }
-        for (; p < nslots; p += DW_SL) {
-            w1 += (double)p1[(size_t)p * st];
-            if (tr) wx += (double)p1[(size_t)p * st + total];
+#pragma unroll
+            for (int q = 0; q < DW_UN; ++q) {
+                const bool ok = p + q * DW_SL < nslots;
+                w1 += ok ? (double)v[q] : 0.0;
+                wx += ok ? (double)u[q] : 0.0;
+            }
         }
     }
-    s1[sl][ox] = w1;
-    sx[sl][ox] = wx;
+    // lanes l, l^16, l^32, l^48 hold the 4 slices of one output
+    w1 += __shfl_xor(w1, 16, 64); wx += __shfl_xor(wx, 16, 64);
+    w1 += __shfl_xor(w1, 32, 64); wx += __shfl_xor(wx, 32, 64);
+    if ((threadIdx.x & 63) < DW_OX) { s1[wave][ox] = w1; sx[wave][ox] = wx; }
     __syncthreads();
-    // 64 slices -> 1: four rounds of pairwise adds (fixed tree)
-    for (int h = DW_SL / 2; h >= 1; h >>= 1) {
-        if (sl < h) { s1[sl][ox] += s1[sl + h][ox]; sx[sl][ox] += sx[sl + h][ox]; }
-        __syncthreads();
-    }
-    if (sl != 0 || i >= total) return;
-    w1 = s1[0][ox];
-    wx = sx[0][ox];
+    if (threadIdx.x >= DW_OX || i >= total) return;
+    w1 = 0.0; wx = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { w1 += s1[q][ox]; wx += sx[q][ox]; }
     const int n = (int)(i % cout), m = (int)(i / cout);
     double A = 1.0;
     if (use_bn) A = (gamma ? (double)gamma[n] : 1.0) / sqrt((double)var[n] + (double)eps);
