@@ -43,6 +43,8 @@ SIGNATURES = {
     "gspn_threenn": [_I, _I, _I, _P, _P, _P, _P, _P],
     "gspn_threeinterpolate": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
     "gspn_threeinterpolate_grad": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
+    "gspn_fp_concat": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P],
+    "gspn_fp_concat_grad": [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "gspn_nmdistance": [_I, _I, _P, _I, _P, _P, _P, _P, _P, _P],
     "gspn_nmdistance_grad": [_I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P],
     "gspn_sa_group_concat": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P],
@@ -52,6 +54,7 @@ SIGNATURES = {
     "gspn_bnrelu_maxpool": [_L, _I, _I, _P, _I, _P, _P, _P, _P, _P],
     "gspn_bnrelu_apply": [_L, _I, _P, _I, _P, _P, _P, _I, _P],
     "gspn_mlp_bwd_wgrad": [_L, _I, _I, _c.POINTER(DyArgs), _P, _I, _P, _P, _P, _P, _P, _F, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "gspn_mlp_bwd_dw": [_L, _I, _I, _c.POINTER(DyArgs), _P, _I, _P, _P, _F, _I, _I, _P, _P, _P],
     "gspn_mlp_bwd_data": [_L, _I, _I, _c.POINTER(DyArgs), _P, _P, _I, _P],
     "gspn_fill_zero": [_P, _L, _P],
 }

@@ -77,6 +77,13 @@ static inline int gspn_launch_status() {
     return e == hipSuccess ? 0 : (int)e;
 }
 
+// CUs the persistent / statically partitioned kernels plan for.  MI355X has 256; the schedule this library is built around keeps
+// up to 16 of them busy with farthest point sampling of the NEXT batches on side streams (one CU per scene, geometry.py), and a grid
+// sized for exactly 256 CUs would then run its last workgroups as a second wave (measured: +12 % on the layers for 3 % of the CUs).
+#ifndef GSPN_PLAN_CUS
+#define GSPN_PLAN_CUS 240
+#endif
+
 // grid for a grid-stride kernel over `total` items: enough blocks to fill 256 CUs several times
 // over, capped so very large problems loop instead of launching millions of tiny blocks
 static inline unsigned grid_for(long total, int block) {

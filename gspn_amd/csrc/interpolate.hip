@@ -120,3 +120,77 @@ extern "C" int gspn_threeinterpolate_grad(int b, int n, int c, int m, const floa
     hipLaunchKernelGGL(three_interpolate_grad_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, total, n, c, m, grad_out, idx, weight, grad_points);
     return gspn_launch_status();
 }
+
+// ============================================================================================
+// fp_concat: the input matrix of a feature-propagation MLP in one pass (pointnet_util.py:161-166):
+//   out[row, 0:c2]      = three_interpolate(points2, idx, weight)[row]        ((p1*w1 + p2*w2) + p3*w3, as above)
+//   out[row, c2:c2+c1]  = points1[row]
+//   out[row, c2+c1:ld]  = 0                                                   (row pitch padded to 16 bytes for the MLP)
+// replacing interpolate + tf.concat + pad (three full passes over the (b*n1, c) matrix).  One thread per output element.
+// ============================================================================================
+__global__ void fp_concat_kernel(long total, int n, int m, int c2, int c1, int ld, const float* __restrict__ points2, const int* __restrict__ idx,
+                                 const float* __restrict__ weight, const float* __restrict__ points1, float* __restrict__ out) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long row = i / ld;                // b*n + j
+        const int l = (int)(i - row * ld);
+        float v = 0.f;
+        if (l < c2) {
+            const long bi = row / n;
+            const int* ii = idx + row * 3;
+            const float* w = weight + row * 3;
+            const float* P = points2 + (size_t)bi * m * c2 + l;
+            const float a = P[(size_t)ii[0] * c2] * w[0];
+            const float bb = P[(size_t)ii[1] * c2] * w[1];
+            const float cc = P[(size_t)ii[2] * c2] * w[2];
+            v = (a + bb) + cc;
+        } else if (l < c2 + c1) {
+            v = points1[row * c1 + (l - c2)];
+        }
+        out[i] = v;
+    }
+}
+// gradient: grad_points2[i_t, l] += g[row, l] * w_t (hardware atomics, like three_interpolate_grad), grad_points1[row, l] = g[row, c2 + l]
+__global__ void fp_concat_grad_kernel(long total, int n, int m, int c2, int c1, int ld, const float* __restrict__ g, const int* __restrict__ idx,
+                                      const float* __restrict__ weight, float* __restrict__ grad_points2, float* __restrict__ grad_points1) {
+    const int cc = c2 + c1;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long row = i / cc;
+        const int l = (int)(i - row * cc);
+        const float gv = g[row * ld + l];
+        if (l < c2) {
+            if (grad_points2) {
+                const long bi = row / n;
+                const int* ii = idx + row * 3;
+                const float* w = weight + row * 3;
+                float* G = grad_points2 + (size_t)bi * m * c2 + l;
+                atomicAdd(G + (size_t)ii[0] * c2, gv * w[0]);
+                atomicAdd(G + (size_t)ii[1] * c2, gv * w[1]);
+                atomicAdd(G + (size_t)ii[2] * c2, gv * w[2]);
+            }
+        } else if (grad_points1) {
+            grad_points1[row * c1 + (l - c2)] = gv;
+        }
+    }
+}
+extern "C" int gspn_fp_concat(int b, int n, int m, int c2, int c1, const float* points2, const int* idx, const float* weight,
+                              const float* points1, int ld, float* out, void* stream) {
+    if (b < 0 || n < 0 || m <= 0 || c2 <= 0 || c1 < 0 || ld < c2 + c1 || (c1 > 0 && !points1)) return GSPN_ERR_ARG;
+    const long total = (long)b * n * ld;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(fp_concat_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, total, n, m, c2, c1, ld, points2, idx, weight, points1, out);
+    return gspn_launch_status();
+}
+extern "C" int gspn_fp_concat_grad(int b, int n, int m, int c2, int c1, int ld, const float* grad_out, const int* idx, const float* weight,
+                                   float* grad_points2, float* grad_points1, void* stream) {
+    if (b < 0 || n < 0 || m <= 0 || c2 <= 0 || c1 < 0 || ld < c2 + c1) return GSPN_ERR_ARG;
+    if (b == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (grad_points2) {
+        hipError_t e = hipMemsetAsync(grad_points2, 0, sizeof(float) * (size_t)b * m * c2, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    const long total = (long)b * n * (c2 + c1);
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(fp_concat_grad_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, total, n, m, c2, c1, ld, grad_out, idx, weight, grad_points2, grad_points1);
+    return gspn_launch_status();
+}

@@ -449,7 +449,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_stream_kernel(int rows, int cin, 
             }
         }
         __syncthreads();
-        // per-block partial sums stats[part][2][cout]; parts this launch does not produce are zero-filled by workgroup 0
+        // per-block partial sums stats[part][2][cout]; parts this launch does not produce are zero-filled
         float* ws = stats + (size_t)blockIdx.x * 2 * cout;
         for (int j = t; j < BN; j += 256) {
             const int col = n0 + j;
@@ -460,17 +460,17 @@ __global__ __launch_bounds__(256) void mlp_fwd_stream_kernel(int rows, int cin, 
                 ws[cout + col] = q;
             }
         }
-        if (blockIdx.x == 0)
-            for (long f = (long)gridDim.x * 2 * cout + t; f < (long)nparts * 2 * cout; f += 256) {
-                const int col = (int)(f % cout);
-                if (col >= n0 && col < n0 + BN) stats[f] = 0.f;
-            }
+        // (spread over all workgroups: a single one would serialise ~500 stores per thread at the tail of the launch)
+        for (long f = (long)gridDim.x * 2 * cout + (long)blockIdx.x * 256 + t; f < (long)nparts * 2 * cout; f += (long)gridDim.x * 256) {
+            const int col = (int)(f % cout);
+            if (col >= n0 && col < n0 + BN) stats[f] = 0.f;
+        }
     }
 }
 
 static inline unsigned row_grid(long rows, int ytiles, int per_cu) {
     const long ntiles = (rows + TM - 1) / TM;
-    long cap = 256L * per_cu / (ytiles > 0 ? ytiles : 1);
+    long cap = (long)GSPN_PLAN_CUS * per_cu / (ytiles > 0 ? ytiles : 1);
     if (cap < 64) cap = 64;
     return (unsigned)(ntiles < cap ? ntiles : cap);
 }
@@ -508,7 +508,7 @@ extern "C" int gspn_mlp_fwd(long rows, int cin, int cout, const float* X, int ld
             if (bpc > 4) bpc = 4;
             if (bpc < 1) bpc = 1;
             const unsigned nparts = fwd_blocks(rows, cout);
-            long gx = 256L * bpc / yt;
+            long gx = (long)GSPN_PLAN_CUS * bpc / yt;
             if (gx > ntiles) gx = ntiles;
             if (gx > (long)nparts) gx = nparts;
             if (gx < 1) gx = 1;
@@ -1219,10 +1219,10 @@ static WgradPlan wgrad_plan(long rows, int cin, int cout, bool generic = false) 
     const long BM = 32L * p.MTs, BN = 32L * p.NTs;
     long rpc_min = 4 * BM * BN / (BM + 2 * BN);            // input bytes of a chunk >= 2 x its partial-tile bytes
     if (rpc_min < 4L * p.TKW) rpc_min = 4L * p.TKW;
-    long chunks = (256L * 3) / ntile;                       // upper target: 3 workgroups per CU
+    long chunks = ((long)GSPN_PLAN_CUS * 3) / ntile;          // upper target: 3 workgroups per CU
     if (chunks < 1) chunks = 1;
     const long by_size = rows / rpc_min;                    // chunks allowed by the size rule
-    long floor_ch = 256 / ntile;                            // but never fewer than one workgroup per CU (if the layer has the rows)
+    long floor_ch = GSPN_PLAN_CUS / ntile;                            // but never fewer than one workgroup per CU (if the layer has the rows)
     if (floor_ch < 1) floor_ch = 1;
     if (chunks > by_size) chunks = by_size > floor_ch ? by_size : floor_ch;
     long rpc = (rows + chunks - 1) / chunks;
@@ -1352,19 +1352,9 @@ __global__ __launch_bounds__(1024) void wgrad_dw_kernel(long rows, int cin, int 
     dW[i] = (float)(A * w1);
 }
 
-extern "C" int gspn_mlp_bwd_wgrad(long rows, int cin, int cout, const gspn_dy_args* a, const float* X, int ldx,
-                                  const float* in_scale, const float* in_shift, const float* mean, const float* var, const float* gamma,
-                                  float eps, int use_bn, int is_training, float* work, float* cA, float* cB, float* cC,
-                                  float* dgamma, float* dbeta, float* dbias, float* dW, void* stream) {
-    if (rows <= 0 || cin <= 0 || cout <= 0 || ldx < cin || !a || !a->Y || !a->scale || !a->shift || !work || !dW) return GSPN_ERR_ARG;
-    if (!a->dZ && !(a->dPool && a->pool_arg && a->ns > 0)) return GSPN_ERR_ARG;
-    if ((in_scale == nullptr) != (in_shift == nullptr)) return GSPN_ERR_ARG;
-    if (use_bn && (!mean || !var)) return GSPN_ERR_ARG;
-    if (cin > MAXCH || cout > MAXCH) return GSPN_ERR_UNSUPPORTED;
-    hipStream_t st = (hipStream_t)stream;
-    if (rows >= (1L << 31)) return GSPN_ERR_UNSUPPORTED;
+// which kernel / plan a (layer, operand alignment) gets: shared by gspn_mlp_bwd_wgrad and gspn_mlp_bwd_dw so both find the same workspace layout
+static WgradPlan wgrad_choose(long rows, int cin, int cout, const gspn_dy_args* a, const float* X, int ldx, bool* use_stream_out) {
     const bool pooled = a->dZ == nullptr;
-    const bool tr = use_bn && is_training;
     // streaming kernel: 16-byte aligned rows, 32-bit in-chunk offsets, pool groups that tile the stage
     bool use_stream = vec_ok(X, ldx) && vec_ok(a->Y, a->ldy) && (pooled || vec_ok(a->dZ, a->ldz)) && ldx >= 4 && cout >= 4;
     WgradPlan p = wgrad_plan(rows, cin, cout, false);
@@ -1374,6 +1364,25 @@ extern "C" int gspn_mlp_bwd_wgrad(long rows, int cin, int cout, const gspn_dy_ar
         if (pooled && !(a->ns >= 16 && a->ns % 2 == 0 && (a->ns % p.TKW == 0 || p.TKW % a->ns == 0) && rows % a->ns == 0)) use_stream = false;
     }
     if (!use_stream) p = wgrad_plan(rows, cin, cout, true);
+    *use_stream_out = use_stream;
+    return p;
+}
+
+extern "C" int gspn_mlp_bwd_wgrad(long rows, int cin, int cout, const gspn_dy_args* a, const float* X, int ldx,
+                                  const float* in_scale, const float* in_shift, const float* mean, const float* var, const float* gamma,
+                                  float eps, int use_bn, int is_training, float* work, float* cA, float* cB, float* cC,
+                                  float* dgamma, float* dbeta, float* dbias, float* dW, void* stream) {
+    if (rows <= 0 || cin <= 0 || cout <= 0 || ldx < cin || !a || !a->Y || !a->scale || !a->shift || !work) return GSPN_ERR_ARG;
+    if (!a->dZ && !(a->dPool && a->pool_arg && a->ns > 0)) return GSPN_ERR_ARG;
+    if ((in_scale == nullptr) != (in_shift == nullptr)) return GSPN_ERR_ARG;
+    if (use_bn && (!mean || !var)) return GSPN_ERR_ARG;
+    if (cin > MAXCH || cout > MAXCH) return GSPN_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    if (rows >= (1L << 31)) return GSPN_ERR_UNSUPPORTED;
+    const bool pooled = a->dZ == nullptr;
+    const bool tr = use_bn && is_training;
+    bool use_stream;
+    const WgradPlan p = wgrad_choose(rows, cin, cout, a, X, ldx, &use_stream);
     char* wb = reinterpret_cast<char*>(work);
     if (reinterpret_cast<uintptr_t>(wb) % 16) return GSPN_ERR_ARG;
     double* red = reinterpret_cast<double*>(wb);
@@ -1419,8 +1428,28 @@ extern "C" int gspn_mlp_bwd_wgrad(long rows, int cin, int cout, const gspn_dy_ar
     const int cmax = cin > cout ? cin : cout;
     hipLaunchKernelGGL(wgrad_small_reduce_kernel, dim3(cmax), dim3(256), 0, st, rows, cin, cout, (int)p.nch, RP, GP, red, g3, mean, var, gamma, eps,
                        use_bn, is_training, cA, cB, cC, dgamma, dbeta, dbias);
-    hipLaunchKernelGGL(wgrad_dw_kernel, dim3((unsigned)(((long)cin * cout + DW_OX - 1) / DW_OX)), dim3(1024), 0, st, rows, cin, cout, (int)p.nslots, PP, red, g3,
-                       var, gamma, eps, use_bn, is_training, dW);
+    if (dW)
+        hipLaunchKernelGGL(wgrad_dw_kernel, dim3((unsigned)(((long)cin * cout + DW_OX - 1) / DW_OX)), dim3(1024), 0, st, rows, cin, cout, (int)p.nslots, PP, red, g3,
+                           var, gamma, eps, use_bn, is_training, dW);
+    return gspn_launch_status();
+}
+
+// The deferred last kernel of pass A: dW from the partial tiles / sums that gspn_mlp_bwd_wgrad(..., dW = NULL, ...) left in `work`.
+// Nothing downstream of the layer needs dW before the optimiser, so a caller may run this on another stream (after the wgrad call,
+// with the same rows/cin/cout/a/X/ldx so that the workspace layout is found again) and let it overlap the next layer's kernels.
+extern "C" int gspn_mlp_bwd_dw(long rows, int cin, int cout, const gspn_dy_args* a, const float* X, int ldx, const float* var, const float* gamma,
+                               float eps, int use_bn, int is_training, const float* work, float* dW, void* stream) {
+    if (rows <= 0 || cin <= 0 || cout <= 0 || ldx < cin || !a || !a->Y || !work || !dW) return GSPN_ERR_ARG;
+    if (use_bn && !var) return GSPN_ERR_ARG;
+    if (cin > MAXCH || cout > MAXCH || rows >= (1L << 31)) return GSPN_ERR_UNSUPPORTED;
+    bool use_stream;
+    const WgradPlan p = wgrad_choose(rows, cin, cout, a, X, ldx, &use_stream);
+    const char* wb = reinterpret_cast<const char*>(work);
+    const double* red = reinterpret_cast<const double*>(wb);
+    const float* g3 = reinterpret_cast<const float*>(wb + ws_off_g3(cout));
+    const float* PP = reinterpret_cast<const float*>(wb + ws_off_pp(p.nch, cin, cout));
+    hipLaunchKernelGGL(wgrad_dw_kernel, dim3((unsigned)(((long)cin * cout + DW_OX - 1) / DW_OX)), dim3(1024), 0, (hipStream_t)stream, rows, cin, cout,
+                       (int)p.nslots, PP, red, g3, var, gamma, eps, use_bn, is_training, dW);
     return gspn_launch_status();
 }
 

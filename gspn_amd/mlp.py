@@ -15,6 +15,21 @@ from . import _lib as L
 
 BN_EPS = 1e-3      # tf.contrib.layers.batch_norm default epsilon (tf_util.py:529-534 passes none)
 
+# The last kernel of a layer's weight-gradient pass (the double-precision sum over partial tiles) has no consumer before the
+# optimiser and cannot fill the chip (latency-bound); DEFER_DW = True puts it on a side stream where it overlaps the next layer's
+# kernels.  Off by default: inside a captured step the fork becomes a multi-branch hipGraph, and ROCm 7.2 replays those far slower
+# than a linear graph (measured on MI355X: 3.9 -> 6.6 ms per step), which costs more than the ~0.2 ms of overlap gains.
+DEFER_DW = False
+_side_streams = {}
+
+
+def _side_stream(dev):
+    key = (dev.type, dev.index)
+    s = _side_streams.get(key)
+    if s is None:
+        s = _side_streams[key] = torch.cuda.Stream(device=dev)
+    return s
+
 
 class LayerParams:
     """Variables of one conv2d scope (tf_util.py:159-183): weights (cin,cout) [= the (1,1,cin,cout) kernel],
@@ -107,6 +122,8 @@ class _MlpStack(torch.autograd.Function):
         dz = None if pool_ns else d_out          # dense upstream gradient of the current layer
         ldz = d_out.shape[1]
         dx0 = None
+        side = main = None
+        keep = []
         with torch.cuda.device(dev):
             for li in range(len(layers) - 1, -1, -1):
                 lp = layers[li]
@@ -130,8 +147,17 @@ class _MlpStack(torch.autograd.Function):
                 work = torch.empty(int(lib.gspn_mlp_bwd_work_bytes(rows, cin, cout)) // 4 + 4, dtype=torch.float32, device=dev)
                 L.check(lib.gspn_mlp_bwd_wgrad(rows, cin, cout, ctypes.byref(a), L.ptr(xin), xld, L.ptr(in_scale), L.ptr(in_shift),
                                                L.ptr(mean), L.ptr(var), L.ptr(lp.gamma if lp.bn else None), BN_EPS, int(lp.bn), int(is_training),
-                                               L.ptr(work), L.ptr(cA), L.ptr(cB), L.ptr(cC), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dbias), L.ptr(dW), st),
-                        "mlp_bwd_wgrad")
+                                               L.ptr(work), L.ptr(cA), L.ptr(cB), L.ptr(cC), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dbias),
+                                               None if DEFER_DW else L.ptr(dW), st), "mlp_bwd_wgrad")
+                if DEFER_DW:
+                    if side is None:
+                        side = _side_stream(dev)
+                        main = torch.cuda.current_stream()
+                    side.wait_event(main.record_event())            # after this layer's wgrad + channel sums
+                    L.check(lib.gspn_mlp_bwd_dw(rows, cin, cout, ctypes.byref(a), L.ptr(xin), xld, L.ptr(var), L.ptr(lp.gamma if lp.bn else None),
+                                                BN_EPS, int(lp.bn), int(is_training), L.ptr(work), L.ptr(dW),
+                                                ctypes.c_void_p(side.cuda_stream)), "mlp_bwd_dw")
+                    keep.append((work, a))                          # alive until the side stream has joined below
                 g = [dW, dbias]
                 if lp.bn:
                     g += [dbeta, dgamma]
@@ -146,6 +172,9 @@ class _MlpStack(torch.autograd.Function):
                     dz, ldz = dx, dx.shape[1]
                 # keep the buffers referenced by `a` alive until the kernels are enqueued (same stream: ordered)
                 del a
+            if side is not None:
+                main.wait_event(side.record_event())                # join: the gradients (and the workspaces) are complete past here
+        del keep
         return (dx0, None, None) + tuple(grads)
 
 

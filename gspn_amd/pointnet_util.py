@@ -49,6 +49,54 @@ class _GroupConcat(torch.autograd.Function):
         return None, None, gp, None, None
 
 
+class _FpConcat(torch.autograd.Function):
+    """rows = concat([three_interpolate(points2, idx, weight), points1]) (pointnet_util.py:161-166) as a (b*n1, ld) matrix with a
+    16-byte row pitch, in one kernel; gradients: scatter-add to points2 (as three_interpolate_grad), slice to points1."""
+
+    @staticmethod
+    def forward(ctx, points2, idx, weight, points1):
+        b, m, c2 = points2.shape
+        n = idx.shape[1]
+        c1 = 0 if points1 is None else points1.shape[2]
+        ld = (c2 + c1 + 3) // 4 * 4
+        out = torch.empty((b * n, ld), dtype=torch.float32, device=points2.device)
+        with torch.cuda.device(points2.device):
+            L.check(L.lib().gspn_fp_concat(b, n, m, c2, c1, L.ptr(points2), L.ptr(idx), L.ptr(weight), L.ptr(points1), ld, L.ptr(out), L.stream()),
+                    "fp_concat")
+        ctx.save_for_backward(idx, weight)
+        ctx.dims = (b, n, m, c2, c1, ld)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        idx, weight = ctx.saved_tensors
+        b, n, m, c2, c1, ld = ctx.dims
+        g = g.contiguous()
+        g2 = torch.empty((b, m, c2), dtype=torch.float32, device=g.device) if ctx.needs_input_grad[0] else None
+        g1 = torch.empty((b, n, c1), dtype=torch.float32, device=g.device) if (c1 > 0 and ctx.needs_input_grad[3]) else None
+        if g2 is not None or g1 is not None:
+            with torch.cuda.device(g.device):
+                L.check(L.lib().gspn_fp_concat_grad(b, n, m, c2, c1, ld, L.ptr(g), L.ptr(idx), L.ptr(weight), L.ptr(g2), L.ptr(g1), L.stream()),
+                        "fp_concat_grad")
+        return g2, None, None, g1
+
+
+def fp_concat(points2, idx, weight, points1):
+    points2 = L.need(points2, torch.float32, 3, "points2")
+    idx = L.need(idx, torch.int32, 3, "idx")
+    weight = L.need(weight.detach(), torch.float32, 3, "weight")
+    if points1 is not None:
+        points1 = L.need(points1, torch.float32, 3, "points1")
+    b = points2.shape[0]
+    if idx.shape[0] != b or idx.shape[2] != 3:
+        raise ValueError("ThreeInterpolate expects (b,n,3) idx shape")                      # tf_interpolate.cpp:199
+    if tuple(weight.shape) != tuple(idx.shape):
+        raise ValueError("ThreeInterpolate expects (b,n,3) weight shape")                   # tf_interpolate.cpp:203
+    if points1 is not None and (points1.shape[0] != b or points1.shape[1] != idx.shape[1]):
+        raise ValueError("pointnet_fp_module: points1 must be (b, n1, c1)")
+    return _FpConcat.apply(points2, idx, weight, points1)
+
+
 def group_concat(xyz, new_xyz, points, idx, xyz_first=True):
     xyz = L.need(xyz.detach(), torch.float32, 3, "xyz")
     new_xyz = L.need(new_xyz.detach(), torch.float32, 3, "new_xyz")
@@ -160,17 +208,15 @@ def pointnet_fp_module(xyz1, xyz2, points1, points2, mlp, is_training, bn_decay,
         if geometry is None:
             geometry = fp_geometry(xyz1, xyz2)
         idx, weight = geometry.idx, geometry.weight
-        interpolated_points = three_interpolate(points2, idx, weight)
-        if points1 is not None:
-            new_points1 = torch.cat([interpolated_points, points1], dim=2)   # :164 (interp FIRST)
-        else:
-            new_points1 = interpolated_points
         if len(mlp) == 0:
-            return new_points1
-        b, n1, cin = new_points1.shape
+            interpolated_points = three_interpolate(points2, idx, weight)
+            if points1 is not None:
+                return torch.cat([interpolated_points, points1], dim=2)       # :164 (interp FIRST)
+            return interpolated_points
+        # fused: interpolate + concat + 16-byte row pitch in one pass, straight into the MLP's input matrix
+        b, n1 = idx.shape[0], idx.shape[1]
+        cin = points2.shape[2] + (0 if points1 is None else points1.shape[2])
+        x2d = fp_concat(points2, idx, weight, points1)
         layers = _mlp_layers(mlp, cin, 'conv_', bn)
-        x2d = new_points1.reshape(b * n1, cin)
-        if cin % 4:                        # 16-byte row pitch for the float4 staging path
-            x2d = torch.nn.functional.pad(x2d, (0, 4 - cin % 4))
         out = mlp_stack(x2d, cin, layers, bool(is_training), bn_decay, pool_ns=None)
         return out.view(b, n1, mlp[-1])

@@ -101,6 +101,16 @@ int gspn_threeinterpolate(int b, int m, int c, int n, const float* points, const
  * grad_points (b,m,c) is zeroed here first. */
 int gspn_threeinterpolate_grad(int b, int n, int c, int m, const float* grad_out, const int* idx, const float* weight, float* grad_points, void* stream);
 
+/* Input matrix of a feature-propagation MLP in one pass -- three_interpolate + tf.concat of utils/pointnet_util.py:161-166
+ * (interpolated features FIRST, then points1), written with row pitch ld >= c2+c1 (pad columns zero):
+ *   out (b*n, ld);  points2 (b,m,c2), idx/weight (b,n,3), points1 (b,n,c1) or NULL when c1 == 0.
+ * gspn_fp_concat_grad: grad_out (b*n, ld) -> grad_points2 (b,m,c2) (zeroed here, then scatter-added: tf_interpolate.cpp:131-153)
+ * and grad_points1 (b,n,c1); either output may be NULL. */
+int gspn_fp_concat(int b, int n, int m, int c2, int c1, const float* points2, const int* idx, const float* weight,
+                   const float* points1, int ld, float* out, void* stream);
+int gspn_fp_concat_grad(int b, int n, int m, int c2, int c1, int ld, const float* grad_out, const int* idx, const float* weight,
+                        float* grad_points2, float* grad_points1, void* stream);
+
 /* ---------------- tf_ops/nn_distance -------------------------------------------------- */
 
 /* NmDistanceKernelLauncher(b,n,xyz,m,xyz2,result,result_i,result2,result2_i)  tf_nndistance.cpp:168,
@@ -192,12 +202,16 @@ typedef struct gspn_dy_args {
  *   cA=gamma*rstd (1 without BN), cB=-gamma*rstd^2*r1/R, cC=-gamma*rstd*(r0/R - mean*rstd*r1/R)   (0 outside training)
  *   dgamma=r1, dbeta=r0 (under BN), dbias=sum(dY).
  * mean/var are the statistics the forward pass normalised with (batch, or moving when !is_training).
- * Any of cA..dbias may be NULL. */
+ * Any of cA..dbias may be NULL.  dW may be NULL too: the final sum over the partial tiles is then left to
+ * gspn_mlp_bwd_dw (same rows/cin/cout/a/X/ldx, same `work`), which nothing downstream of the layer waits for -- a caller can
+ * put it on another stream, ordered after this call, and overlap it with the next layer's kernels. */
 int gspn_mlp_bwd_wgrad(long rows, int cin, int cout, const gspn_dy_args* a, const float* X, int ldx,
                        const float* in_scale, const float* in_shift, const float* mean, const float* var, const float* gamma,
                        float eps, int use_bn, int is_training, float* work, float* cA, float* cB, float* cC,
                        float* dgamma, float* dbeta, float* dbias, float* dW, void* stream);
 long gspn_mlp_bwd_work_bytes(long rows, int cin, int cout);
+int gspn_mlp_bwd_dw(long rows, int cin, int cout, const gspn_dy_args* a, const float* X, int ldx, const float* var, const float* gamma,
+                    float eps, int use_bn, int is_training, const float* work, float* dW, void* stream);
 /* Pass B -- dX(rows,ldx)[:, :cin] = dY . W^T with dY = cA*dyh + cB*y + cC rebuilt on the fly */
 int gspn_mlp_bwd_data(long rows, int cin, int cout, const gspn_dy_args* a, const float* W, float* dX, int ldx, void* stream);
 

@@ -207,3 +207,58 @@ def test_captured_step_replays_the_eager_step():
     # parameters' .grad are views of the bucket: an optimiser sees the replayed gradients
     p0 = store.parameters()[0]
     assert p0.grad.data_ptr() == st["bucket"].flat.data_ptr()
+
+
+@pytest.mark.parametrize("b,n1,n2,c1,c2", [(2, 1500, 300, 3, 64), (1, 700, 90, 0, 33), (2, 512, 128, 64, 128)])
+def test_fp_concat_matches_interpolate_plus_concat(b, n1, n2, c1, c2):
+    """the fused FP input matrix == three_interpolate + concat (+ zero padded pitch), forward bit-exact, gradients to rounding"""
+    from gspn_amd.pointnet_util import fp_concat
+    from gspn_amd.tf_interpolate import three_interpolate, three_nn
+    g = torch.Generator(device="cpu").manual_seed(n1)
+    xyz1 = torch.rand(b, n1, 3, generator=g).cuda()
+    xyz2 = torch.rand(b, n2, 3, generator=g).cuda()
+    dist, idx = three_nn(xyz1, xyz2)
+    w = 1.0 / torch.clamp(dist, min=1e-10)
+    w = w / w.sum(dim=2, keepdim=True)
+    p2 = torch.randn(b, n2, c2, generator=g).cuda().requires_grad_(True)
+    p1 = torch.randn(b, n1, c1, generator=g).cuda().requires_grad_(True) if c1 else None
+    out = fp_concat(p2, idx, w, p1)
+    ld = (c1 + c2 + 3) // 4 * 4
+    assert out.shape == (b * n1, ld)
+    p2r = p2.detach().clone().requires_grad_(True)
+    p1r = p1.detach().clone().requires_grad_(True) if c1 else None
+    ref = three_interpolate(p2r, idx, w)
+    if c1:
+        ref = torch.cat([ref, p1r], dim=2)
+    ref = ref.reshape(b * n1, c1 + c2)
+    assert torch.equal(out[:, :c1 + c2], ref)
+    assert (out[:, c1 + c2:] == 0).all()
+    go = torch.randn(out.shape, generator=g).cuda()
+    out.backward(go)
+    ref.backward(go[:, :c1 + c2].contiguous())
+    assert rel_err(p2.grad, p2r.grad) < 1e-5
+    if c1:
+        assert torch.equal(p1.grad, p1r.grad)
+
+
+def test_deferred_dw_matches_inline():
+    """gspn_mlp_bwd_dw on a side stream (mlp.DEFER_DW) gives the inline weight gradients"""
+    from gspn_amd import mlp as M
+    from tests.test_gpu_mlp import make_params, to_layers
+    g = torch.Generator().manual_seed(5)
+    x64 = torch.randn(4096, 32, generator=g, dtype=torch.float64)
+    res = []
+    for defer in (False, True):
+        layers = to_layers(make_params([32, 64], 32, seed=9))
+        x = x64.float().cuda().requires_grad_(True)
+        old = M.DEFER_DW
+        M.DEFER_DW = defer
+        try:
+            out = M.mlp_stack(x, 32, layers, True, 0.7, pool_ns=32)
+            out.square().sum().backward()
+            torch.cuda.synchronize()
+        finally:
+            M.DEFER_DW = old
+        res.append([lp.weights.grad.clone() for lp in layers] + [x.grad.clone()])
+    for a_, b_ in zip(*res):
+        assert torch.equal(a_, b_)

@@ -36,3 +36,43 @@ geo = GeometryStream(dev)
 def both():
     p = geo.submit(pn2_geometry, xyz); cap.replay(); st["opt"].step(); p.get()
 print("geometry || (graph + adam):          %.3f ms" % timeit(both))
+from gspn_amd.tf_sampling import farthest_point_sample, gather_point
+from gspn_amd.tf_interpolate import three_nn
+from gspn_amd.tf_grouping import query_ball_point
+l1 = G["sa"][0].new_xyz; l2 = G["sa"][1].new_xyz; l3 = G["sa"][2].new_xyz
+def side(fn):
+    def f():
+        p = geo.submit(fn, xyz); cap.replay(); st["opt"].step(); p.get()
+    return f
+print("layers || FPS1 only:                 %.3f ms" % timeit(side(lambda x: farthest_point_sample(2048, x))))
+print("layers || FPS1+FPS2+FPS3:            %.3f ms" % timeit(side(lambda x: (farthest_point_sample(2048, x), farthest_point_sample(512, l1), farthest_point_sample(128, l2)))))
+print("layers || 3 x three_nn:              %.3f ms" % timeit(side(lambda x: (three_nn(l2, l3), three_nn(l1, l2), three_nn(x, l1)))))
+print("layers || 3 x ball query:            %.3f ms" % timeit(side(lambda x: (query_ball_point(0.2, 32, x, l1), query_ball_point(0.4, 32, l1, l2), query_ball_point(0.8, 32, l2, l3)))))
+print("three_nn x3 alone:                   %.3f ms" % timeit(lambda: (three_nn(l2, l3), three_nn(l1, l2), three_nn(xyz, l1))))
+print("FPS1 alone:                          %.3f ms" % timeit(lambda: farthest_point_sample(2048, xyz)))
+x1 = xyz[:1].contiguous(); x4 = xyz[:4].contiguous()
+print("layers || FPS1 of 1 scene:           %.3f ms" % timeit(side(lambda x: farthest_point_sample(2048, x1))))
+print("layers || FPS1 of 4 scenes:          %.3f ms" % timeit(side(lambda x: farthest_point_sample(2048, x4))))
+big = torch.empty(64 * 1024 * 1024, device=dev)
+print("layers || 10 x fill 256MB:           %.3f ms" % timeit(side(lambda x: [big.fill_(1.0) for _ in range(10)])))
+print("10 x fill 256MB alone:               %.3f ms" % timeit(lambda: [big.fill_(1.0) for _ in range(10)]))
+def eager_layers():
+    for p in store.parameters(): p.grad = None
+    fwd_bwd()
+print("layers eager (no graph) alone:       %.3f ms" % timeit(eager_layers))
+def eager_side():
+    p = geo.submit(lambda x: farthest_point_sample(2048, x), xyz); eager_layers(); p.get()
+print("layers eager || FPS1:                %.3f ms" % timeit(eager_side))
+lo_pri, hi_pri = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, -1)
+print("priority range (lowest, highest):", lo_pri, hi_pri)
+hi = torch.cuda.Stream(device=dev, priority=-1)
+torch.cuda.synchronize()
+with torch.cuda.stream(hi):
+    cap_hi = CapturedStep(fwd_bwd)
+    def side_hi(fn):
+        def f():
+            p = geo.submit(fn, xyz); cap_hi.replay(); st["opt"].step(); p.get()
+        return f
+    print("hi-pri layers alone:                 %.3f ms" % timeit(lambda: (cap_hi.replay(), st["opt"].step())))
+    print("hi-pri layers || FPS1:               %.3f ms" % timeit(side_hi(lambda x: farthest_point_sample(2048, x))))
+    print("hi-pri layers || full geometry:      %.3f ms" % timeit(side_hi(pn2_geometry)))
