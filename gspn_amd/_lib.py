@@ -29,6 +29,7 @@ SIGNATURES = {
     "gspn_dist_policy": [],
     "gspn_abi_version": [],
     "gspn_farthestpointsampling": [_I, _I, _I, _P, _P, _P, _P],
+    "gspn_fps_background": [_I],
     "gspn_fps_cells": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
     "gspn_farthestpointsampling_cells": [_I, _I, _I, _P, _P, _P, _P],
     "gspn_gatherpoint": [_I, _I, _I, _P, _P, _P, _P],

@@ -475,7 +475,8 @@ static inline unsigned row_grid(long rows, int ytiles, int per_cu) {
     return (unsigned)(ntiles < cap ? ntiles : cap);
 }
 // number of row-blocks (= partial-statistics rows) the forward launch of a (rows, cout) layer uses
-static inline unsigned fwd_blocks(long rows, int cout) { return row_grid(rows, cout <= 64 ? 1 : (cout + 127) / 128, 4); }
+// (workgroups per CU = what the kernel's LDS footprint lets reside at once: a persistent grid larger than that runs a second wave)
+static inline unsigned fwd_blocks(long rows, int cout) { return row_grid(rows, cout <= 64 ? 1 : (cout + 127) / 128, cout <= 64 ? 4 : 3); }
 extern "C" long gspn_mlp_fwd_stats_bytes(long rows, int cout) {
     if (rows < 0 || cout <= 0) return GSPN_ERR_ARG;
     return (long)sizeof(float) * 2 * cout * (long)fwd_blocks(rows > 0 ? rows : 1, cout);
@@ -535,7 +536,7 @@ extern "C" int gspn_mlp_fwd(long rows, int cin, int cout, const float* X, int ld
     }
     const bool v = vec_ok(X, ldx) && vec_ok(W, cout);
 #define FWD_LAUNCH(BN_, V_, YT_)                                                                                                   \
-    hipLaunchKernelGGL((mlp_fwd_kernel<BN_, V_>), dim3(row_grid(rows, YT_, 4), YT_), dim3(256), 0, st, rows, cin, cout, X, ldx, \
+    hipLaunchKernelGGL((mlp_fwd_kernel<BN_, V_>), dim3(fwd_blocks(rows, cout), YT_), dim3(256), 0, st, rows, cin, cout, X, ldx, \
                        in_scale, in_shift, W, bias, Y, ldy, stats)
     if (cout <= 32) { if (v) FWD_LAUNCH(32, true, 1); else FWD_LAUNCH(32, false, 1); }
     else if (cout <= 64) { if (v) FWD_LAUNCH(64, true, 1); else FWD_LAUNCH(64, false, 1); }
@@ -1592,8 +1593,8 @@ extern "C" int gspn_mlp_bwd_data(long rows, int cin, int cout, const gspn_dy_arg
     const bool v = vec_ok(a->Y, a->ldy) && vec_ok(W, cout) && (pooled || vec_ok(a->dZ, a->ldz));
 #define BD_LAUNCH(BN_, V_, YT_)                                                                                                        \
     do {                                                                                                                               \
-        if (pooled) hipLaunchKernelGGL((mlp_bwd_data_kernel<BN_, V_, true>), dim3(row_grid(rows, YT_, 4), YT_), dim3(256), 0, st, rows, cin, cout, *a, W, dX, ldx); \
-        else        hipLaunchKernelGGL((mlp_bwd_data_kernel<BN_, V_, false>), dim3(row_grid(rows, YT_, 4), YT_), dim3(256), 0, st, rows, cin, cout, *a, W, dX, ldx); \
+        if (pooled) hipLaunchKernelGGL((mlp_bwd_data_kernel<BN_, V_, true>), dim3(row_grid(rows, YT_, BN_ >= 128 ? 3 : 4), YT_), dim3(256), 0, st, rows, cin, cout, *a, W, dX, ldx); \
+        else        hipLaunchKernelGGL((mlp_bwd_data_kernel<BN_, V_, false>), dim3(row_grid(rows, YT_, BN_ >= 128 ? 3 : 4), YT_), dim3(256), 0, st, rows, cin, cout, *a, W, dX, ldx); \
     } while (0)
     if (cin <= 32) { if (v) BD_LAUNCH(32, true, 1); else BD_LAUNCH(32, false, 1); }
     else if (cin <= 64) { if (v) BD_LAUNCH(64, true, 1); else BD_LAUNCH(64, false, 1); }

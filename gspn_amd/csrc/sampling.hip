@@ -41,6 +41,18 @@ __device__ long long g_fps_tl[16 * 8];
 #define FPS_TICK(i) do {} while (0)
 #endif
 
+// Background mode.  A CU whose four wave slots per SIMD issue VALU instructions without a break slows every bandwidth-bound kernel
+// running elsewhere on the chip by ~10 % (measured on MI355X with tools/queue_probe2.py: a pure-VALU workgroup of 16 waves on ONE CU
+// costs a concurrent HBM-streaming chain +9 %; one s_sleep 1 per ~64 VALU instructions removes the effect for +4 % on the spinning
+// kernel).  FPS is exactly such a kernel, and in the intended schedule it runs beside the MLP layers on a side stream with time to
+// spare -- so launches made while background mode is on yield once per 8 points.  Process-wide switch, consulted at launch.
+static int g_fps_yield = 0;
+extern "C" int gspn_fps_background(int on) {
+    const int prev = g_fps_yield;
+    g_fps_yield = on ? 1 : 0;
+    return prev;
+}
+
 template <int P>
 struct FpsGroup {
     static constexpr int G = (P >= 8) ? 8 : P;   // points per resolve group
@@ -55,7 +67,7 @@ __device__ __forceinline__ int vmax3_i32(int a, int b, int c) {
 
 // P = points per thread (even), ZLDS = z plane in LDS instead of VGPRs
 template <int P, bool ZLDS>
-__global__ __launch_bounds__(FPS_T) void fps_resident_kernel(int n, int m, const float* __restrict__ inp, int* __restrict__ out) {
+__global__ __launch_bounds__(FPS_T) void fps_resident_kernel(int n, int m, const float* __restrict__ inp, int* __restrict__ out, int yield) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // [0,512)    : candidates, 2 buffers x 16 waves x int4 {max bits, x, y, z}
     // [512,640)  : candidate indices, 2 buffers x 16 waves x int
@@ -135,6 +147,7 @@ __global__ __launch_bounds__(FPS_T) void fps_resident_kernel(int n, int m, const
                 gm = vmax3_i32(gm, __float_as_int(td[pp][0]), __float_as_int(td[pp][1]));
             }
             g[q] = gm;
+            if (yield) __builtin_amdgcn_s_sleep(1);   // background mode: see gspn_fps_background
             __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from interleaving groups (VGPR pressure)
         }
         int best = g[0];
@@ -237,7 +250,7 @@ __device__ long long g_cell_prof[32];
 
 template <int P, bool ZLDS>
 __global__ __launch_bounds__(FPS_T) void fps_cell_kernel(int n, int m, int csz, const float* __restrict__ sxyz, const int* __restrict__ perm,
-                                                         const float* __restrict__ inp0, int inp0_stride, int* __restrict__ out) {
+                                                         const float* __restrict__ inp0, int inp0_stride, int* __restrict__ out, int yield) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // [0,1024)   : candidates, 2 buffers x 16 waves x {int4 {v bits, x, y, z}, int4 {sorted position, bound bits, -, -}}
     // [1024,1040): batch record written by wave 0
@@ -358,6 +371,7 @@ __global__ __launch_bounds__(FPS_T) void fps_cell_kernel(int n, int m, int csz, 
                         td[pp][1] = vmin_f32(d[1], td[pp][1]);
                     }
                     zq = zn;
+                    if (yield) __builtin_amdgcn_s_sleep(1);      // background mode: see gspn_fps_background
                 }
             } else {
 #pragma unroll
@@ -647,7 +661,7 @@ static int launch_fps_resident(int b, int n, int m, const float* inp, int* out, 
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL((fps_resident_kernel<P, ZLDS>), dim3(b), dim3(FPS_T), lds, st, n, m, inp, out);
+    hipLaunchKernelGGL((fps_resident_kernel<P, ZLDS>), dim3(b), dim3(FPS_T), lds, st, n, m, inp, out, g_fps_yield);
     return gspn_launch_status();
 }
 
@@ -765,7 +779,7 @@ static int launch_fps_cell(int b, int n, int m, int csz, const float* sxyz, cons
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL((fps_cell_kernel<P, ZLDS>), dim3(b), dim3(FPS_T), lds, st, n, m, csz, sxyz, perm, inp0, stride0, out);
+    hipLaunchKernelGGL((fps_cell_kernel<P, ZLDS>), dim3(b), dim3(FPS_T), lds, st, n, m, csz, sxyz, perm, inp0, stride0, out, g_fps_yield);
     return gspn_launch_status();
 }
 // FPS on a spatially pre-sorted scene (see fps_cell_kernel): sxyz (b,n,3) = inp gathered by perm (b,n) [sorted position -> original

@@ -15,6 +15,7 @@ Results are identical to the inline path (same kernels, same inputs); only the s
 """
 import torch
 
+from . import _lib as L
 from .tf_grouping import knn_point, query_ball_point
 from .tf_interpolate import three_nn
 from .tf_sampling import farthest_point_sample, gather_point
@@ -103,7 +104,12 @@ class GeometryStream:
             for a in args:
                 if isinstance(a, torch.Tensor):
                     a.record_stream(self.stream)
-            with torch.no_grad():
-                value = fn(*args, **kwargs)
+            # FPS launched from here runs beside the layers: background mode (it yields, see gspn_fps_background)
+            prev = L.lib().gspn_fps_background(1)
+            try:
+                with torch.no_grad():
+                    value = fn(*args, **kwargs)
+            finally:
+                L.lib().gspn_fps_background(prev)
             done = self.stream.record_event()
         return PendingGeometry(value, done, self.stream)

@@ -39,6 +39,10 @@ int gspn_abi_version(void);
  * n > GSPN_FPS_RESIDENT_MAX (the on-chip kernel needs none; may be NULL below that). */
 #define GSPN_FPS_RESIDENT_MAX 32768
 int gspn_farthestpointsampling(int b, int n, int m, const float* inp, float* temp, int* out, void* stream);
+/* Background mode for the FPS kernels (process-wide, read at launch; returns the previous setting).  When on, the sampling loop
+ * yields (s_sleep 1) once per 8 points: ~4 % slower, but it no longer slows bandwidth-bound kernels running next to it on other
+ * streams (a CU issuing VALU work without a break costs them ~10 % chip-wide on MI355X).  Results are unaffected. */
+int gspn_fps_background(int on);
 
 /* Same result as gspn_farthestpointsampling, several times fewer serial rounds: FPS on a scene that the caller has sorted into
  * 16 spatial cells (csz = ceil(n/16) points each, Morton order; inside a cell by the reference tie rank (k mod 512, k)):

@@ -1,0 +1,66 @@
+// side kernels for queue_probe: a single workgroup that just burns time (VALU spin / s_sleep / LDS traffic), duration ~ms
+#include <hip/hip_runtime.h>
+extern "C" __global__ void spin_valu(long long cycles, float* out) {
+    long long t0 = clock64(); float a = threadIdx.x;
+    while (clock64() - t0 < cycles) { for (int i = 0; i < 64; ++i) a = a * 1.0001f + 0.5f; }
+    if (a == 1.2345f) out[0] = a;
+}
+extern "C" __global__ void spin_sleep(long long cycles, float* out) {
+    long long t0 = clock64();
+    while (clock64() - t0 < cycles) { __builtin_amdgcn_s_sleep(64); }
+    if (cycles == 1) out[0] = 1.f;
+}
+extern "C" __global__ void spin_lds(long long cycles, float* out) {
+    extern __shared__ float lds[];
+    long long t0 = clock64(); float a = 0.f;
+    for (int i = threadIdx.x; i < 32768; i += blockDim.x) lds[i] = i;
+    __syncthreads();
+    while (clock64() - t0 < cycles) { for (int i = 0; i < 64; ++i) a += lds[(threadIdx.x * 17 + i * 64) & 32767]; __syncthreads(); }
+    if (a == 1.2345f) out[0] = a;
+}
+// fixed-trip-count variants (no s_memtime polling in the loop)
+extern "C" __global__ void loop_valu(long long iters, float* out) {
+    float a = threadIdx.x, b = 1.0001f;
+    for (long long it = 0; it < iters; ++it) { for (int i = 0; i < 64; ++i) a = a * b + 0.5f; }
+    if (a == 1.2345f) out[0] = a;
+}
+extern "C" __global__ __launch_bounds__(1024) void loop_valu_fullregs(long long iters, float* out) {
+    float a = threadIdx.x, b = 1.0001f;
+    asm volatile("v_mov_b32 v127, 0" ::: "v127");          // claim 128 VGPRs: 4 waves x 128 fill the SIMD's register file
+    for (long long it = 0; it < iters; ++it) { for (int i = 0; i < 64; ++i) a = a * b + 0.5f; }
+    if (a == 1.2345f) out[0] = a;
+}
+template <int MODE>
+__global__ __launch_bounds__(1024) void loop_valu_yield(long long iters, float* out) {
+    float a = threadIdx.x, b = 1.0001f;
+    asm volatile("v_mov_b32 v127, 0" ::: "v127");
+    for (long long it = 0; it < iters; ++it) {
+        for (int i = 0; i < 64; ++i) a = a * b + 0.5f;
+        if (MODE == 0) __builtin_amdgcn_s_sleep(1);
+        if (MODE == 1) __builtin_amdgcn_s_sleep(4);
+        if (MODE == 2) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15");
+        if (MODE == 3) __builtin_amdgcn_s_setprio(0);
+    }
+    if (a == 1.2345f) out[0] = a;
+}
+extern "C" __global__ void loop_valu_barrier(long long iters, float* out) {
+    float a = threadIdx.x, b = 1.0001f;
+    for (long long it = 0; it < iters; ++it) { for (int i = 0; i < 64; ++i) a = a * b + 0.5f; __syncthreads(); }
+    if (a == 1.2345f) out[0] = a;
+}
+extern "C" int launch_spin(int which, int blocks, int threads, long long cycles, float* out, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (which == 6) hipLaunchKernelGGL(loop_valu_yield<0>, dim3(blocks), dim3(threads), 0, st, cycles, out);
+    else if (which == 7) hipLaunchKernelGGL(loop_valu_yield<1>, dim3(blocks), dim3(threads), 0, st, cycles, out);
+    else if (which == 8) hipLaunchKernelGGL(loop_valu_yield<2>, dim3(blocks), dim3(threads), 0, st, cycles, out);
+    else if (which == 5) hipLaunchKernelGGL(loop_valu_fullregs, dim3(blocks), dim3(threads), 0, st, cycles, out);
+    else if (which == 3) hipLaunchKernelGGL(loop_valu, dim3(blocks), dim3(threads), 0, st, cycles, out);
+    else if (which == 4) hipLaunchKernelGGL(loop_valu_barrier, dim3(blocks), dim3(threads), 0, st, cycles, out);
+    else if (which == 0) hipLaunchKernelGGL(spin_valu, dim3(blocks), dim3(threads), 0, st, cycles, out);
+    else if (which == 1) hipLaunchKernelGGL(spin_sleep, dim3(blocks), dim3(threads), 0, st, cycles, out);
+    else {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&spin_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        hipLaunchKernelGGL(spin_lds, dim3(blocks), dim3(threads), 131072, st, cycles, out);
+    }
+    return (int)hipGetLastError();
+}
