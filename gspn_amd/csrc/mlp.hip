@@ -1460,7 +1460,8 @@ extern "C" int gspn_mlp_bwd_dw(long rows, int cin, int cout, const gspn_dy_args*
 // ============================================================================================
 template <int BN, bool VEC, bool POOLED>
 __global__ __launch_bounds__(256) void mlp_bwd_data_kernel(long rows, int cin, int cout, gspn_dy_args a, const float* __restrict__ W,
-                                                           float* __restrict__ dX, int ldx) {
+                                                           float* __restrict__ dX, int ldx, int col0) {
+    // `cin` is the END of the column range [col0, cin) of dX this launch produces (gspn_mlp_bwd_data_cols)
     constexpr int NT = BN / 32;
     constexpr int LDBT = BN + 1;                 // B written transposed: odd pitch
     constexpr int NB = (TK / 4 * BN) / 256;      // float4 (along k) per thread per chunk
@@ -1468,7 +1469,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_data_kernel(long rows, int cin, i
     __shared__ __attribute__((aligned(16))) float sB[TK * LDBT];
     __shared__ float sSc[MAXCH], sSh[MAXCH], sCA[MAXCH], sCB[MAXCH], sCC[MAXCH];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int n0 = blockIdx.y * BN;
+    const int n0 = col0 + blockIdx.y * BN;
     const long ntiles = (rows + TM - 1) / TM;
     const int nchunks = (cout + TK - 1) / TK;
     stage_chan(sSc, a.scale, cout, 1.f);
@@ -1582,23 +1583,31 @@ __global__ __launch_bounds__(256) void mlp_bwd_data_kernel(long rows, int cin, i
         __syncthreads();
     }
 }
-extern "C" int gspn_mlp_bwd_data(long rows, int cin, int cout, const gspn_dy_args* a, const float* W, float* dX, int ldx, void* stream) {
+// columns [col0, col0 + ncols) of dX only: the rest of the row is left untouched (the caller does not need it -- e.g. the xyz columns
+// of a set-abstraction input, whose gradient pointnet_util.py never uses -- which can halve the N dimension of the GEMM)
+extern "C" int gspn_mlp_bwd_data_cols(long rows, int cin, int cout, const gspn_dy_args* a, const float* W, int col0, int ncols, float* dX, int ldx,
+                                      void* stream) {
     if (rows < 0 || cin <= 0 || cout <= 0 || ldx < cin || !a || !a->Y || !a->scale || !a->shift || !a->cA || !a->cB || !a->cC) return GSPN_ERR_ARG;
     if (!a->dZ && !(a->dPool && a->pool_arg && a->ns > 0)) return GSPN_ERR_ARG;
+    if (col0 < 0 || ncols <= 0 || col0 + ncols > cin) return GSPN_ERR_ARG;
     if (cin > MAXCH || cout > MAXCH) return GSPN_ERR_UNSUPPORTED;
     if (rows == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     if (rows >= (1L << 31)) return GSPN_ERR_UNSUPPORTED;
     const bool pooled = a->dZ == nullptr;
     const bool v = vec_ok(a->Y, a->ldy) && vec_ok(W, cout) && (pooled || vec_ok(a->dZ, a->ldz));
+    const int cend = col0 + ncols;
 #define BD_LAUNCH(BN_, V_, YT_)                                                                                                        \
     do {                                                                                                                               \
-        if (pooled) hipLaunchKernelGGL((mlp_bwd_data_kernel<BN_, V_, true>), dim3(row_grid(rows, YT_, BN_ >= 128 ? 3 : 4), YT_), dim3(256), 0, st, rows, cin, cout, *a, W, dX, ldx); \
-        else        hipLaunchKernelGGL((mlp_bwd_data_kernel<BN_, V_, false>), dim3(row_grid(rows, YT_, BN_ >= 128 ? 3 : 4), YT_), dim3(256), 0, st, rows, cin, cout, *a, W, dX, ldx); \
+        if (pooled) hipLaunchKernelGGL((mlp_bwd_data_kernel<BN_, V_, true>), dim3(row_grid(rows, YT_, BN_ >= 128 ? 3 : 4), YT_), dim3(256), 0, st, rows, cend, cout, *a, W, dX, ldx, col0); \
+        else        hipLaunchKernelGGL((mlp_bwd_data_kernel<BN_, V_, false>), dim3(row_grid(rows, YT_, BN_ >= 128 ? 3 : 4), YT_), dim3(256), 0, st, rows, cend, cout, *a, W, dX, ldx, col0); \
     } while (0)
-    if (cin <= 32) { if (v) BD_LAUNCH(32, true, 1); else BD_LAUNCH(32, false, 1); }
-    else if (cin <= 64) { if (v) BD_LAUNCH(64, true, 1); else BD_LAUNCH(64, false, 1); }
-    else { const int yt = (cin + 127) / 128; if (v) BD_LAUNCH(128, true, yt); else BD_LAUNCH(128, false, yt); }
+    if (ncols <= 32) { if (v) BD_LAUNCH(32, true, 1); else BD_LAUNCH(32, false, 1); }
+    else if (ncols <= 64) { if (v) BD_LAUNCH(64, true, 1); else BD_LAUNCH(64, false, 1); }
+    else { const int yt = (ncols + 127) / 128; if (v) BD_LAUNCH(128, true, yt); else BD_LAUNCH(128, false, yt); }
 #undef BD_LAUNCH
     return gspn_launch_status();
+}
+extern "C" int gspn_mlp_bwd_data(long rows, int cin, int cout, const gspn_dy_args* a, const float* W, float* dX, int ldx, void* stream) {
+    return gspn_mlp_bwd_data_cols(rows, cin, cout, a, W, 0, cin, dX, ldx, stream);
 }

@@ -164,9 +164,14 @@ class _MlpStack(torch.autograd.Function):
                 grads = g + grads
                 if li > 0 or ctx.x_needs_grad:
                     dx = torch.empty((rows, xld), dtype=torch.float32, device=dev) if li == 0 else torch.empty((rows, cin), dtype=torch.float32, device=dev)
-                    if li == 0 and xld > cin:
+                    if li == 0 and xld > cin and spec.get("grad_cols") is None:
                         dx.zero_()
-                    L.check(lib.gspn_mlp_bwd_data(rows, cin, cout, ctypes.byref(a), L.ptr(lp.weights), L.ptr(dx), dx.shape[1], st), "mlp_bwd_data")
+                    gc = spec.get("grad_cols") if li == 0 else None
+                    if gc is not None:          # only these input columns feed a gradient upstream (e.g. not the xyz columns of an SA input)
+                        L.check(lib.gspn_mlp_bwd_data_cols(rows, cin, cout, ctypes.byref(a), L.ptr(lp.weights), int(gc[0]), int(gc[1]), L.ptr(dx),
+                                                           dx.shape[1], st), "mlp_bwd_data_cols")
+                    else:
+                        L.check(lib.gspn_mlp_bwd_data(rows, cin, cout, ctypes.byref(a), L.ptr(lp.weights), L.ptr(dx), dx.shape[1], st), "mlp_bwd_data")
                     if li == 0:
                         dx0 = dx
                     dz, ldz = dx, dx.shape[1]
@@ -178,14 +183,18 @@ class _MlpStack(torch.autograd.Function):
         return (dx0, None, None) + tuple(grads)
 
 
-def mlp_stack(x, cin, layers, is_training, bn_decay, pool_ns=None):
-    """x: (rows, ld>=cin) float32 on a ROCm device.  Returns (rows/pool_ns, C_last) if pool_ns else (rows, C_last)."""
+def mlp_stack(x, cin, layers, is_training, bn_decay, pool_ns=None, grad_cols=None):
+    """x: (rows, ld>=cin) float32 on a ROCm device.  Returns (rows/pool_ns, C_last) if pool_ns else (rows, C_last).
+    grad_cols = (col0, ncols): the only columns of x whose gradient the caller will read (the rest of x.grad is left undefined)."""
     if not layers:
         raise ValueError("mlp_stack needs at least one layer")
     x = L.need(x, torch.float32, 2, "x")
     if pool_ns and x.shape[0] % pool_ns:
         raise ValueError("rows must be a multiple of pool_ns")
-    spec = {"layers": layers, "is_training": is_training, "decay": 0.9 if bn_decay is None else float(bn_decay), "pool_ns": pool_ns}
+    if grad_cols is not None and not (0 <= grad_cols[0] and grad_cols[1] > 0 and grad_cols[0] + grad_cols[1] <= cin):
+        raise ValueError("grad_cols must be a column range inside [0, cin)")
+    spec = {"layers": layers, "is_training": is_training, "decay": 0.9 if bn_decay is None else float(bn_decay), "pool_ns": pool_ns,
+            "grad_cols": grad_cols}
     flat = []
     for lp in layers:
         flat += lp.tensors()

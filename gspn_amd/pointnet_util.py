@@ -165,7 +165,9 @@ def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_al
             rows = group_concat(xyz, new_xyz, points, idx, xyz_first=True)      # (b*npoint*nsample, pitch >= 3+c)
             cin = 3 + (0 if points is None else points.shape[2])
             layers = _mlp_layers(mlp, cin, 'conv', bn)
-            pooled = mlp_stack(rows, cin, layers, bool(is_training), bn_decay, pool_ns=nsample)     # (b*npoint, mlp[-1])
+            # group_concat's gradient reads the feature columns only (xyz carries no gradient): backward skips the 3 xyz columns of dX
+            gcols = (3, cin - 3) if cin > 3 else None
+            pooled = mlp_stack(rows, cin, layers, bool(is_training), bn_decay, pool_ns=nsample, grad_cols=gcols)     # (b*npoint, mlp[-1])
             new_points = pooled.view(b, npoint, 1, mlp[-1])
         else:
             if group_all:
@@ -218,5 +220,8 @@ def pointnet_fp_module(xyz1, xyz2, points1, points2, mlp, is_training, bn_decay,
         cin = points2.shape[2] + (0 if points1 is None else points1.shape[2])
         x2d = fp_concat(points2, idx, weight, points1)
         layers = _mlp_layers(mlp, cin, 'conv_', bn)
-        out = mlp_stack(x2d, cin, layers, bool(is_training), bn_decay, pool_ns=None)
+        # fp_concat's gradient reads the points1 columns only if points1 wants a gradient (the last FP level gets raw colours)
+        c2 = points2.shape[2]
+        gcols = (0, c2) if (points1 is not None and not points1.requires_grad) else None
+        out = mlp_stack(x2d, cin, layers, bool(is_training), bn_decay, pool_ns=None, grad_cols=gcols)
         return out.view(b, n1, mlp[-1])

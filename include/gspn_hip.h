@@ -218,6 +218,10 @@ int gspn_mlp_bwd_dw(long rows, int cin, int cout, const gspn_dy_args* a, const f
                     float eps, int use_bn, int is_training, const float* work, float* dW, void* stream);
 /* Pass B -- dX(rows,ldx)[:, :cin] = dY . W^T with dY = cA*dyh + cB*y + cC rebuilt on the fly */
 int gspn_mlp_bwd_data(long rows, int cin, int cout, const gspn_dy_args* a, const float* W, float* dX, int ldx, void* stream);
+/* ... restricted to columns [col0, col0+ncols) of dX (the other columns are left untouched): for inputs whose leading or trailing
+ * channels need no gradient -- the xyz columns of a set-abstraction input, the raw colours of the last FP level. */
+int gspn_mlp_bwd_data_cols(long rows, int cin, int cout, const gspn_dy_args* a, const float* W, int col0, int ncols, float* dX, int ldx,
+                           void* stream);
 
 int gspn_fill_zero(void* ptr, long bytes, void* stream);
 

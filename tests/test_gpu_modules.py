@@ -262,3 +262,21 @@ def test_deferred_dw_matches_inline():
         res.append([lp.weights.grad.clone() for lp in layers] + [x.grad.clone()])
     for a_, b_ in zip(*res):
         assert torch.equal(a_, b_)
+
+
+def test_fp_module_grad_cols_shortcut_is_exact():
+    """when points1 needs no gradient the first layer's dX is computed for the interpolated columns only: same gradient to points2"""
+    from gspn_amd.pointnet_util import pointnet_fp_module
+    g = torch.Generator().manual_seed(4)
+    xyz1 = torch.rand(2, 900, 3, generator=g).cuda()
+    xyz2 = torch.rand(2, 200, 3, generator=g).cuda()
+    p1 = torch.randn(2, 900, 3, generator=g).cuda()
+    p2v = torch.randn(2, 200, 32, generator=g).cuda()
+    grads = []
+    for rg in (True, False):
+        fresh_store(21)
+        p2 = p2v.clone().requires_grad_(True)
+        out = pointnet_fp_module(xyz1, xyz2, p1.clone().requires_grad_(rg), p2, [32, 16], True, 0.5, 'fa')
+        out.square().mean().backward()
+        grads.append(p2.grad.clone())
+    assert rel_err(grads[1], grads[0]) < 1e-6
