@@ -859,6 +859,12 @@ __global__ __launch_bounds__(256) void mlp_bwd_wgrad_kernel(long rows, int cin, 
 // LDS image of one stage: [A: TKW x BM][Y: TKW x BN][dZ: TKW x BN (dense only)], linear (a wave-load writes 1 KiB contiguous).
 // A max-pooled upstream gradient (POOLED) is never expanded: per stage a lane fetches the arg-max offset and the pooled
 // gradient of its column for the <= NGMAX pool groups the stage covers, and dz = (arg == row % ns) ? dPool : 0.
+// Three stage buffers (two stages in flight) instead of two: measured on MI355X at the bench shapes it does NOT pay -- the third buffer
+// costs a workgroup per CU (72 KB of LDS) and pass A is bound by MFMA + VALU issue, not by bytes in flight (64->64 x 262144 rows:
+// 72.7 us with two buffers, 76.4 us with three).  Kept as a build option.
+#ifndef WGRAD_NBUF3
+#define WGRAD_NBUF3 0
+#endif
 // Work split inside a workgroup: the T = MT*NTT tiles and WK k-parts are dealt to the 4 waves as a (GM x GN) grid of wave groups
 // times WK k-parts (GM*GN*WK == 4).  Wave (gm, gn, kp) owns the AM x BNW block of tiles {tm = gm + GM*a} x {tn = gn + GN*b} over
 // the rows of k-part kp: one k-loop with all its accumulators live, A operands shared along b and B operands along a.
@@ -888,7 +894,13 @@ __global__ __launch_bounds__(256, ((WgradSplit<MT, NTT>::AM * WgradSplit<MT, NTT
     constexpr int SF = TKW * (BM + BN + (POOLED ? 0 : BN));           // floats per stage
     constexpr int NGMAX = POOLED ? (TKW >= 16 ? TKW / 16 : 1) : 1;    // pool groups per stage (ns >= 16)
     constexpr int JA = (PA + 3) / 4, JB = (PB + 3) / 4;
-    __shared__ __attribute__((aligned(16))) float sbuf[2 * SF];
+    // Stage buffers.  With three, TWO stages are in flight while one is consumed (more bytes in flight per CU: Little's law at 8 TB/s);
+    // the wait for "stage s has landed" is then a COUNTED vmcnt that leaves the newer stage's pieces outstanding.  That is only sound
+    // when the loop's only vector-memory operations are the in-order LDS-DMA loads and every wave issues the same number per stage:
+    // dense upstream gradient (the pooled variant interleaves ordinary loads) and whole multiples of 4 pieces per array.
+    constexpr int PPW = JA + (POOLED ? JB : 2 * JB);                  // pieces per wave per stage
+    constexpr int NBUF = (WGRAD_NBUF3 && !POOLED && PA % 4 == 0 && PB % 4 == 0 && 3 * SF * 4 <= 80 * 1024 && PPW <= 15) ? 3 : 2;
+    __shared__ __attribute__((aligned(16))) float sbuf[NBUF * SF];
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int l31 = lane & 31, half = lane >> 5;
     const int kp = wave % WK, grp = wave / WK;
@@ -928,7 +940,7 @@ __global__ __launch_bounds__(256, ((WgradSplit<MT, NTT>::AM * WgradSplit<MT, NTT
     const float* Yc = a.Y + (size_t)r_begin * a.ldy;
     const float* Zc = POOLED ? nullptr : a.dZ + (size_t)r_begin * a.ldz;
     auto issue = [&](int s) {
-        float* dst = sbuf + (s & 1) * SF;
+        float* dst = sbuf + (s % NBUF) * SF;
         const int k0 = s * TKW;
 #pragma unroll
         for (int j = 0; j < JA; ++j) {
@@ -946,7 +958,7 @@ __global__ __launch_bounds__(256, ((WgradSplit<MT, NTT>::AM * WgradSplit<MT, NTT
     };
 
     // ---- per-operand constants: AM input-channel columns, BNW output-channel columns per lane ----
-    float isc[AM], ish[AM], bsc[BNW], bsh[BNW], bmu[BNW], brs[BNW];
+    float isc[AM], ish[AM], bsc[BNW], bsh[BNW], bmr[BNW], brs[BNW];
     int ao[AM], bo[BNW];
     const float lo = in_scale ? 0.f : -__builtin_inff();               // relu floor (none for a raw first-layer input)
 #pragma unroll
@@ -962,8 +974,8 @@ __global__ __launch_bounds__(256, ((WgradSplit<MT, NTT>::AM * WgradSplit<MT, NTT
         const int n = min(n0 + bo[y], cout - 1);
         bsc[y] = a.scale[n];
         bsh[y] = a.shift[n];
-        bmu[y] = mean ? mean[n] : 0.f;
         brs[y] = var ? (float)(1.0 / sqrt((double)var[n] + (double)eps)) : 1.f;
+        bmr[y] = -(mean ? mean[n] : 0.f) * brs[y];
     }
     // ---- pooled gradient: per (column tile, group-in-stage) arg-max offset and pooled gradient of the lane's column ----
     const int ns = POOLED ? a.ns : TKW;
@@ -1013,10 +1025,13 @@ __global__ __launch_bounds__(256, ((WgradSplit<MT, NTT>::AM * WgradSplit<MT, NTT
 
     pool_fetch();
     issue(0);
+    if (NBUF == 3 && nit > 1) issue(1);
     for (int s = 0; s < nit; ++s) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of stage s have landed ...
+        // this wave's pieces of stage s have landed (with three buffers the PPW pieces of stage s+1 may still be in flight) ...
+        if (NBUF == 3 && s + 1 < nit) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                        // ... and so have everyone else's; stage s-1 is fully consumed
-        const float* buf = sbuf + (s & 1) * SF;
+        const float* buf = sbuf + (s % NBUF) * SF;
         if constexpr (POOLED) {
 #pragma unroll
             for (int y = 0; y < BNW; ++y)
@@ -1024,7 +1039,8 @@ __global__ __launch_bounds__(256, ((WgradSplit<MT, NTT>::AM * WgradSplit<MT, NTT
                 for (int gl = 0; gl < NGMAX; ++gl) { p_arg[y][gl] = n_ok[y][gl] ? n_arg[y][gl] : -1; p_dp[y][gl] = n_dp[y][gl]; }
             off_cur = off_nxt;
         }
-        if (s + 1 < nit) { pool_fetch(); issue(s + 1); }
+        if (NBUF == 3) { if (s + 2 < nit) issue(s + 2); }
+        else if (s + 1 < nit) { pool_fetch(); issue(s + 1); }
         const float* sA = buf;
         const float* sY = buf + TKW * BM;
         const float* sZ = buf + TKW * (BM + BN);
@@ -1032,12 +1048,15 @@ __global__ __launch_bounds__(256, ((WgradSplit<MT, NTT>::AM * WgradSplit<MT, NTT
         auto compute = [&](auto tail_c) {
             constexpr bool TAIL = decltype(tail_c)::value;
             // one MFMA k-pair: this lane's row r of the stage; gl = pool group of that row (compile-time when it matters)
+            // VALU instructions are not hidden under the MFMAs on this chip (~3.4 SIMD cycles each, tools/mfma_probe.hip), so the operand
+            // arithmetic is spelled with single fused operations (the mask / x-hat differ from the forward's two-rounding forms by one
+            // ulp at most: irrelevant for a gradient) and the column sums are taken only by the wave groups that report them.
             auto step = [&](int r, int gl_rt) {
                 float av[AM], dyh[BNW], xh[BNW];
 #pragma unroll
                 for (int x = 0; x < AM; ++x) {
                     // (no inline asm here: hipcc's hazard recogniser does not see an asm VALU write feeding an MFMA operand)
-                    av[x] = __builtin_fmaxf(sA[r * BM + ao[x]] * isc[x] + ish[x], lo);
+                    av[x] = __builtin_fmaxf(__builtin_fmaf(sA[r * BM + ao[x]], isc[x], ish[x]), lo);
                     if (TAIL) av[x] = r < live ? av[x] : 0.f;
                 }
 #pragma unroll
@@ -1053,14 +1072,22 @@ __global__ __launch_bounds__(256, ((WgradSplit<MT, NTT>::AM * WgradSplit<MT, NTT
                             if (gl == gl_rt) dz = p_arg[y][gl] == off_cur + r - gl * gs ? p_dp[y][gl] : 0.f;
                     }
                     if (TAIL) dz = r < live ? dz : 0.f;
-                    dyh[y] = (yv * bsc[y] + bsh[y]) > 0.f ? dz : 0.f;
-                    xh[y] = (yv - bmu[y]) * brs[y];
-                    r0a[y] += dyh[y];
-                    r1a[y] += dyh[y] * xh[y];
+                    dyh[y] = __builtin_fmaf(yv, bsc[y], bsh[y]) > 0.f ? dz : 0.f;
+                    xh[y] = __builtin_fmaf(yv, brs[y], bmr[y]);              // (y - mean) * rstd
+                }
+                if (gm == 0) {
+#pragma unroll
+                    for (int y = 0; y < BNW; ++y) {
+                        r0a[y] += dyh[y];
+                        r1a[y] = __builtin_fmaf(dyh[y], xh[y], r1a[y]);
+                    }
+                }
+                if (gn == 0) {
+#pragma unroll
+                    for (int x = 0; x < AM; ++x) g3a[x] += av[x];
                 }
 #pragma unroll
                 for (int x = 0; x < AM; ++x) {
-                    g3a[x] += av[x];
 #pragma unroll
                     for (int y = 0; y < BNW; ++y) {
                         acc1[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x], dyh[y], acc1[x][y], 0, 0, 0);
@@ -1091,7 +1118,7 @@ __global__ __launch_bounds__(256, ((WgradSplit<MT, NTT>::AM * WgradSplit<MT, NTT
     // k-parts > 0 hand their accumulators to part 0 through LDS (fixed order), so ONE partial tile per chunk leaves the CU.
     if constexpr (WK > 1) {
         constexpr int TILEF = 16 * 64;                                    // floats of one 32x32 accumulator tile, [reg][lane]
-        static_assert((WK - 1) * SP::G * BNW * TILEF <= 2 * SF, "k-part exchange fits the stage buffers");
+        static_assert((WK - 1) * SP::G * BNW * TILEF <= NBUF * SF, "k-part exchange fits the stage buffers");
 #pragma unroll
         for (int which = 0; which < (WANT_GX ? 2 : 1); ++which) {
 #pragma unroll
@@ -1154,7 +1181,7 @@ __global__ __launch_bounds__(256, ((WgradSplit<MT, NTT>::AM * WgradSplit<MT, NTT
     __syncthreads();
     float* sR = sbuf;                                   // [WK*2][2][BN]
     float* sG = sbuf + WK * 2 * 2 * BN;                 // [WK*2][BM]
-    static_assert(WK * 2 * (2 * BN + BM) <= 2 * SF, "reduction scratch fits the stage buffers");
+    static_assert(WK * 2 * (2 * BN + BM) <= NBUF * SF, "reduction scratch fits the stage buffers");
     {
         const int part = kp * 2 + half;
         if (gm == 0) {
@@ -1202,7 +1229,7 @@ __global__ __launch_bounds__(256, ((WgradSplit<MT, NTT>::AM * WgradSplit<MT, NTT
 //   * slots: when nch partial tiles fit in 64 MB every chunk owns a slot and the main kernel uses plain stores
 //     (shared == 0: no zero fill, no atomics); otherwise chunks share `nslots` zero-filled slots through fp32 atomics.
 struct WgradPlan { int MTs, NTs, nrow, ncol, TKW, WK, shared; long rpc, nch, nslots; };
-static WgradPlan wgrad_plan(long rows, int cin, int cout, bool generic = false) {
+static WgradPlan wgrad_plan(long rows, int cin, int cout, bool generic = false, bool pooled = false) {
     WgradPlan p;
     const int mt = (cin + 31) / 32, nt = (cout + 31) / 32;
     p.nrow = (mt + 3) / 4; p.ncol = (nt + 3) / 4;
@@ -1220,7 +1247,13 @@ static WgradPlan wgrad_plan(long rows, int cin, int cout, bool generic = false) 
     const long BM = 32L * p.MTs, BN = 32L * p.NTs;
     long rpc_min = 4 * BM * BN / (BM + 2 * BN);            // input bytes of a chunk >= 2 x its partial-tile bytes
     if (rpc_min < 4L * p.TKW) rpc_min = 4L * p.TKW;
-    long chunks = ((long)GSPN_PLAN_CUS * 3) / ntile;          // upper target: 3 workgroups per CU
+    // workgroups per CU: 3 with two stage buffers, 2 when the kernel takes three (same condition as NBUF in wgrad_stream_kernel)
+    int bpc = 3;
+    if (!generic && !pooled && WGRAD_NBUF3) {
+        const long pa = p.TKW * BM / 4 / 64, pb = p.TKW * BN / 4 / 64, sf = (long)p.TKW * (BM + 2 * BN);
+        if (pa % 4 == 0 && pb % 4 == 0 && 3 * sf * 4 <= 80 * 1024 && pa / 4 + 2 * (pb / 4) <= 15) bpc = 2;
+    }
+    long chunks = ((long)GSPN_PLAN_CUS * bpc) / ntile;        // upper target: every workgroup resident at once
     if (chunks < 1) chunks = 1;
     const long by_size = rows / rpc_min;                    // chunks allowed by the size rule
     long floor_ch = GSPN_PLAN_CUS / ntile;                            // but never fewer than one workgroup per CU (if the layer has the rows)
@@ -1249,9 +1282,12 @@ static size_t ws_off_pp(long nch, int cin, int cout) { return (ws_off_gp(nch, ci
 static size_t ws_total(long nch, long nslots, int cin, int cout) { return ws_off_pp(nch, cin, cout) + sizeof(float) * (size_t)nslots * 2 * cin * cout; }
 extern "C" long gspn_mlp_bwd_work_bytes(long rows, int cin, int cout) {
     if (rows <= 0 || cin <= 0 || cout <= 0) return GSPN_ERR_ARG;
-    const WgradPlan p = wgrad_plan(rows, cin, cout), q = wgrad_plan(rows, cin, cout, true);
-    const size_t a = ws_total(p.nch, p.nslots, cin, cout), b = ws_total(q.nch, q.nslots, cin, cout);
-    return (long)(a > b ? a : b);
+    const WgradPlan p = wgrad_plan(rows, cin, cout), q = wgrad_plan(rows, cin, cout, true), r = wgrad_plan(rows, cin, cout, false, true);
+    size_t a = ws_total(p.nch, p.nslots, cin, cout);
+    const size_t b = ws_total(q.nch, q.nslots, cin, cout), c = ws_total(r.nch, r.nslots, cin, cout);
+    if (b > a) a = b;
+    if (c > a) a = c;
+    return (long)a;
 }
 
 // one WORKGROUP per channel index n in [0, max(cin,cout)): r0, r1 (and g3[n]) summed over chunks in double -> coefficients etc.
@@ -1358,7 +1394,7 @@ static WgradPlan wgrad_choose(long rows, int cin, int cout, const gspn_dy_args* 
     const bool pooled = a->dZ == nullptr;
     // streaming kernel: 16-byte aligned rows, 32-bit in-chunk offsets, pool groups that tile the stage
     bool use_stream = vec_ok(X, ldx) && vec_ok(a->Y, a->ldy) && (pooled || vec_ok(a->dZ, a->ldz)) && ldx >= 4 && cout >= 4;
-    WgradPlan p = wgrad_plan(rows, cin, cout, false);
+    WgradPlan p = wgrad_plan(rows, cin, cout, false, pooled);
     if (use_stream) {
         const long ldmax = ldx > a->ldy ? (ldx > a->ldz ? ldx : a->ldz) : (a->ldy > a->ldz ? a->ldy : a->ldz);
         if (p.rpc * ldmax >= (1L << 31)) use_stream = false;
