@@ -76,7 +76,7 @@ def main():
 
     store = tf_util.set_variable_store(tf_util.VariableStore(device=dev, seed=1234))   # same weights on every rank
     state = {"bucket": None, "opt": None, "i": 0, "pend": None}
-    geo = None if args.no_overlap else [GeometryStream(dev) for _ in range(DEPTH)]
+    geo = None if args.no_overlap else [GeometryStream(dev) for _ in range(DEPTH)]     # (default priority: a high-priority geometry queue starves the layers, 3.7 -> 8.1 ms per step)
     use_graph = geo is not None and not args.no_graph
     pend = {}                   # step index -> PendingGeometry
 
@@ -195,7 +195,7 @@ def main():
                        "schedule": "geometry inline" if args.no_overlap else ("geometry of batches k+1, k+2 on two side streams under the layers of batch k"
                                                                                + ("; fwd+bwd replayed from a hipGraph" if use_graph else "")),
                        "global_batch": global_batch, "npoints": NPOINTS, "parallelism": "dp%d (scenes sharded, one flat RCCL grad all-reduce)" % world},
-            "roofline": {"bound": "hbm", "kernel": "fps_cell_kernel<32,true> + its sort pre-pass (SA1: 8 x 32768 -> 2048)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "fps_cell_kernel<32,true> (SA1: 8 x 32768 -> 2048; its sort pre-pass, 0.07 ms, is timed outside the bracket)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_ms": fps_avg_ms, "launches_timed": len(fps_ms)},
             "host_enqueue_ms_per_step": t_host / args.steps * 1e3,

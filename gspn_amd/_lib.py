@@ -32,6 +32,8 @@ SIGNATURES = {
     "gspn_fps_background": [_I],
     "gspn_fps_cells": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
     "gspn_farthestpointsampling_cells": [_I, _I, _I, _P, _P, _P, _P],
+    "gspn_fps_cells_prepass": [_I, _I, _P, _P, _P],
+    "gspn_fps_cells_sample": [_I, _I, _I, _P, _P, _P, _P],
     "gspn_gatherpoint": [_I, _I, _I, _P, _P, _P, _P],
     "gspn_scatteraddpoint": [_I, _I, _I, _P, _P, _P, _P],
     "gspn_probsample": [_I, _I, _I, _P, _P, _P, _P, _P],

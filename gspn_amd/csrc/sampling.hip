@@ -806,11 +806,12 @@ extern "C" long gspn_fps_cells_ws_bytes(int b, int n) {
     if (b < 0 || n <= 0) return GSPN_ERR_ARG;
     return (long)b * n * (4 + 4 + 12);
 }
-// Drop-in for gspn_farthestpointsampling (identical output) for 64 <= n <= 32768: pre-pass + fps_cell_kernel, all on `stream`.
-extern "C" int gspn_farthestpointsampling_cells(int b, int n, int m, const float* inp, void* ws, int* out, void* stream) {
-    if (b < 0 || n <= 0 || m <= 0) return GSPN_ERR_ARG;
+// The two halves of gspn_farthestpointsampling_cells, separately callable (so that a caller can time the sampling kernel alone):
+// the spatial pre-pass that fills `ws` ...
+extern "C" int gspn_fps_cells_prepass(int b, int n, const float* inp, void* ws, void* stream) {
+    if (b < 0 || n <= 0) return GSPN_ERR_ARG;
     if (b == 0) return 0;
-    if (!inp || !ws || !out) return GSPN_ERR_ARG;
+    if (!inp || !ws) return GSPN_ERR_ARG;
     if (n > GSPN_FPS_RESIDENT_MAX || b > 65535) return GSPN_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     unsigned* keys = reinterpret_cast<unsigned*>(ws);
@@ -824,10 +825,28 @@ extern "C" int gspn_farthestpointsampling_cells(int b, int n, int m, const float
     else if (csz <= 512) hipLaunchKernelGGL(fps_cellsort_kernel<512>, g2, dim3(256), 0, st, n, csz, inp, keys, sxyz, perm);
     else if (csz <= 1024) hipLaunchKernelGGL(fps_cellsort_kernel<1024>, g2, dim3(512), 0, st, n, csz, inp, keys, sxyz, perm);
     else hipLaunchKernelGGL(fps_cellsort_kernel<2048>, g2, dim3(1024), 0, st, n, csz, inp, keys, sxyz, perm);
-    int rc = gspn_launch_status();
-    if (rc) return rc;
+    return gspn_launch_status();
+}
+// ... and the sampling kernel on a workspace the pre-pass has filled for the same (b, n, inp)
+extern "C" int gspn_fps_cells_sample(int b, int n, int m, const float* inp, const void* ws, int* out, void* stream) {
+    if (b < 0 || n <= 0 || m <= 0) return GSPN_ERR_ARG;
+    if (b == 0) return 0;
+    if (!inp || !ws || !out) return GSPN_ERR_ARG;
+    if (n > GSPN_FPS_RESIDENT_MAX || b > 65535) return GSPN_ERR_UNSUPPORTED;
+    const unsigned* keys = reinterpret_cast<const unsigned*>(ws);
+    const int* perm = reinterpret_cast<const int*>(keys + (size_t)b * n);
+    const float* sxyz = reinterpret_cast<const float*>(perm + (size_t)b * n);
     // original point 0 of scene i is inp[i*n*3 ..]: a strided view, the kernel only needs a pointer + stride -> pass inp with stride n*3
-    return gspn_fps_cells_strided(b, n, m, csz, sxyz, perm, inp, n * 3, out, stream);
+    return gspn_fps_cells_strided(b, n, m, (n + 15) / 16, sxyz, perm, inp, n * 3, out, stream);
+}
+// Drop-in for gspn_farthestpointsampling (identical output) for 64 <= n <= 32768: pre-pass + fps_cell_kernel, all on `stream`.
+extern "C" int gspn_farthestpointsampling_cells(int b, int n, int m, const float* inp, void* ws, int* out, void* stream) {
+    if (b < 0 || n <= 0 || m <= 0) return GSPN_ERR_ARG;
+    if (b == 0) return 0;
+    if (!inp || !ws || !out) return GSPN_ERR_ARG;
+    const int rc = gspn_fps_cells_prepass(b, n, inp, ws, stream);
+    if (rc) return rc;
+    return gspn_fps_cells_sample(b, n, m, inp, ws, out, stream);
 }
 
 extern "C" int gspn_farthestpointsampling(int b, int n, int m, const float* inp, float* temp, int* out, void* stream) {

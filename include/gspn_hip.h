@@ -54,6 +54,10 @@ int gspn_fps_cells(int b, int n, int m, int csz, const float* sxyz, const int* p
  * per-cell rank sort, two small kernels) and the cell kernel on `stream`.  ws: gspn_fps_cells_ws_bytes(b,n) bytes of scratch. */
 long gspn_fps_cells_ws_bytes(int b, int n);
 int gspn_farthestpointsampling_cells(int b, int n, int m, const float* inp, void* ws, int* out, void* stream);
+/* The two halves of gspn_farthestpointsampling_cells on the same workspace: the spatial pre-pass (counting sort into 16 cells + rank
+ * sort inside each cell) and the sampling kernel proper.  Calling them one after the other on one stream equals the combined call. */
+int gspn_fps_cells_prepass(int b, int n, const float* inp, void* ws, void* stream);
+int gspn_fps_cells_sample(int b, int n, int m, const float* inp, const void* ws, int* out, void* stream);
 
 /* gatherpointLauncher(b,n,m,inp,idx,out)  tf_sampling.cpp:125, tf_sampling_g.cu:206-208 */
 int gspn_gatherpoint(int b, int n, int m, const float* inp, const int* idx, float* out, void* stream);
