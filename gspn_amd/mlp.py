@@ -183,6 +183,63 @@ class _MlpStack(torch.autograd.Function):
         return (dx0, None, None) + tuple(grads)
 
 
+class _Linear(torch.autograd.Function):
+    """y = x.W + b with no batch-norm and no activation (tf_util.conv1d(..., activation_fn=None), e.g. model_rpointnet.py:71-73,262-263)
+    on the same kernels: the forward GEMM's raw output IS the result; backward runs the two passes with an always-open ReLU mask
+    (scale 0, shift 1) and use_bn = 0, so dY = dz."""
+
+    @staticmethod
+    def forward(ctx, x, cin, w, b):
+        lib = L.lib()
+        rows, ld = x.shape
+        cout = w.shape[1]
+        y = torch.empty((rows, cout), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            L.check(lib.gspn_mlp_fwd(rows, cin, cout, L.ptr(x), ld, None, None, L.ptr(w), L.ptr(b), L.ptr(y), cout, None, L.stream()), "mlp_fwd")
+        ctx.save_for_backward(x, w, y)
+        ctx.cin = cin
+        return y
+
+    @staticmethod
+    def backward(ctx, dz):
+        lib = L.lib()
+        x, w, y = ctx.saved_tensors
+        cin = ctx.cin
+        rows, ld = x.shape
+        cout = w.shape[1]
+        dz = dz.contiguous()
+        dev = dz.device
+        one = torch.ones(cout, dtype=torch.float32, device=dev)
+        zero = torch.zeros(cout, dtype=torch.float32, device=dev)
+        cA, cB, cC = torch.empty_like(one), torch.empty_like(one), torch.empty_like(one)
+        a = L.DyArgs()
+        a.Y, a.ldy = y.data_ptr(), cout
+        a.dZ, a.ldz, a.dPool, a.pool_arg, a.ns = dz.data_ptr(), cout, None, None, 0
+        a.scale, a.shift = zero.data_ptr(), one.data_ptr()          # 0*y + 1 > 0: every element passes
+        a.cA, a.cB, a.cC = cA.data_ptr(), cB.data_ptr(), cC.data_ptr()
+        dW = torch.empty_like(w)
+        dbias = torch.empty(cout, dtype=torch.float32, device=dev)
+        dx = None
+        with torch.cuda.device(dev):
+            work = torch.empty(int(lib.gspn_mlp_bwd_work_bytes(rows, cin, cout)) // 4 + 4, dtype=torch.float32, device=dev)
+            L.check(lib.gspn_mlp_bwd_wgrad(rows, cin, cout, ctypes.byref(a), L.ptr(x), ld, None, None, None, None, None, BN_EPS, 0, 0,
+                                           L.ptr(work), L.ptr(cA), L.ptr(cB), L.ptr(cC), None, None, L.ptr(dbias), L.ptr(dW), L.stream()), "mlp_bwd_wgrad")
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty((rows, ld), dtype=torch.float32, device=dev)
+                if ld > cin:
+                    dx.zero_()
+                L.check(lib.gspn_mlp_bwd_data(rows, cin, cout, ctypes.byref(a), L.ptr(w), L.ptr(dx), ld, L.stream()), "mlp_bwd_data")
+        return dx, None, dW, dbias
+
+
+def mlp_linear(x, cin, lp):
+    """x (rows, ld >= cin) -> x[:, :cin].W + b for a LayerParams without batch-norm."""
+    if lp.bn:
+        raise ValueError("mlp_linear is the no-BN, no-activation layer")
+    x = L.need(x, torch.float32, 2, "x")
+    return _Linear.apply(x, cin, lp.weights, lp.biases)
+
+
 def mlp_stack(x, cin, layers, is_training, bn_decay, pool_ns=None, grad_cols=None):
     """x: (rows, ld>=cin) float32 on a ROCm device.  Returns (rows/pool_ns, C_last) if pool_ns else (rows, C_last).
     grad_cols = (col0, ncols): the only columns of x whose gradient the caller will read (the rest of x.grad is left undefined)."""

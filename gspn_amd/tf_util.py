@@ -12,7 +12,7 @@ import math
 import torch
 
 from . import _lib as L
-from .mlp import LayerParams, mlp_stack
+from .mlp import mlp_linear, LayerParams, mlp_stack
 
 
 # --------------------------------------------------------------------------- variables / scopes
@@ -181,7 +181,9 @@ def fully_connected(inputs, num_outputs, scope, use_xavier=True, stddev=1e-3, we
 def _apply_layer(x2d, cin, lp, activation_fn, is_training, bn_decay):
     if activation_fn is torch.relu or activation_fn is torch.nn.functional.relu:
         return mlp_stack(x2d, cin, [lp], is_training, bn_decay, None)
-    raise NotImplementedError("only activation_fn=relu is implemented on the MFMA path (all SA/FP layers use it)")
+    if activation_fn is None and not lp.bn:
+        return mlp_linear(x2d, cin, lp)           # plain linear head (model_rpointnet.py:71-73, 262-263)
+    raise NotImplementedError("activation_fn must be relu, or None without batch-norm (the cases the set-abstraction path and its heads use)")
 
 
 def batch_norm_for_conv2d(inputs, is_training, bn_decay, scope, data_format='NHWC'):
