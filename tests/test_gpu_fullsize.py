@@ -1,0 +1,87 @@
+"""Parity at BASELINE.json's full sizes (configs[1] and [2]: 8 scenes x 32768 points): direct comparison with the C oracle where it
+finishes in seconds (multi-threaded over scenes), plus size-independent properties of the outputs."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from tests import data as D
+
+pytestmark = pytest.mark.gpu
+
+B, N = 8, 32768
+
+
+@pytest.fixture(scope="module")
+def scenes():
+    xyz = D.batch("U", B, N)
+    return xyz, torch.from_numpy(xyz).cuda()
+
+
+@pytest.mark.parametrize("m", [1024, 2048])          # config 1 (SA(1024, ...)) and config 2 (SA1 of pn2_fea_extractor)
+def test_fps_full_size_index_exact(scenes, m):
+    from gspn_amd.tf_sampling import farthest_point_sample
+    xyz, t = scenes
+    got = farthest_point_sample(m, t).cpu().numpy()
+    ref = O.farthest_point_sample(m, xyz, mt=True)
+    np.testing.assert_array_equal(got, ref)
+    # properties that do not need the oracle: starts at point 0, no repeats on distinct points, and the greedy invariant --
+    # the min-distance of every later pick to the earlier picks never increases
+    assert (got[:, 0] == 0).all()
+    assert all(len(np.unique(r)) == m for r in got)
+    p = torch.from_numpy(xyz[0][got[0]]).cuda().double()
+    d = torch.cdist(p, p)
+    tri = torch.tril(torch.ones(m, m, dtype=torch.bool, device=d.device), diagonal=-1)
+    mind = torch.where(tri, d, torch.full_like(d, float("inf"))).min(dim=1).values[1:]     # pick j vs picks < j
+    assert (mind[1:] <= mind[:-1] + 1e-6).all()
+
+
+@pytest.mark.parametrize("m,radius", [(1024, 0.1), (2048, 0.2)])
+def test_ball_query_full_size_index_exact(scenes, m, radius):
+    from gspn_amd.tf_grouping import query_ball_point
+    from gspn_amd.tf_sampling import farthest_point_sample, gather_point
+    xyz, t = scenes
+    new_xyz = gather_point(t, farthest_point_sample(m, t))
+    idx, cnt = query_ball_point(radius, 32, t, new_xyz)
+    ridx, rcnt = O.query_ball_point(radius, 32, xyz, new_xyz.cpu().numpy(), mt=True)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ridx)
+    np.testing.assert_array_equal(cnt.cpu().numpy(), rcnt)
+    # properties: the first cnt entries ascend strictly, the tail repeats the first hit, every hit is inside the ball
+    i64 = idx.long()
+    k = torch.arange(32, device=idx.device)[None, None, :]
+    live = k < cnt[..., None]
+    asc = (i64[..., 1:] > i64[..., :-1]) | ~live[..., 1:]
+    assert asc.all()
+    assert (torch.where(live, i64, i64[..., :1]) == i64).all()
+    g = torch.gather(t.unsqueeze(1).expand(-1, m, -1, -1), 2, i64.unsqueeze(-1).expand(-1, -1, -1, 3))
+    assert ((g - new_xyz.unsqueeze(2)).double().norm(dim=-1) < radius + 1e-6).all()
+
+
+def test_three_nn_full_size_exact(scenes):
+    from gspn_amd.tf_interpolate import three_nn
+    from gspn_amd.tf_sampling import farthest_point_sample, gather_point
+    xyz, t = scenes
+    l1 = gather_point(t, farthest_point_sample(2048, t))
+    dist, idx = three_nn(t, l1)
+    rd, ri = O.three_nn(xyz[:2], l1[:2].cpu().numpy())                 # the oracle is single-threaded: two scenes
+    np.testing.assert_array_equal(idx[:2].cpu().numpy(), ri)
+    np.testing.assert_array_equal(dist[:2].cpu().numpy(), rd)
+    assert (dist[..., 0] <= dist[..., 1]).all() and (dist[..., 1] <= dist[..., 2]).all()
+    # every sampled point is its own nearest neighbour at distance 0
+    assert (dist.amin(dim=-1) >= 0).all()
+
+
+def test_sa_module_full_size_batch_split_invariance(scenes):
+    """config 1: SA(1024, 0.1, 32, [64, 64, 128]) forward on 8 x 32768 points; with moving statistics every scene is independent, so the
+    batch of 8 must equal the two halves run separately, bit for bit"""
+    from gspn_amd import tf_util
+    from gspn_amd.pointnet_util import pointnet_sa_module
+    xyz, t = scenes
+    feat = torch.rand(B, N, 3, device="cuda")
+    tf_util.set_variable_store(tf_util.VariableStore(seed=77))
+    with torch.no_grad():
+        nx, npts, idx = pointnet_sa_module(t, feat, 1024, 0.1, 32, [64, 64, 128], None, False, False, None, 'sa')
+        outs = [pointnet_sa_module(t[h:h + 4], feat[h:h + 4], 1024, 0.1, 32, [64, 64, 128], None, False, False, None, 'sa') for h in (0, 4)]
+    assert npts.shape == (B, 1024, 128) and torch.isfinite(npts).all()
+    assert torch.equal(torch.cat([o[1] for o in outs]), npts)
+    assert torch.equal(torch.cat([o[2] for o in outs]), idx)
