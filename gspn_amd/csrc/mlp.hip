@@ -111,8 +111,14 @@ __device__ __forceinline__ DzRaw dz4_raw(const gspn_dy_args& a, long row, int co
         const int last = c - 1;
         const int* ar = a.pool_arg + (size_t)g * c;
         const float* dp = a.dPool + (size_t)g * c;
-        r.arg = make_int4(ar[min(col + 0, last)], ar[min(col + 1, last)], ar[min(col + 2, last)], ar[min(col + 3, last)]);
-        r.v = make_float4(dp[min(col + 0, last)], dp[min(col + 1, last)], dp[min(col + 2, last)], dp[min(col + 3, last)]);
+        if (VEC && (c & 3) == 0) {                           // (groups, c) rows are 16-byte aligned: one quad load each
+            const int kc = col < c ? col : 0;
+            r.arg = *reinterpret_cast<const int4*>(ar + kc);
+            r.v = *reinterpret_cast<const float4*>(dp + kc);
+        } else {
+            r.arg = make_int4(ar[min(col + 0, last)], ar[min(col + 1, last)], ar[min(col + 2, last)], ar[min(col + 3, last)]);
+            r.v = make_float4(dp[min(col + 0, last)], dp[min(col + 1, last)], dp[min(col + 2, last)], dp[min(col + 3, last)]);
+        }
     }
     return r;
 }
@@ -1631,7 +1637,8 @@ extern "C" int gspn_mlp_bwd_data_cols(long rows, int cin, int cout, const gspn_d
     hipStream_t st = (hipStream_t)stream;
     if (rows >= (1L << 31)) return GSPN_ERR_UNSUPPORTED;
     const bool pooled = a->dZ == nullptr;
-    const bool v = vec_ok(a->Y, a->ldy) && vec_ok(W, cout) && (pooled || vec_ok(a->dZ, a->ldz));
+    const bool v = vec_ok(a->Y, a->ldy) && vec_ok(W, cout) &&
+                   (pooled ? (((uintptr_t)a->dPool) % 16 == 0 && ((uintptr_t)a->pool_arg) % 16 == 0) : vec_ok(a->dZ, a->ldz));
     const int cend = col0 + ncols;
 #define BD_LAUNCH(BN_, V_, YT_)                                                                                                        \
     do {                                                                                                                               \
