@@ -1254,7 +1254,15 @@ static WgradPlan wgrad_plan(long rows, int cin, int cout, bool generic = false, 
     long rpc_min = 4 * BM * BN / (BM + 2 * BN);            // input bytes of a chunk >= 2 x its partial-tile bytes
     if (rpc_min < 4L * p.TKW) rpc_min = 4L * p.TKW;
     // workgroups per CU: 3 with two stage buffers, 2 when the kernel takes three (same condition as NBUF in wgrad_stream_kernel)
+    // (the configurations with >= 64 accumulator registers per wave, or 3 row tiles, are compiled for 2 waves per SIMD = 2 workgroups
+    //  per CU -- see the launch bounds of wgrad_stream_kernel; a grid sized for 3 would run a partial second wave)
     int bpc = 3;
+    if (!generic) {
+        const int T = p.MTs * p.NTs;
+        const int WKq = (T % 4 == 0) ? 1 : ((T % 2 == 0) ? 2 : 4);
+        const int tiles_per_wave = T * WKq / 4;
+        if (tiles_per_wave >= 2 || (pooled && p.TKW >= 32)) bpc = 2;
+    }
     if (!generic && !pooled && WGRAD_NBUF3) {
         const long pa = p.TKW * BM / 4 / 64, pb = p.TKW * BN / 4 / 64, sf = (long)p.TKW * (BM + 2 * BN);
         if (pa % 4 == 0 && pb % 4 == 0 && 3 * sf * 4 <= 80 * 1024 && pa / 4 + 2 * (pb / 4) <= 15) bpc = 2;
