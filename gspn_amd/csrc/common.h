@@ -77,11 +77,13 @@ static inline int gspn_launch_status() {
     return e == hipSuccess ? 0 : (int)e;
 }
 
-// CUs the persistent / statically partitioned kernels plan for.  MI355X has 256; the schedule this library is built around keeps
-// up to 16 of them busy with farthest point sampling of the NEXT batches on side streams (one CU per scene, geometry.py), and a grid
-// sized for exactly 256 CUs would then run its last workgroups as a second wave (measured: +12 % on the layers for 3 % of the CUs).
+// CUs the persistent / statically partitioned kernels plan for.  MI355X has 256 (8 XCDs x 32; workgroups go round-robin to the XCDs);
+// the schedule this library is built around keeps up to 16 of them busy with farthest point sampling of the NEXT batches on side
+// streams (one CU per scene, two streams: 2 per XCD), plus the short-lived 8-workgroup FPS launches of the smaller levels.  A grid sized
+// for exactly the CUs that happen to be free runs its last workgroups as a second wave, so the plan leaves 4 CUs per XCD out.
+// Measured on the full step (bench.py, ms per step): 256 -> 3.74, 240 -> 3.68, 224 -> 3.56, 216 -> 3.58, 208 -> 3.60, 192 -> 3.64.
 #ifndef GSPN_PLAN_CUS
-#define GSPN_PLAN_CUS 240
+#define GSPN_PLAN_CUS 224
 #endif
 
 // grid for a grid-stride kernel over `total` items: enough blocks to fill 256 CUs several times

@@ -76,3 +76,16 @@ with torch.cuda.stream(hi):
     print("hi-pri layers alone:                 %.3f ms" % timeit(lambda: (cap_hi.replay(), st["opt"].step())))
     print("hi-pri layers || FPS1:               %.3f ms" % timeit(side_hi(lambda x: farthest_point_sample(2048, x))))
     print("hi-pri layers || full geometry:      %.3f ms" % timeit(side_hi(pn2_geometry)))
+import ctypes
+spin = ctypes.CDLL('tools/libspin_probe.so')
+spin.launch_spin.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_void_p]
+outb = torch.zeros(4, device=dev)
+def spin_side(which, blocks, threads, iters):
+    def fn(x):
+        spin.launch_spin(which, blocks, threads, iters, outb.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    return fn
+print("--- layers (graph + adam) beside synthetic ~2.5 ms side kernels ---")
+for name, which, blocks, threads, iters in (("s_sleep 8 wg x 64", 1, 8, 64, 6000000), ("lds+barrier 8 wg x 1024 (128 KB LDS each)", 2, 8, 1024, 6000000),
+                                            ("valu loop + barrier 8 wg x 1024", 4, 8, 1024, 5200), ("valu loop + s_sleep, 128 VGPRs, 8 wg x 1024", 6, 8, 1024, 5200),
+                                            ("valu loop 8 wg x 256", 3, 8, 256, 20000)):
+    print("  side = %-46s alone %.3f ms; layers beside it: %.3f ms" % (name, timeit(lambda: spin_side(which, blocks, threads, iters)(None), 3), timeit(side(spin_side(which, blocks, threads, iters)))))
