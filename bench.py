@@ -84,7 +84,7 @@ def main():
         """forward + loss + backward of batch k with geometry g, gradients gathered into the flat bucket"""
         xyz, col = batches[k]
         out = pn2_fea_extractor(xyz, col, 'fea', True, 0.5, geometry=g)
-        loss = (out * gout).sum() * (1.0 / out.numel())
+        loss = torch.dot(out.reshape(-1), gout.reshape(-1)) * (1.0 / out.numel())     # one reduction kernel (no product tensor)
         loss.backward()
         if state["bucket"] is None:
             params = store.parameters()

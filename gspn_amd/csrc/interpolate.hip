@@ -194,3 +194,70 @@ extern "C" int gspn_fp_concat_grad(int b, int n, int m, int c2, int c1, int ld, 
     hipLaunchKernelGGL(fp_concat_grad_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, total, n, m, c2, c1, ld, grad_out, idx, weight, grad_points2, grad_points1);
     return gspn_launch_status();
 }
+
+// fp_concat gradient without atomics: the caller supplies, per scene, the (dense point, neighbour slot) pairs grouped by sparse point
+// -- `order` (b, 3n): positions p = 3*i + t into the flattened idx array, sorted by idx[p] with ties in ascending p; `offsets` (b, m+1):
+// the range of `order` that belongs to each sparse point (coordinate-only data, built once per batch next to the 3-NN search).
+// One wave per (scene, sparse point, 64-channel chunk), lane = channel: the contributions of a sparse point are added in ascending
+// (i, t), which is exactly the order of the reference's sequential loop (tf_interpolate.cpp:131-153) -- bit-identical sums, no
+// atomics, and each 256-byte row segment of grad_out is read once per use.
+__global__ __launch_bounds__(256) void fp_concat_grad_csr_kernel(int n, int m, int c2, int c1, int ld, const float* __restrict__ g,
+                                                                 const int* __restrict__ order, const int* __restrict__ offsets,
+                                                                 const float* __restrict__ weight, float* __restrict__ grad_points2,
+                                                                 float* __restrict__ grad_points1, long nwaves2, long copy_total) {
+    const int lane = threadIdx.x & 63;
+    const long wv = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int chunks = (c2 + 63) / 64;
+    if (wv < nwaves2) {
+        if (!grad_points2) return;
+        const int ch = (int)(wv % chunks);
+        const long sj = wv / chunks;                        // scene * m + j
+        const int scene = (int)(sj / m), j = (int)(sj - (long)scene * m);
+        const int l = ch * 64 + lane;
+        const int* off = offsets + (size_t)scene * (m + 1);
+        const int e0 = off[j], e1 = off[j + 1];
+        const int* ord = order + (size_t)scene * 3 * n;
+        const float* w = weight + (size_t)scene * 3 * n;
+        const float* gs = g + (size_t)scene * n * ld;
+        const bool act = l < c2;
+        const int lc = act ? l : 0;
+        float acc = 0.f;
+        int e = e0;
+        for (; e + 3 < e1; e += 4) {                         // 4 independent row loads in flight, added in order
+            const int p0 = ord[e], p1 = ord[e + 1], p2 = ord[e + 2], p3 = ord[e + 3];
+            const float v0 = gs[(size_t)(p0 / 3) * ld + lc], v1 = gs[(size_t)(p1 / 3) * ld + lc];
+            const float v2 = gs[(size_t)(p2 / 3) * ld + lc], v3 = gs[(size_t)(p3 / 3) * ld + lc];
+            acc += v0 * w[p0];
+            acc += v1 * w[p1];
+            acc += v2 * w[p2];
+            acc += v3 * w[p3];
+        }
+        for (; e < e1; ++e) {
+            const int p = ord[e];
+            acc += gs[(size_t)(p / 3) * ld + lc] * w[p];
+        }
+        if (act) grad_points2[((size_t)scene * m + j) * c2 + l] = acc;
+    } else if (grad_points1) {
+        // the points1 columns are a plain slice of grad_out
+        const long nthreads = ((long)gridDim.x * 4 - nwaves2) * 64;
+        for (long i = (wv - nwaves2) * 64 + lane; i < copy_total; i += nthreads) {
+            const long row = i / c1;
+            const int l = (int)(i - row * c1);
+            grad_points1[i] = g[row * ld + c2 + l];
+        }
+    }
+}
+extern "C" int gspn_fp_concat_grad_csr(int b, int n, int m, int c2, int c1, int ld, const float* grad_out, const int* order, const int* offsets,
+                                       const float* weight, float* grad_points2, float* grad_points1, void* stream) {
+    if (b < 0 || n < 0 || m <= 0 || c2 <= 0 || c1 < 0 || ld < c2 + c1 || !order || !offsets || !weight) return GSPN_ERR_ARG;
+    if (b == 0 || n == 0) return 0;
+    const long nwaves2 = (long)b * m * ((c2 + 63) / 64);
+    const long copy_total = grad_points1 ? (long)b * n * c1 : 0;
+    long copy_waves = (copy_total + 64 * 16 - 1) / (64 * 16);          // ~16 elements per lane
+    if (copy_waves > 8192) copy_waves = 8192;
+    const long blocks = (nwaves2 + copy_waves + 3) / 4;
+    if (blocks > 0x7FFFFFFFl) return GSPN_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(fp_concat_grad_csr_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n, m, c2, c1, ld, grad_out, order, offsets,
+                       weight, grad_points2, grad_points1, nwaves2, copy_total);
+    return gspn_launch_status();
+}

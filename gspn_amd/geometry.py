@@ -33,14 +33,15 @@ class SAGeometry:
 
 
 class FPGeometry:
-    """idx (b,n1,3) int32 and weight (b,n1,3) float32 of pointnet_util.py:155-160"""
-    __slots__ = ("idx", "weight")
+    """idx (b,n1,3) int32 and weight (b,n1,3) float32 of pointnet_util.py:155-160, plus the inverse lists the gradient of the
+    interpolation gathers through: order (b, 3*n1) int32 = positions 3*i+t sorted by idx (ties ascending), offsets (b, n2+1) int32."""
+    __slots__ = ("idx", "weight", "order", "offsets")
 
-    def __init__(self, idx, weight):
-        self.idx, self.weight = idx, weight
+    def __init__(self, idx, weight, order=None, offsets=None):
+        self.idx, self.weight, self.order, self.offsets = idx, weight, order, offsets
 
     def tensors(self):
-        return [self.idx, self.weight]
+        return [t for t in (self.idx, self.weight, self.order, self.offsets) if t is not None]
 
 
 def sa_geometry(xyz, npoint, radius, nsample, knn=False):
@@ -61,7 +62,13 @@ def fp_geometry(xyz1, xyz2):
     dist = torch.clamp(dist, min=1e-10)                               # :157
     norm = (1.0 / dist).sum(dim=2, keepdim=True)                      # :158
     weight = (1.0 / dist) / norm                                      # :160
-    return FPGeometry(idx, weight)
+    # inverse lists for the gradient (three_interpolate_grad as a gather in the reference's own summation order)
+    b, n1, _ = idx.shape
+    n2 = xyz2.shape[1]
+    keys, order = torch.sort(idx.reshape(b, 3 * n1), dim=1, stable=True)
+    bounds = torch.arange(n2 + 1, device=idx.device, dtype=keys.dtype).unsqueeze(0).expand(b, -1).contiguous()
+    offsets = torch.searchsorted(keys.contiguous(), bounds).to(torch.int32)
+    return FPGeometry(idx, weight, order.to(torch.int32).contiguous(), offsets.contiguous())
 
 
 class PendingGeometry:

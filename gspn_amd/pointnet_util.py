@@ -54,7 +54,7 @@ class _FpConcat(torch.autograd.Function):
     16-byte row pitch, in one kernel; gradients: scatter-add to points2 (as three_interpolate_grad), slice to points1."""
 
     @staticmethod
-    def forward(ctx, points2, idx, weight, points1):
+    def forward(ctx, points2, idx, weight, points1, order, offsets):
         b, m, c2 = points2.shape
         n = idx.shape[1]
         c1 = 0 if points1 is None else points1.shape[2]
@@ -63,25 +63,29 @@ class _FpConcat(torch.autograd.Function):
         with torch.cuda.device(points2.device):
             L.check(L.lib().gspn_fp_concat(b, n, m, c2, c1, L.ptr(points2), L.ptr(idx), L.ptr(weight), L.ptr(points1), ld, L.ptr(out), L.stream()),
                     "fp_concat")
-        ctx.save_for_backward(idx, weight)
+        ctx.save_for_backward(idx, weight, order, offsets)
         ctx.dims = (b, n, m, c2, c1, ld)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        idx, weight = ctx.saved_tensors
+        idx, weight, order, offsets = ctx.saved_tensors
         b, n, m, c2, c1, ld = ctx.dims
         g = g.contiguous()
         g2 = torch.empty((b, m, c2), dtype=torch.float32, device=g.device) if ctx.needs_input_grad[0] else None
         g1 = torch.empty((b, n, c1), dtype=torch.float32, device=g.device) if (c1 > 0 and ctx.needs_input_grad[3]) else None
         if g2 is not None or g1 is not None:
             with torch.cuda.device(g.device):
-                L.check(L.lib().gspn_fp_concat_grad(b, n, m, c2, c1, ld, L.ptr(g), L.ptr(idx), L.ptr(weight), L.ptr(g2), L.ptr(g1), L.stream()),
-                        "fp_concat_grad")
-        return g2, None, None, g1
+                if order is not None:       # gather through the inverse lists: no atomics, the reference's summation order
+                    L.check(L.lib().gspn_fp_concat_grad_csr(b, n, m, c2, c1, ld, L.ptr(g), L.ptr(order), L.ptr(offsets), L.ptr(weight),
+                                                            L.ptr(g2), L.ptr(g1), L.stream()), "fp_concat_grad_csr")
+                else:
+                    L.check(L.lib().gspn_fp_concat_grad(b, n, m, c2, c1, ld, L.ptr(g), L.ptr(idx), L.ptr(weight), L.ptr(g2), L.ptr(g1), L.stream()),
+                            "fp_concat_grad")
+        return g2, None, None, g1, None, None
 
 
-def fp_concat(points2, idx, weight, points1):
+def fp_concat(points2, idx, weight, points1, order=None, offsets=None):
     points2 = L.need(points2, torch.float32, 3, "points2")
     idx = L.need(idx, torch.int32, 3, "idx")
     weight = L.need(weight.detach(), torch.float32, 3, "weight")
@@ -94,7 +98,10 @@ def fp_concat(points2, idx, weight, points1):
         raise ValueError("ThreeInterpolate expects (b,n,3) weight shape")                   # tf_interpolate.cpp:203
     if points1 is not None and (points1.shape[0] != b or points1.shape[1] != idx.shape[1]):
         raise ValueError("pointnet_fp_module: points1 must be (b, n1, c1)")
-    return _FpConcat.apply(points2, idx, weight, points1)
+    if order is not None:
+        order = L.need(order, torch.int32, 2, "order")
+        offsets = L.need(offsets, torch.int32, 2, "offsets")
+    return _FpConcat.apply(points2, idx, weight, points1, order, offsets)
 
 
 def group_concat(xyz, new_xyz, points, idx, xyz_first=True):
@@ -218,7 +225,7 @@ def pointnet_fp_module(xyz1, xyz2, points1, points2, mlp, is_training, bn_decay,
         # fused: interpolate + concat + 16-byte row pitch in one pass, straight into the MLP's input matrix
         b, n1 = idx.shape[0], idx.shape[1]
         cin = points2.shape[2] + (0 if points1 is None else points1.shape[2])
-        x2d = fp_concat(points2, idx, weight, points1)
+        x2d = fp_concat(points2, idx, weight, points1, geometry.order, geometry.offsets)
         layers = _mlp_layers(mlp, cin, 'conv_', bn)
         # fp_concat's gradient reads the points1 columns only if points1 wants a gradient (the last FP level gets raw colours)
         c2 = points2.shape[2]

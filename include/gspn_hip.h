@@ -118,6 +118,11 @@ int gspn_fp_concat(int b, int n, int m, int c2, int c1, const float* points2, co
                    const float* points1, int ld, float* out, void* stream);
 int gspn_fp_concat_grad(int b, int n, int m, int c2, int c1, int ld, const float* grad_out, const int* idx, const float* weight,
                         float* grad_points2, float* grad_points1, void* stream);
+/* The same gradient without atomics, in the reference's summation order (bit-identical to its sequential loop): `order` (b, 3n) holds the
+ * positions p = 3*i + t of the flattened idx array sorted by idx[p] (ties in ascending p), `offsets` (b, m+1) the range of each sparse
+ * point in it -- coordinate-only data a caller builds once per batch (gspn_amd/geometry.py: fp_geometry). */
+int gspn_fp_concat_grad_csr(int b, int n, int m, int c2, int c1, int ld, const float* grad_out, const int* order, const int* offsets,
+                            const float* weight, float* grad_points2, float* grad_points1, void* stream);
 
 /* ---------------- tf_ops/nn_distance -------------------------------------------------- */
 

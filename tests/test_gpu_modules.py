@@ -280,3 +280,27 @@ def test_fp_module_grad_cols_shortcut_is_exact():
         out.square().mean().backward()
         grads.append(p2.grad.clone())
     assert rel_err(grads[1], grads[0]) < 1e-6
+
+
+@pytest.mark.parametrize("b,n1,n2,c1,c2", [(2, 1500, 300, 3, 64), (1, 700, 90, 0, 33), (2, 512, 128, 64, 130)])
+def test_fp_concat_gather_gradient_is_bit_exact_vs_reference_order(b, n1, n2, c1, c2):
+    """with the inverse lists of fp_geometry the interpolation gradient is a gather in the reference's own summation order
+    (tf_interpolate.cpp:131-153): identical bits to the C oracle, no atomics"""
+    from gspn_amd.geometry import fp_geometry
+    from gspn_amd.pointnet_util import fp_concat
+    g = torch.Generator(device="cpu").manual_seed(n1 + c2)
+    xyz1 = torch.rand(b, n1, 3, generator=g).cuda()
+    xyz2 = torch.rand(b, n2, 3, generator=g).cuda()
+    geo = fp_geometry(xyz1, xyz2)
+    assert geo.order.shape == (b, 3 * n1) and geo.offsets.shape == (b, n2 + 1)
+    assert (geo.offsets[:, 0] == 0).all() and (geo.offsets[:, -1] == 3 * n1).all()
+    p2 = torch.randn(b, n2, c2, generator=g).cuda().requires_grad_(True)
+    p1 = torch.randn(b, n1, c1, generator=g).cuda().requires_grad_(True) if c1 else None
+    out = fp_concat(p2, geo.idx, geo.weight, p1, geo.order, geo.offsets)
+    go = torch.randn(out.shape, generator=g).cuda()
+    out.backward(go)
+    gi = go[:, :c2].reshape(b, n1, c2).contiguous().cpu().numpy()
+    ref = O.three_interpolate_grad(p2.detach().cpu().numpy(), geo.idx.cpu().numpy(), geo.weight.cpu().numpy(), gi)
+    np.testing.assert_array_equal(p2.grad.cpu().numpy(), ref)
+    if c1:
+        assert torch.equal(p1.grad, go[:, c2:c2 + c1].reshape(b, n1, c1))
