@@ -91,7 +91,7 @@ def main():
             state["bucket"] = parallel.FlatGradBucket(params)
             state["opt"] = torch.optim.Adam(params, lr=1e-3, fused=True)     # one multi-tensor kernel for the whole update
         state["bucket"].flatten()
-        return loss
+        return loss.detach()          # (a live loss would keep the autograd graph -- and its AccumulateGrad nodes -- alive across captures)
 
     def finish():
         state["bucket"].all_reduce()                 # one flat RCCL all-reduce (no-op at world 1)

@@ -15,8 +15,9 @@ import torch
 
 class CapturedStep:
     def __init__(self, fn, warmup=2, pool=None):
-        """fn(): enqueue the step on the current stream, return a tensor (e.g. the loss) or None.  It is run `warmup`
-        times eagerly on a side stream (lazy initialisation, variable creation), then captured."""
+        """fn(): enqueue the step on the current stream, return a DETACHED tensor (e.g. loss.detach()) or None -- a result that still
+        carries its autograd graph keeps that graph's AccumulateGrad nodes alive into the next capture.  fn is run `warmup` times
+        eagerly on a side stream (lazy initialisation, variable creation), then captured."""
         self.graph = torch.cuda.CUDAGraph()
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()
