@@ -15,51 +15,117 @@
 #define NN_TILE 1024
 #define NN_BLOCK 256
 
+// NN_Q queries per lane (1: measured on MI355X, 2 per lane halves the LDS reads but runs 1.8x slower -- half the waves, and a batch now
+// takes the slow path when either query passes).  The scan is latency-bound per wave, not VALU-bound: what pays is testing NN_B
+// candidates per branch (independent rejection values, one compare) instead of one data-dependent branch per candidate.
+#define NN_Q 1
+#define NN_B 8             // candidates tested per branch: the rejection values of a batch are independent (ILP), one compare decides
 __global__ __launch_bounds__(NN_BLOCK) void three_nn_kernel(int b, int n, int m, const float* __restrict__ xyz1, const float* __restrict__ xyz2,
                                                             float* __restrict__ dist, int* __restrict__ idx) {
-    __shared__ float4 tile[NN_TILE];
+    __shared__ float4 tile[NN_TILE + NN_B];
+    __shared__ float tile_pm[NN_BLOCK / 64];
     const int scene = blockIdx.x % b;               // scene <-> XCD affinity for the sparse cloud
-    const int j = (blockIdx.x / b) * NN_BLOCK + threadIdx.x;
-    const bool live = j < n;
-    float x1 = 0.f, y1 = 0.f, z1 = 0.f;
-    if (live) {
-        const float* q = xyz1 + ((size_t)scene * n + j) * 3;
-        x1 = q[0]; y1 = q[1]; z1 = q[2];
+    const int j0 = (blockIdx.x / b) * (NN_BLOCK * NN_Q) + threadIdx.x;      // queries j0 + u*NN_BLOCK
+    float x1[NN_Q], y1[NN_Q], z1[NN_Q];
+#pragma unroll
+    for (int u = 0; u < NN_Q; ++u) {
+        const int j = j0 + u * NN_BLOCK;
+        x1[u] = y1[u] = z1[u] = 0.f;
+        if (j < n) {
+            const float* q = xyz1 + ((size_t)scene * n + j) * 3;
+            x1[u] = q[0]; y1[u] = q[1]; z1[u] = q[2];
+        }
     }
     // double best=1e40 in the reference (:66): any finite float is smaller, +inf/NaN are not ->
     // identical to a float +inf initialiser; (float)1e40 == +inf on output (:91-96)
-    float b1 = INFINITY, b2 = INFINITY, b3 = INFINITY;
-    int i1 = 0, i2 = 0, i3 = 0;
+    float b1[NN_Q], b2[NN_Q], b3[NN_Q];
+    int i1[NN_Q], i2[NN_Q], i3[NN_Q];
+    // Exact search, cheap rejection: a candidate can only enter the top three if d < b3.  d = |p|^2 - 2 p.q + |q|^2, so the test
+    // "|p|^2 - 2 p.q < b3 - |q|^2 + margin" (3 FMAs against a per-lane threshold, |p|^2 precomputed in the tile) never rejects such a
+    // candidate as long as `margin` covers the rounding of both evaluations; survivors are re-evaluated with the reference's own
+    // expression and compared exactly as before.
+    float qx2[NN_Q], qy2[NN_Q], qz2[NN_Q], qq[NN_Q], qn[NN_Q], thr[NN_Q], margin[NN_Q];
+#pragma unroll
+    for (int u = 0; u < NN_Q; ++u) {
+        b1[u] = b2[u] = b3[u] = INFINITY;
+        i1[u] = i2[u] = i3[u] = 0;
+        qx2[u] = -2.f * x1[u]; qy2[u] = -2.f * y1[u]; qz2[u] = -2.f * z1[u];
+        qq[u] = __builtin_fmaf(x1[u], x1[u], __builtin_fmaf(y1[u], y1[u], z1[u] * z1[u]));
+        qn[u] = sqrtf(qq[u]);
+        thr[u] = INFINITY;
+        margin[u] = 0.f;
+    }
     const float* sp = xyz2 + (size_t)scene * m * 3;
     for (int k0 = 0; k0 < m; k0 += NN_TILE) {
         const int cnt = min(NN_TILE, m - k0);
         __syncthreads();
-        for (int t = threadIdx.x; t < cnt; t += NN_BLOCK)
-            tile[t] = make_float4(sp[(size_t)(k0 + t) * 3 + 0], sp[(size_t)(k0 + t) * 3 + 1], sp[(size_t)(k0 + t) * 3 + 2], 0.f);
+        float pm = 0.f;
+        for (int t = threadIdx.x; t < cnt; t += NN_BLOCK) {
+            const float px = sp[(size_t)(k0 + t) * 3 + 0], py = sp[(size_t)(k0 + t) * 3 + 1], pz = sp[(size_t)(k0 + t) * 3 + 2];
+            const float pw = __builtin_fmaf(px, px, __builtin_fmaf(py, py, pz * pz));
+            tile[t] = make_float4(px, py, pz, pw);
+            pm = fmaxf(pm, pw);
+        }
+        // largest |p|^2 of the tile (bounds the rounding error of the rejection test for every candidate in it)
+        for (int s_ = 32; s_ >= 1; s_ >>= 1) pm = fmaxf(pm, __shfl_xor(pm, s_, 64));
+        if ((threadIdx.x & 63) == 0) tile_pm[threadIdx.x >> 6] = pm;
         __syncthreads();
-#pragma unroll 4
-        for (int k = 0; k < cnt; ++k) {
-            const float4 p = tile[k];
-            const float d = dist2_host(p.x - x1, p.y - y1, p.z - z1);        // :74
-            if (d < b3) {                                                   // rare after warm-up
-                const int kk = k0 + k;
-                if (d < b1) { b3 = b2; i3 = i2; b2 = b1; i2 = i1; b1 = d; i1 = kk; }
-                else if (d < b2) { b3 = b2; i3 = i2; b2 = d; i2 = kk; }
-                else { b3 = d; i3 = kk; }
+        pm = fmaxf(fmaxf(tile_pm[0], tile_pm[1]), fmaxf(tile_pm[2], tile_pm[3]));
+#pragma unroll
+        for (int u = 0; u < NN_Q; ++u) {
+            const float r = sqrtf(pm) + qn[u];
+            margin[u] = 4e-6f * r * r;                   // >> 8 ulp of (|p| + |q|)^2: both evaluations err by a few ulp of that scale
+            thr[u] = (b3[u] - qq[u]) + margin[u];        // +inf while fewer than three candidates were seen
+        }
+        // pad the tile to a whole batch with candidates that can never pass (|p|^2 = +inf)
+        for (int t = cnt + threadIdx.x; t < ((cnt + NN_B - 1) / NN_B) * NN_B; t += NN_BLOCK) tile[t] = make_float4(0.f, 0.f, 0.f, INFINITY);
+        __syncthreads();
+        for (int k = 0; k < cnt; k += NN_B) {
+            float4 p[NN_B];
+#pragma unroll
+            for (int v = 0; v < NN_B; ++v) p[v] = tile[k + v];
+#pragma unroll
+            for (int u = 0; u < NN_Q; ++u) {
+                float sd[NN_B];
+#pragma unroll
+                for (int v = 0; v < NN_B; ++v)
+                    sd[v] = __builtin_fmaf(p[v].x, qx2[u], __builtin_fmaf(p[v].y, qy2[u], __builtin_fmaf(p[v].z, qz2[u], p[v].w)));
+                float smin = sd[0];
+#pragma unroll
+                for (int v = 1; v < NN_B; ++v) smin = fminf(smin, sd[v]);
+                if (smin < thr[u]) {                                                // rare after warm-up: walk the batch in index order
+#pragma unroll
+                    for (int v = 0; v < NN_B; ++v) {
+                        if (sd[v] < thr[u]) {
+                            const float d = dist2_host(p[v].x - x1[u], p[v].y - y1[u], p[v].z - z1[u]);   // :74, the reference's expression
+                            if (d < b3[u]) {
+                                const int kk = k0 + k + v;
+                                if (d < b1[u]) { b3[u] = b2[u]; i3[u] = i2[u]; b2[u] = b1[u]; i2[u] = i1[u]; b1[u] = d; i1[u] = kk; }
+                                else if (d < b2[u]) { b3[u] = b2[u]; i3[u] = i2[u]; b2[u] = d; i2[u] = kk; }
+                                else { b3[u] = d; i3[u] = kk; }
+                                thr[u] = (b3[u] - qq[u]) + margin[u];
+                            }
+                        }
+                    }
+                }
             }
         }
     }
-    if (live) {
-        float* od = dist + ((size_t)scene * n + j) * 3;
-        int* oi = idx + ((size_t)scene * n + j) * 3;
-        od[0] = b1; od[1] = b2; od[2] = b3;
-        oi[0] = i1; oi[1] = i2; oi[2] = i3;
+#pragma unroll
+    for (int u = 0; u < NN_Q; ++u) {
+        const int j = j0 + u * NN_BLOCK;
+        if (j < n) {
+            float* od = dist + ((size_t)scene * n + j) * 3;
+            int* oi = idx + ((size_t)scene * n + j) * 3;
+            od[0] = b1[u]; od[1] = b2[u]; od[2] = b3[u];
+            oi[0] = i1[u]; oi[1] = i2[u]; oi[2] = i3[u];
+        }
     }
 }
 extern "C" int gspn_threenn(int b, int n, int m, const float* xyz1, const float* xyz2, float* dist, int* idx, void* stream) {
     if (b < 0 || n < 0 || m < 0) return GSPN_ERR_ARG;
     if (b == 0 || n == 0) return 0;
-    const long long blocks = (long long)b * ((n + NN_BLOCK - 1) / NN_BLOCK);
+    const long long blocks = (long long)b * ((n + NN_BLOCK * NN_Q - 1) / (NN_BLOCK * NN_Q));
     if (blocks > 0x7FFFFFFFll) return GSPN_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(three_nn_kernel, dim3((unsigned)blocks), dim3(NN_BLOCK), 0, (hipStream_t)stream, b, n, m, xyz1, xyz2, dist, idx);
     return gspn_launch_status();
