@@ -85,3 +85,50 @@ def test_sa_module_full_size_batch_split_invariance(scenes):
     assert npts.shape == (B, 1024, 128) and torch.isfinite(npts).all()
     assert torch.equal(torch.cat([o[1] for o in outs]), npts)
     assert torch.equal(torch.cat([o[2] for o in outs]), idx)
+
+
+def test_nn_distance_config4_shape_exact():
+    """BASELINE config 3 (C4 of SURVEY 8): Chamfer nn_distance on (B*NUM_SAMPLE, 512, 3) pairs -- 2048 clouds per GPU.  The oracle
+    (tf_nndistance_g.cu:5-127 restated) checks a slab of clouds bit for bit; the rest is checked through the definition's invariants."""
+    from gspn_amd.tf_nndistance import nn_distance
+    rng = np.random.default_rng(11)
+    nb, n = 2048, 512
+    a = rng.standard_normal((nb, n, 3)).astype(np.float32)
+    c = (a[:, rng.permutation(n)] + 0.05 * rng.standard_normal((nb, n, 3))).astype(np.float32)
+    d1, i1, d2, i2 = nn_distance(torch.from_numpy(a).cuda(), torch.from_numpy(c).cuda())
+    r1, ri1, r2, ri2 = O.nn_distance(a[:96], c[:96])
+    np.testing.assert_array_equal(i1[:96].cpu().numpy(), ri1)
+    np.testing.assert_array_equal(i2[:96].cpu().numpy(), ri2)
+    np.testing.assert_array_equal(d1[:96].cpu().numpy(), r1)
+    np.testing.assert_array_equal(d2[:96].cpu().numpy(), r2)
+    # invariants on all 2048 clouds: the reported distance is the distance to the reported index, and no other point is closer
+    ta, tc = torch.from_numpy(a).cuda().double(), torch.from_numpy(c).cuda().double()
+    full = torch.cdist(ta, tc) ** 2
+    got = torch.gather(full, 2, i1.long().unsqueeze(-1)).squeeze(-1)
+    assert torch.allclose(got, d1.double(), rtol=1e-5, atol=1e-7)
+    assert (full.min(dim=2).values >= d1.double() * (1 - 1e-5) - 1e-7).all()
+    assert (full.min(dim=1).values >= d2.double() * (1 - 1e-5) - 1e-7).all()
+
+
+def test_multi_encoding_net_config4_shape(scenes):
+    """the context encoder of the proposal head at its real shape (model_rpointnet.py:377: 256 seeds, radii .5/1/1.5, nsample
+    256/256/512, mlp [64,128,256] x 3, use_xyz) on 32768-point scenes: ball-query indices exact vs the oracle, outputs finite, and with
+    moving statistics the batch splits exactly (every scene independent)"""
+    from gspn_amd import tf_util
+    from gspn_amd.proposal_head import multi_encoding_net
+    from gspn_amd.tf_grouping import query_ball_point
+    xyz, t = scenes
+    t4, x4 = t[:4].contiguous(), xyz[:4]
+    feat = torch.rand(4, N, 3, device="cuda")
+    tf_util.set_variable_store(tf_util.VariableStore(seed=5))
+    args = (256, [0.5, 1.0, 1.5], [256, 256, 512], [[64, 128, 256]] * 3, [], False, None, 'enc')
+    with torch.no_grad():
+        new_xyz, new_points, _, fps_idx = multi_encoding_net(t4, feat, *args, use_xyz=True)
+        halves = [multi_encoding_net(t4[h:h + 2], feat[h:h + 2], *args, use_xyz=True) for h in (0, 2)]
+    assert new_points.shape == (4, 256, 768) and torch.isfinite(new_points).all()
+    np.testing.assert_array_equal(fps_idx.cpu().numpy(), O.farthest_point_sample(256, x4, mt=True))
+    assert torch.equal(torch.cat([h[1] for h in halves]), new_points)
+    idx, cnt = query_ball_point(1.5, 512, t4, new_xyz)
+    ridx, rcnt = O.query_ball_point(1.5, 512, x4, new_xyz.cpu().numpy(), mt=True)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ridx)
+    np.testing.assert_array_equal(cnt.cpu().numpy(), rcnt)
