@@ -48,9 +48,25 @@ extern "C" __global__ void loop_valu_barrier(long long iters, float* out) {
     for (long long it = 0; it < iters; ++it) { for (int i = 0; i < 64; ++i) a = a * b + 0.5f; __syncthreads(); }
     if (a == 1.2345f) out[0] = a;
 }
+// occupancy-only side kernels: hold a CU's LDS (or all of its vector registers) while doing nothing
+extern "C" __global__ void hold_lds(long long cycles, float* out) {
+    extern __shared__ float lds[];
+    if (threadIdx.x == 0) lds[0] = 1.f;
+    long long t0 = clock64();
+    while (clock64() - t0 < cycles) { __builtin_amdgcn_s_sleep(64); }
+    if (cycles == 1) out[0] = lds[0];
+}
+extern "C" __global__ __launch_bounds__(1024) void hold_vgpr(long long cycles, float* out) {
+    asm volatile("v_mov_b32 v127, 0" ::: "v127");
+    long long t0 = clock64();
+    while (clock64() - t0 < cycles) { __builtin_amdgcn_s_sleep(64); }
+    if (cycles == 1) out[0] = 1.f;
+}
 extern "C" int launch_spin(int which, int blocks, int threads, long long cycles, float* out, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    if (which == 6) hipLaunchKernelGGL(loop_valu_yield<0>, dim3(blocks), dim3(threads), 0, st, cycles, out);
+    if (which == 9) { hipFuncSetAttribute(reinterpret_cast<const void*>(&hold_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 131072); hipLaunchKernelGGL(hold_lds, dim3(blocks), dim3(threads), 131072, st, cycles, out); }
+    else if (which == 10) hipLaunchKernelGGL(hold_vgpr, dim3(blocks), dim3(threads), 0, st, cycles, out);
+    else if (which == 6) hipLaunchKernelGGL(loop_valu_yield<0>, dim3(blocks), dim3(threads), 0, st, cycles, out);
     else if (which == 7) hipLaunchKernelGGL(loop_valu_yield<1>, dim3(blocks), dim3(threads), 0, st, cycles, out);
     else if (which == 8) hipLaunchKernelGGL(loop_valu_yield<2>, dim3(blocks), dim3(threads), 0, st, cycles, out);
     else if (which == 5) hipLaunchKernelGGL(loop_valu_fullregs, dim3(blocks), dim3(threads), 0, st, cycles, out);

@@ -85,7 +85,8 @@ def spin_side(which, blocks, threads, iters):
         spin.launch_spin(which, blocks, threads, iters, outb.data_ptr(), torch.cuda.current_stream().cuda_stream)
     return fn
 print("--- layers (graph + adam) beside synthetic ~2.5 ms side kernels ---")
-for name, which, blocks, threads, iters in (("s_sleep 8 wg x 64", 1, 8, 64, 6000000), ("lds+barrier 8 wg x 1024 (128 KB LDS each)", 2, 8, 1024, 6000000),
+for name, which, blocks, threads, iters in (("hold 128 KB LDS, sleeping, 8 wg x 64", 9, 8, 64, 6000000), ("hold 128 KB LDS, sleeping, 16 wg x 64", 9, 16, 64, 6000000),
+                                            ("hold all VGPRs, sleeping, 8 wg x 1024", 10, 8, 1024, 6000000), ("s_sleep 8 wg x 64", 1, 8, 64, 6000000), ("lds+barrier 8 wg x 1024 (128 KB LDS each)", 2, 8, 1024, 6000000),
                                             ("valu loop + barrier 8 wg x 1024", 4, 8, 1024, 5200), ("valu loop + s_sleep, 128 VGPRs, 8 wg x 1024", 6, 8, 1024, 5200),
                                             ("valu loop 8 wg x 256", 3, 8, 256, 20000)):
     print("  side = %-46s alone %.3f ms; layers beside it: %.3f ms" % (name, timeit(lambda: spin_side(which, blocks, threads, iters)(None), 3), timeit(side(spin_side(which, blocks, threads, iters)))))
