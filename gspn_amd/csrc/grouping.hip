@@ -227,6 +227,48 @@ extern "C" int gspn_sa_group_concat_grad(int b, int n, int c, int m, int nsample
     return gspn_launch_status();
 }
 
+// The same gradient as a gather: `order` (b, m*ns) = positions of the flattened idx row sorted by data-point index (ties ascending),
+// `offsets` (b, n+1) = each data point's range in it (coordinate-only data, built next to the ball query: geometry.py).  One wave per
+// (scene, data point, 64-channel chunk), lane = channel; fixed summation order, no atomics, no zero fill -- the reference's atomicAdd
+// has no defined order, so any fixed one is as faithful, and this one makes the whole backward pass reproducible.
+__global__ __launch_bounds__(256) void sa_group_concat_grad_csr_kernel(int n, int c, int m_ns, int xyz_first, int ld, const float* __restrict__ grad_out,
+                                                                       const int* __restrict__ order, const int* __restrict__ offsets,
+                                                                       float* __restrict__ grad_points, long nwaves) {
+    const int lane = threadIdx.x & 63;
+    const long wv = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wv >= nwaves) return;
+    const int chunks = (c + 63) / 64;
+    const int ch = (int)(wv % chunks);
+    const long sp = wv / chunks;                            // scene * n + p
+    const int scene = (int)(sp / n), p = (int)(sp - (long)scene * n);
+    const int l = ch * 64 + lane;
+    const int lc = (l < c ? l : 0) + (xyz_first ? 3 : 0);
+    const int* off = offsets + (size_t)scene * (n + 1);
+    const int e0 = off[p], e1 = off[p + 1];
+    const int* ord = order + (size_t)scene * m_ns;
+    const float* gs = grad_out + (size_t)scene * m_ns * ld;
+    float acc = 0.f;
+    int e = e0;
+    for (; e + 3 < e1; e += 4) {
+        const float v0 = gs[(size_t)ord[e] * ld + lc], v1 = gs[(size_t)ord[e + 1] * ld + lc];
+        const float v2 = gs[(size_t)ord[e + 2] * ld + lc], v3 = gs[(size_t)ord[e + 3] * ld + lc];
+        acc += v0; acc += v1; acc += v2; acc += v3;
+    }
+    for (; e < e1; ++e) acc += gs[(size_t)ord[e] * ld + lc];
+    if (l < c) grad_points[((size_t)scene * n + p) * c + l] = acc;
+}
+extern "C" int gspn_sa_group_concat_grad_csr(int b, int n, int c, int m, int nsample, const int* order, const int* offsets, int xyz_first, int ld_out,
+                                             const float* grad_out, float* grad_points, void* stream) {
+    if (b < 0 || n <= 0 || c <= 0 || m < 0 || nsample < 0 || ld_out < 3 + c || !order || !offsets) return GSPN_ERR_ARG;
+    if (b == 0) return 0;
+    const long nwaves = (long)b * n * ((c + 63) / 64);
+    const long blocks = (nwaves + 3) / 4;
+    if (blocks > 0x7FFFFFFFl) return GSPN_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(sa_group_concat_grad_csr_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n, c, m * nsample, xyz_first, ld_out,
+                       grad_out, order, offsets, grad_points, nwaves);
+    return gspn_launch_status();
+}
+
 // ============================================================================================
 // group_maxpool / grad  (tf_grouping_g.cu:88-134): fused gather + max over nsample.
 // init -10000, strict '>' (first maximum wins).  One thread per (query, channel): consecutive

@@ -14,8 +14,8 @@ def pn2_geometry(xyz):
     3-NN weights of the three FP levels.  Feed it to pn2_fea_extractor(..., geometry=...) -- typically computed for
     the next batch on a GeometryStream (geometry.py) while the current batch trains."""
     sa, cur = [], xyz
-    for npoint, radius, nsample in PN2_SA_SPEC:
-        g = sa_geometry(cur, npoint, radius, nsample)
+    for level, (npoint, radius, nsample) in enumerate(PN2_SA_SPEC):
+        g = sa_geometry(cur, npoint, radius, nsample, inverse=level > 0)      # level 0 groups the raw colours: no gradient flows there
         sa.append(g)
         cur = g.new_xyz
     l1, l2, l3 = sa[0].new_xyz, sa[1].new_xyz, sa[2].new_xyz

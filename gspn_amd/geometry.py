@@ -22,14 +22,25 @@ from .tf_sampling import farthest_point_sample, gather_point
 
 
 class SAGeometry:
-    """new_xyz (b,npoint,3), idx (b,npoint,nsample) int32, pts_cnt (b,npoint) int32 or None (knn)"""
-    __slots__ = ("new_xyz", "idx", "pts_cnt", "npoint", "nsample")
+    """new_xyz (b,npoint,3), idx (b,npoint,nsample) int32, pts_cnt (b,npoint) int32 or None (knn), plus the inverse lists the gradient
+    of the grouping gathers through: order (b, npoint*nsample) int32 = grouped positions sorted by data-point index, offsets (b, n+1)."""
+    __slots__ = ("new_xyz", "idx", "pts_cnt", "npoint", "nsample", "order", "offsets")
 
-    def __init__(self, new_xyz, idx, pts_cnt, npoint, nsample):
+    def __init__(self, new_xyz, idx, pts_cnt, npoint, nsample, order=None, offsets=None):
         self.new_xyz, self.idx, self.pts_cnt, self.npoint, self.nsample = new_xyz, idx, pts_cnt, npoint, nsample
+        self.order, self.offsets = order, offsets
 
     def tensors(self):
-        return [t for t in (self.new_xyz, self.idx, self.pts_cnt) if t is not None]
+        return [t for t in (self.new_xyz, self.idx, self.pts_cnt, self.order, self.offsets) if t is not None]
+
+
+def inverse_lists(idx2d, n):
+    """idx2d (b, L) int32 with values in [0, n) -> order (b, L) int32 (positions sorted by value, ties ascending), offsets (b, n+1) int32"""
+    b = idx2d.shape[0]
+    keys, order = torch.sort(idx2d, dim=1, stable=True)
+    bounds = torch.arange(n + 1, device=idx2d.device, dtype=keys.dtype).unsqueeze(0).expand(b, -1).contiguous()
+    offsets = torch.searchsorted(keys.contiguous(), bounds).to(torch.int32)
+    return order.to(torch.int32).contiguous(), offsets.contiguous()
 
 
 class FPGeometry:
@@ -44,7 +55,7 @@ class FPGeometry:
         return [t for t in (self.idx, self.weight, self.order, self.offsets) if t is not None]
 
 
-def sa_geometry(xyz, npoint, radius, nsample, knn=False):
+def sa_geometry(xyz, npoint, radius, nsample, knn=False, inverse=True):
     """pointnet_util.py:38-40: centres by FPS, neighbours by ball query (or kNN)."""
     xyz = xyz.detach()
     new_xyz = gather_point(xyz, farthest_point_sample(npoint, xyz))
@@ -53,7 +64,8 @@ def sa_geometry(xyz, npoint, radius, nsample, knn=False):
         cnt = None
     else:
         idx, cnt = query_ball_point(radius, nsample, xyz, new_xyz)
-    return SAGeometry(new_xyz, idx, cnt, npoint, nsample)
+    order, offsets = inverse_lists(idx.reshape(idx.shape[0], -1), xyz.shape[1]) if inverse else (None, None)
+    return SAGeometry(new_xyz, idx, cnt, npoint, nsample, order, offsets)
 
 
 def fp_geometry(xyz1, xyz2):
@@ -64,11 +76,8 @@ def fp_geometry(xyz1, xyz2):
     weight = (1.0 / dist) / norm                                      # :160
     # inverse lists for the gradient (three_interpolate_grad as a gather in the reference's own summation order)
     b, n1, _ = idx.shape
-    n2 = xyz2.shape[1]
-    keys, order = torch.sort(idx.reshape(b, 3 * n1), dim=1, stable=True)
-    bounds = torch.arange(n2 + 1, device=idx.device, dtype=keys.dtype).unsqueeze(0).expand(b, -1).contiguous()
-    offsets = torch.searchsorted(keys.contiguous(), bounds).to(torch.int32)
-    return FPGeometry(idx, weight, order.to(torch.int32).contiguous(), offsets.contiguous())
+    order, offsets = inverse_lists(idx.reshape(b, 3 * n1), xyz2.shape[1])
+    return FPGeometry(idx, weight, order, offsets)
 
 
 class PendingGeometry:

@@ -22,7 +22,7 @@ class _GroupConcat(torch.autograd.Function):
     gradient flows to `points` only (xyz/new_xyz are inputs of the network)."""
 
     @staticmethod
-    def forward(ctx, xyz, new_xyz, points, idx, xyz_first):
+    def forward(ctx, xyz, new_xyz, points, idx, xyz_first, order, offsets):
         b, n, _ = xyz.shape
         _, m, ns = idx.shape
         c = 0 if points is None else points.shape[2]
@@ -31,22 +31,26 @@ class _GroupConcat(torch.autograd.Function):
         with torch.cuda.device(xyz.device):
             L.check(L.lib().gspn_sa_group_concat(b, n, c, m, ns, L.ptr(xyz), L.ptr(new_xyz), L.ptr(points), L.ptr(idx),
                                                  int(xyz_first), ld, L.ptr(out), L.stream()), "sa_group_concat")
-        ctx.save_for_backward(idx)
+        ctx.save_for_backward(idx, order, offsets)
         ctx.dims = (b, n, c, m, ns, int(xyz_first), ld)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        (idx,) = ctx.saved_tensors
+        idx, order, offsets = ctx.saved_tensors
         b, n, c, m, ns, xyz_first, ld = ctx.dims
         gp = None
         if c > 0 and ctx.needs_input_grad[2]:
             g = g.contiguous()
             gp = torch.empty((b, n, c), dtype=torch.float32, device=g.device)
             with torch.cuda.device(g.device):
-                L.check(L.lib().gspn_sa_group_concat_grad(b, n, c, m, ns, L.ptr(idx), xyz_first, ld, L.ptr(g), L.ptr(gp), L.stream()),
-                        "sa_group_concat_grad")
-        return None, None, gp, None, None
+                if order is not None:       # gather through the inverse lists: fixed order, no atomics
+                    L.check(L.lib().gspn_sa_group_concat_grad_csr(b, n, c, m, ns, L.ptr(order), L.ptr(offsets), xyz_first, ld, L.ptr(g), L.ptr(gp),
+                                                                  L.stream()), "sa_group_concat_grad_csr")
+                else:
+                    L.check(L.lib().gspn_sa_group_concat_grad(b, n, c, m, ns, L.ptr(idx), xyz_first, ld, L.ptr(g), L.ptr(gp), L.stream()),
+                            "sa_group_concat_grad")
+        return None, None, gp, None, None, None, None
 
 
 class _FpConcat(torch.autograd.Function):
@@ -104,13 +108,16 @@ def fp_concat(points2, idx, weight, points1, order=None, offsets=None):
     return _FpConcat.apply(points2, idx, weight, points1, order, offsets)
 
 
-def group_concat(xyz, new_xyz, points, idx, xyz_first=True):
+def group_concat(xyz, new_xyz, points, idx, xyz_first=True, order=None, offsets=None):
     xyz = L.need(xyz.detach(), torch.float32, 3, "xyz")
     new_xyz = L.need(new_xyz.detach(), torch.float32, 3, "new_xyz")
     idx = L.need(idx, torch.int32, 3, "idx")
     if points is not None:
         points = L.need(points, torch.float32, 3, "points")
-    return _GroupConcat.apply(xyz, new_xyz, points, idx, xyz_first)
+    if order is not None:
+        order = L.need(order, torch.int32, 2, "order")
+        offsets = L.need(offsets, torch.int32, 2, "offsets")
+    return _GroupConcat.apply(xyz, new_xyz, points, idx, xyz_first, order, offsets)
 
 
 def sample_and_group(npoint, radius, nsample, xyz, points, tnet_spec=None, knn=False, use_xyz=True):
@@ -167,9 +174,9 @@ def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_al
             raise ValueError("pointnet_sa_module: precomputed geometry does not match this module")
         if fused:
             if geometry is None:
-                geometry = sa_geometry(xyz, npoint, radius, nsample)
+                geometry = sa_geometry(xyz, npoint, radius, nsample, inverse=points is not None and points.requires_grad)
             new_xyz, idx = geometry.new_xyz, geometry.idx
-            rows = group_concat(xyz, new_xyz, points, idx, xyz_first=True)      # (b*npoint*nsample, pitch >= 3+c)
+            rows = group_concat(xyz, new_xyz, points, idx, True, geometry.order, geometry.offsets)      # (b*npoint*nsample, pitch >= 3+c)
             cin = 3 + (0 if points is None else points.shape[2])
             layers = _mlp_layers(mlp, cin, 'conv', bn)
             # group_concat's gradient reads the feature columns only (xyz carries no gradient): backward skips the 3 xyz columns of dX

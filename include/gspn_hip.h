@@ -148,6 +148,10 @@ int gspn_sa_group_concat(int b, int n, int c, int m, int nsample, const float* x
  * zeroed here first. */
 int gspn_sa_group_concat_grad(int b, int n, int c, int m, int nsample, const int* idx, int xyz_first, int ld_out,
                               const float* grad_out, float* grad_points, void* stream);
+/* The same gradient as a gather (no atomics, fixed summation order): `order` (b, m*nsample) = positions of the flattened idx rows
+ * sorted by data-point index (ties ascending), `offsets` (b, n+1) = each data point's range in it. */
+int gspn_sa_group_concat_grad_csr(int b, int n, int c, int m, int nsample, const int* order, const int* offsets, int xyz_first, int ld_out,
+                                  const float* grad_out, float* grad_points, void* stream);
 
 /* ---------------- utils/tf_util.py conv2d 1x1 (+bias +BN +ReLU) : the shared MLP ------- */
 /* The reference delegates this arithmetic to TensorFlow (tf_util.py:120-185, 515-534):

@@ -304,3 +304,19 @@ def test_fp_concat_gather_gradient_is_bit_exact_vs_reference_order(b, n1, n2, c1
     np.testing.assert_array_equal(p2.grad.cpu().numpy(), ref)
     if c1:
         assert torch.equal(p1.grad, go[:, c2:c2 + c1].reshape(b, n1, c1))
+
+
+def test_training_step_is_bit_reproducible():
+    """no atomics on the training path (static row split, gather gradients through inverse lists): two identical steps give identical bits"""
+    from gspn_amd.fea_extractor import pn2_fea_extractor
+    xyz = torch.from_numpy(D.batch("D", 2, 8192)).cuda()
+    col = torch.rand(2, 8192, 3, device="cuda")
+    res = []
+    for _ in range(2):
+        store = fresh_store(13)
+        out = pn2_fea_extractor(xyz, col, 'fea', True, 0.5)
+        out.square().mean().backward()
+        res.append((out.detach().clone(), {n: p.grad.detach().clone() for n, p in store.named_parameters()}))
+    assert torch.equal(res[0][0], res[1][0])
+    for n in res[0][1]:
+        assert torch.equal(res[0][1][n], res[1][1][n]), n
