@@ -55,6 +55,14 @@ __device__ __forceinline__ int row_max_i32(int v) {
     v = max(v, dpp_i32<DPP_ROW_MIRROR>(v));
     return v;
 }
+// bitwise OR over the 16 lanes of a DPP row (every lane of the row gets the result)
+__device__ __forceinline__ int row_or_i32(int v) {
+    v |= dpp_i32<DPP_QUAD_XOR1>(v);
+    v |= dpp_i32<DPP_QUAD_XOR2>(v);
+    v |= dpp_i32<DPP_ROW_HALF_MIRROR>(v);
+    v |= dpp_i32<DPP_ROW_MIRROR>(v);
+    return v;
+}
 __device__ __forceinline__ int oct_max_i32(int v) {
     v = max(v, dpp_i32<DPP_QUAD_XOR1>(v));
     v = max(v, dpp_i32<DPP_QUAD_XOR2>(v));

@@ -243,7 +243,10 @@ __global__ __launch_bounds__(FPS_T) void fps_resident_kernel(int n, int m, const
 #define FPS_AMAX 6        // max picks accepted per round
 #ifdef FPS_PROFILE
 __device__ long long g_cell_prof[32];
-#define CELL_TICK(i) do { const long long _n = clock64(); cprof[i] += _n - ctprev; ctprev = _n; } while (0)
+__device__ int g_cell_waves[16 * 4];      // per wave of scene 0: {applies, refreshes, -, -}
+__device__ long long g_cell_tl[3 * 16 * 8];   // timestamps of rounds 200, 300, 400 of scene 0: [round][wave][tick]
+#define CELL_TICK(i) do { const long long _n = clock64(); cprof[i] += _n - ctprev; ctprev = _n; \
+        if (blockIdx.x == 0 && lane == 0 && (tlround == 200 || tlround == 300 || tlround == 400)) g_cell_tl[((tlround / 100 - 2) * 16 + wave) * 8 + i] = _n; } while (0)
 #else
 #define CELL_TICK(i) do {} while (0)
 #endif
@@ -315,7 +318,8 @@ __global__ __launch_bounds__(FPS_T) void fps_cell_kernel(int n, int m, int csz, 
     int nacc = 1;
     int j = 1;                      // number of outputs written so far
     int wmax = __float_as_int(1e38f);          // wave's current max min-distance (bits); padding-only waves settle at -1.0f
-    bool dirty = true;
+    bool need = true;                          // the cached candidate must be recomputed
+    unsigned myconf = 0;                       // candidates of the last exchange that would lower the cached candidate's min-distance
     // cached candidate of this wave
     int cv = 0, ck = 0, cpos = 0, cbound = NEG_ONE_BITS;
     float cfx = 0.f, cfy = 0.f, cfz = 0.f;
@@ -325,10 +329,14 @@ __global__ __launch_bounds__(FPS_T) void fps_cell_kernel(int n, int m, int csz, 
     long long cprof[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long ctprev = clock64();
     int napplied = 0, nrefresh = 0;
+    int tlround = 0;
 #endif
 
     int4* s_batch = s_cand + 4 * FPS_W;       // batch record broadcast by wave 0: {nacc, acc_list, terminal, j_new}
     while (j < m) {
+#ifdef FPS_PROFILE
+        tlround = round;
+#endif
         // ---- apply the accepted centres (culled per wave) ----
         // culling, all centres of the round at once: lane u (< nacc) tests centre u against this wave's bounding box.
         // Conservative in fp32: every point of the wave has dist2 >= L*(1-1e-5); a wave whose max min-distance is below that cannot change.
@@ -384,16 +392,17 @@ __global__ __launch_bounds__(FPS_T) void fps_cell_kernel(int n, int m, int csz, 
                     td[pp][1] = vmin_f32(d[1], td[pp][1]);
                 }
             }
-            dirty = true;
 #ifdef FPS_PROFILE
             ++napplied;
 #endif
         }
         CELL_TICK(0);
 
-        // ---- refresh this wave's candidate (best point + runner-up bound) if anything changed ----
-        if (dirty) {
-            int best = NEG_ONE_BITS;             // per-lane max over its slots (only dirty waves pay for this)
+        // ---- refresh this wave's candidate (best point + runner-up bound) -- only when the cached one is gone: it was picked, or
+        //      one of the centres just applied lies closer to it than its min-distance.  Otherwise it is still the wave's best point
+        //      with the same value (the other points only went down), and the cached runner-up bound is still an upper bound ----
+        if (need) {
+            int best = NEG_ONE_BITS;             // per-lane max over its slots
 #pragma unroll
             for (int pp = 0; pp < P / 2; ++pp) best = vmax3_i32(best, __float_as_int(td[pp][0]), __float_as_int(td[pp][1]));
             wmax = wave_max_i32(best);
@@ -442,7 +451,7 @@ __global__ __launch_bounds__(FPS_T) void fps_cell_kernel(int n, int m, int csz, 
             }
             cbound = max(s1, s2);
             cfx = fx; cfy = fy; cfz = fz;
-            dirty = false;
+            need = false;
 #ifdef FPS_PROFILE
             ++nrefresh;
 #endif
@@ -457,66 +466,58 @@ __global__ __launch_bounds__(FPS_T) void fps_cell_kernel(int n, int m, int csz, 
         __syncthreads();
         CELL_TICK(2);
 
-        // ---- batch selection, distributed: every wave ranks ITS OWN candidate (how many candidates beat it) and finds which
-        //      candidates would spoil it (dist2(own, other) < own min-distance), publishes those two words, and after a second
-        //      barrier the accept scan is a handful of scalar bit operations per pick, done redundantly by every wave ----
+        // ---- batch selection, distributed.  The accepted picks are a prefix of the candidates in value order, so whether the
+        //      candidate of rank p is acceptable GIVEN that ranks 0..p-1 are accepted can be decided by its own wave: none of the
+        //      better candidates may spoil it (dist2(own, other) < own min-distance, evaluated exactly as the update would) and it
+        //      must beat the runner-up bounds of all of them.  Every wave publishes {rank, acceptable}; after a second barrier the
+        //      batch is the run of acceptable ranks 0, 1, ... -- two 16-lane OR reductions, done redundantly by every wave ----
         int2* s_info = reinterpret_cast<int2*>(smem + 1280) + (round & 1) * FPS_W;
         const int l15 = lane & 15;
         const int4 mine = s_cand[buf + l15 * 2];                  // candidate l15: {v, x, y, z}
+        const int4 mine2 = s_cand[buf + l15 * 2 + 1];             // {sorted position, runner-up bound, -, -}
+        int myrank;
         {
             const unsigned better = (unsigned)(__ballot(mine.x > cv) & 0xFFFFull);
             const unsigned equal = (unsigned)(__ballot(mine.x == cv && l15 != wave) & 0xFFFFull);
             // dist2(point = own candidate, centre = candidate l15), exactly as the update would evaluate it
             const float dd = dist2_cuda(cfx - __int_as_float(mine.y), cfy - __int_as_float(mine.z), cfz - __int_as_float(mine.w));
             const unsigned conf = (unsigned)(__ballot(l15 != wave && mine.x >= 0 && dd < __int_as_float(cv)) & 0xFFFFull);
+            myconf = conf;
+            // largest runner-up bound among the better candidates
+            const int bb = __builtin_amdgcn_readfirstlane(row_max_i32(((better >> l15) & 1u) ? mine2.y : NEG_ONE_BITS));
             int cnt = __builtin_popcount(better);
             if (cv < 0) cnt = 64;                                 // empty / padding-only waves never rank
-            if (lane == 0) s_info[wave] = make_int2(cnt | ((equal != 0u && cv >= 0) ? 256 : 0), (int)conf);
+            myrank = cnt;
+            const bool okw = cnt == 0 || ((conf & better) == 0u && cv > bb);
+            if (lane == 0) s_info[wave] = make_int2(cnt | ((equal != 0u && cv >= 0) ? 256 : 0) | (okw ? 512 : 0), (int)conf);
         }
         __syncthreads();
         CELL_TICK(4);
         const int2 info = s_info[l15];
-        const int bnd_l = s_cand[buf + l15 * 2 + 1].y;
-        const bool slow = __ballot((info.x & 256) && (info.x & 255) < FPS_AMAX) != 0ull;    // equal values among the leaders (rare)
+        const int rk = info.x & 255;
+        const bool slow = __ballot((info.x & 256) && rk < FPS_AMAX) != 0ull;    // equal values among the leaders (rare)
         if (!slow) {
-            // accept scan, redundantly in every wave: a few scalar bit operations per pick
-            int na = 0, alist = 0, term = 0;
-            unsigned acc_mask = 0;
-            int bmax = NEG_ONE_BITS;
-            bool go = true;
-#pragma unroll
-            for (int p = 0; p < FPS_AMAX; ++p) {
-                const unsigned mk = (unsigned)(__ballot((info.x & 255) == p) & 0xFFFFull);
-                if (go && mk != 0u && (j + p) < m) {
-                    const int w = __builtin_ctz(mk);
-                    const int vw = __builtin_amdgcn_readlane(mine.x, w);
-                    const unsigned cf = (unsigned)__builtin_amdgcn_readlane(info.y, w);
-                    if (p == 0 && vw == 0) {                      // everything is covered: the sequential algorithm repeats this pick forever
-                        int voff = 0;
-                        asm volatile("" : "+v"(voff));
-                        term = 1 + __builtin_amdgcn_readfirstlane(pm[__builtin_amdgcn_readlane(s_cand[buf + l15 * 2 + 1].x, w) + voff]);
-                        go = false;
-                    } else if (p == 0 || ((cf & acc_mask) == 0u && vw > bmax)) {
-                        acc_mask |= 1u << w;
-                        bmax = max(bmax, __builtin_amdgcn_readlane(bnd_l, w));
-                        alist |= w << (4 * p);
-                        ++na;
-                    } else {
-                        go = false;
-                    }
-                } else {
-                    go = false;
-                }
+            const int okb = __builtin_amdgcn_readfirstlane(row_or_i32((rk < FPS_AMAX && (info.x & 512)) ? (1 << rk) : 0));
+            const int wl = __builtin_amdgcn_readfirstlane(row_or_i32(rk < FPS_AMAX ? (l15 << (4 * rk)) : 0));       // wave of every rank
+            int na = __builtin_ctz(~(unsigned)okb);               // run of acceptable ranks 0, 1, ...
+            na = min(na, min(FPS_AMAX, m - j));
+            int term = 0;
+            const unsigned zero0 = (unsigned)(__ballot(rk == 0 && mine.x == 0) & 0xFFFFull);
+            if (zero0 != 0u) {                                    // everything is covered: the sequential algorithm repeats this pick forever
+                int voff = 0;
+                asm volatile("" : "+v"(voff));
+                term = 1 + __builtin_amdgcn_readfirstlane(pm[__builtin_amdgcn_readlane(mine2.x, __builtin_ctz(zero0)) + voff]);
+                na = 0;
             }
             nacc = na;
-            acc_list = alist;
+            acc_list = na > 0 ? (wl & (int)((1ull << (4 * na)) - 1ull)) : 0;
             abuf = buf;
             termk = term;
-            for (int u = 0; u < nacc; ++u)
-                if (((acc_list >> (4 * u)) & 15) == wave) {            // own candidate accepted as pick number j+u: write it, mark consumed
-                    if (lane == 0) o[j + u] = ck;
-                    dirty = true;
-                }
+            if (myrank < na) {                                     // own candidate accepted as pick number j+rank: write it, mark consumed
+                if (lane == 0) o[j + myrank] = ck;
+                need = true;
+            }
+            if ((myconf & (unsigned)(__ballot(rk < na) & 0xFFFFull)) != 0u) need = true;      // an accepted centre reaches the cached candidate
             j += na;
             CELL_TICK(3);
             if (termk != 0) break;
@@ -574,11 +575,14 @@ __global__ __launch_bounds__(FPS_T) void fps_cell_kernel(int n, int m, int csz, 
             abuf = buf;
             termk = __builtin_amdgcn_readfirstlane(br.z);
             const int jnew = __builtin_amdgcn_readfirstlane(br.w);
-            for (int u = 0; u < nacc; ++u)
-                if (((acc_list >> (4 * u)) & 15) == wave) {
+            for (int u = 0; u < nacc; ++u) {
+                const int wu = (acc_list >> (4 * u)) & 15;
+                if (wu == wave) {
                     if (lane == 0) o[j + u] = ck;
-                    dirty = true;
+                    need = true;
                 }
+                if ((myconf >> wu) & 1u) need = true;
+            }
             j = jnew;
             CELL_TICK(3);
             if (termk != 0) break;
@@ -588,6 +592,7 @@ __global__ __launch_bounds__(FPS_T) void fps_cell_kernel(int n, int m, int csz, 
     if (termk != 0)
         for (int jj = j + t; jj < m; jj += FPS_T) o[jj] = termk - 1;
 #ifdef FPS_PROFILE
+    if (blockIdx.x == 0 && lane == 0) { g_cell_waves[wave * 4] = napplied; g_cell_waves[wave * 4 + 1] = nrefresh; }
     if (blockIdx.x == 0 && (t == 0 || t == FPS_T - 64)) {
         long long* d = g_cell_prof + (t ? 16 : 0);
         for (int i = 0; i < 4; ++i) d[i] = cprof[i];

@@ -44,6 +44,28 @@ def test_fps_all_kernels_agree_with_oracle(mode, min_n, kind, b, n, m, monkeypat
     np.testing.assert_array_equal(got, ref)
 
 
+@pytest.mark.parametrize("mode", ["cells", "cells_torch", "resident"])
+@pytest.mark.parametrize("b,n,m,grid", [(2, 32768, 1500, 24), (1, 32768, 3000, 12), (2, 20000, 700, 16), (1, 9000, 500, 10), (1, 32768, 40, 2)])
+def test_fps_lattice_ties(mode, b, n, m, grid, monkeypatch):
+    """points on a small integer lattice: exact ties between the maxima of different lanes, sub-cells and waves, duplicates, and (for
+    m > grid^3) the degenerate tail -- the reference's tie order (k mod 512, k) decides every one of them"""
+    from gspn_amd import tf_sampling
+    monkeypatch.setattr(tf_sampling, "FPS_MODE", mode)
+    monkeypatch.setattr(tf_sampling, "FPS_CELLS_MIN_N", 64)
+    rng = np.random.default_rng(grid * 1000 + n)
+    xyz = (rng.integers(0, grid, size=(b, n, 3)).astype(np.float32) / np.float32(8.0)).astype(np.float32)
+    ref = O.farthest_point_sample(m, xyz)
+    got = tf_sampling.farthest_point_sample(m, dev(xyz)).cpu().numpy()
+    np.testing.assert_array_equal(got, ref)
+
+
+def test_fps_all_points_identical_full_size():
+    from gspn_amd.tf_sampling import farthest_point_sample
+    xyz = np.full((2, 32768, 3), 0.5, np.float32)
+    got = farthest_point_sample(50, dev(xyz)).cpu().numpy()
+    assert (got == 0).all()
+
+
 def test_fps_streaming_large_n():
     from gspn_amd.tf_sampling import farthest_point_sample
     xyz = D.batch("D", 2, 40000)
