@@ -62,6 +62,7 @@ SIGNATURES = {
     "gspn_mlp_bwd_dw": [_L, _I, _I, _c.POINTER(DyArgs), _P, _I, _P, _P, _F, _I, _I, _P, _P, _P],
     "gspn_mlp_bwd_data": [_L, _I, _I, _c.POINTER(DyArgs), _P, _P, _I, _P],
     "gspn_mlp_bwd_data_cols": [_L, _I, _I, _c.POINTER(DyArgs), _P, _I, _I, _P, _I, _P],
+    "gspn_mlp_bwd_data_dw": [_L, _I, _I, _c.POINTER(DyArgs), _P, _I, _I, _P, _I, _P, _I, _P, _P, _F, _I, _I, _P, _P, _P],
     "gspn_fill_zero": [_P, _L, _P],
 }
 

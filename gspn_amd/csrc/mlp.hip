@@ -1356,32 +1356,47 @@ __global__ __launch_bounds__(256) void wgrad_small_reduce_kernel(long rows, int 
 #define DW_OX 16
 #define DW_SL 64
 #define DW_UN 8
-__global__ __launch_bounds__(1024) void wgrad_dw_kernel(long rows, int cin, int cout, int nslots, const float* __restrict__ PP, const double* __restrict__ red,
-                                                        const float* __restrict__ g3, const float* __restrict__ var, const float* __restrict__ gamma, float eps,
-                                                        int use_bn, int is_training, float* __restrict__ dW) {
-    __shared__ double s1[16][DW_OX], sx[16][DW_OX];
-    const long total = (long)cin * cout;
-    const double R = (double)rows;
-    const bool tr = use_bn && is_training;
+// everything the dW reduction needs besides its block index (also carried by mlp_bwd_data_kernel, which can run it in spare workgroups)
+struct DwJob {
+    long rows;
+    int cin, cout, nslots, nblk;          // nblk = ceil(cin*cout / DW_OX) workgroups
+    const float* PP;
+    const double* red;
+    const float* g3;
+    const float* var;
+    const float* gamma;
+    float eps;
+    int use_bn, is_training;
+    float* dW;
+};
+// One workgroup of NTH threads = DW_OX consecutive outputs x NTH/DW_OX interleaved slot slices; sh = 2 * (NTH/64) * DW_OX doubles.
+template <int NTH>
+__device__ __forceinline__ void wgrad_dw_block(const DwJob& j, unsigned blk, double* sh) {
+    constexpr int SL = NTH / DW_OX, NW = NTH / 64;
+    double* s1 = sh;
+    double* sx = sh + NW * DW_OX;
+    const long total = (long)j.cin * j.cout;
+    const double R = (double)j.rows;
+    const bool tr = j.use_bn && j.is_training;
     const int ox = threadIdx.x % DW_OX, sl = threadIdx.x / DW_OX, wave = threadIdx.x >> 6;
-    const long i = blockIdx.x * (long)DW_OX + ox;
+    const long i = blk * (long)DW_OX + ox;
     const long ic = i < total ? i : total - 1;                   // clamped: every lane takes part in the shuffles
     double w1 = 0.0, wx = 0.0;
     {
-        const float* p1 = PP + ic;
+        const float* p1 = j.PP + ic;
         const size_t st = 2 * (size_t)total;
-        const int last = nslots - 1;
-        for (int p = sl; p < nslots; p += DW_UN * DW_SL) {
+        const int last = j.nslots - 1;
+        for (int p = sl; p < j.nslots; p += DW_UN * SL) {
             float v[DW_UN], u[DW_UN];
 #pragma unroll
             for (int q = 0; q < DW_UN; ++q) {                    // clamped slot index: unconditional loads, masked below
-                const int pq = min(p + q * DW_SL, last);
+                const int pq = min(p + q * SL, last);
                 v[q] = p1[(size_t)pq * st];
                 u[q] = tr ? p1[(size_t)pq * st + total] : 0.f;
             }
 #pragma unroll
             for (int q = 0; q < DW_UN; ++q) {
-                const bool ok = p + q * DW_SL < nslots;
+                const bool ok = p + q * SL < j.nslots;
                 w1 += ok ? (double)v[q] : 0.0;
                 wx += ok ? (double)u[q] : 0.0;
             }
@@ -1390,17 +1405,28 @@ __global__ __launch_bounds__(1024) void wgrad_dw_kernel(long rows, int cin, int 
     // lanes l, l^16, l^32, l^48 hold the 4 slices of one output
     w1 += __shfl_xor(w1, 16, 64); wx += __shfl_xor(wx, 16, 64);
     w1 += __shfl_xor(w1, 32, 64); wx += __shfl_xor(wx, 32, 64);
-    if ((threadIdx.x & 63) < DW_OX) { s1[wave][ox] = w1; sx[wave][ox] = wx; }
+    if ((threadIdx.x & 63) < DW_OX) { s1[wave * DW_OX + ox] = w1; sx[wave * DW_OX + ox] = wx; }
     __syncthreads();
     if (threadIdx.x >= DW_OX || i >= total) return;
     w1 = 0.0; wx = 0.0;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) { w1 += s1[q][ox]; wx += sx[q][ox]; }
-    const int n = (int)(i % cout), m = (int)(i / cout);
+    for (int q = 0; q < NW; ++q) { w1 += s1[q * DW_OX + ox]; wx += sx[q * DW_OX + ox]; }
+    const int n = (int)(i % j.cout), m = (int)(i / j.cout);
     double A = 1.0;
-    if (use_bn) A = (gamma ? (double)gamma[n] : 1.0) / sqrt((double)var[n] + (double)eps);
-    if (tr) w1 -= (red[n] / R) * (double)g3[m] + (red[cout + n] / R) * wx;
-    dW[i] = (float)(A * w1);
+    if (j.use_bn) A = (j.gamma ? (double)j.gamma[n] : 1.0) / sqrt((double)j.var[n] + (double)j.eps);
+    if (tr) w1 -= (j.red[n] / R) * (double)j.g3[m] + (j.red[j.cout + n] / R) * wx;
+    j.dW[i] = (float)(A * w1);
+}
+__global__ __launch_bounds__(1024) void wgrad_dw_kernel(DwJob j) {
+    __shared__ double sh[2 * 16 * DW_OX];
+    wgrad_dw_block<1024>(j, blockIdx.x, sh);
+}
+static DwJob dw_job(long rows, int cin, int cout, long nslots, const float* PP, const double* red, const float* g3, const float* var, const float* gamma,
+                    float eps, int use_bn, int is_training, float* dW) {
+    DwJob j;
+    j.rows = rows; j.cin = cin; j.cout = cout; j.nslots = (int)nslots; j.nblk = (int)(((long)cin * cout + DW_OX - 1) / DW_OX);
+    j.PP = PP; j.red = red; j.g3 = g3; j.var = var; j.gamma = gamma; j.eps = eps; j.use_bn = use_bn; j.is_training = is_training; j.dW = dW;
+    return j;
 }
 
 // which kernel / plan a (layer, operand alignment) gets: shared by gspn_mlp_bwd_wgrad and gspn_mlp_bwd_dw so both find the same workspace layout
@@ -1479,9 +1505,10 @@ extern "C" int gspn_mlp_bwd_wgrad(long rows, int cin, int cout, const gspn_dy_ar
     const int cmax = cin > cout ? cin : cout;
     hipLaunchKernelGGL(wgrad_small_reduce_kernel, dim3(cmax), dim3(256), 0, st, rows, cin, cout, (int)p.nch, RP, GP, red, g3, mean, var, gamma, eps,
                        use_bn, is_training, cA, cB, cC, dgamma, dbeta, dbias);
-    if (dW)
-        hipLaunchKernelGGL(wgrad_dw_kernel, dim3((unsigned)(((long)cin * cout + DW_OX - 1) / DW_OX)), dim3(1024), 0, st, rows, cin, cout, (int)p.nslots, PP, red, g3,
-                           var, gamma, eps, use_bn, is_training, dW);
+    if (dW) {
+        const DwJob j = dw_job(rows, cin, cout, p.nslots, PP, red, g3, var, gamma, eps, use_bn, is_training, dW);
+        hipLaunchKernelGGL(wgrad_dw_kernel, dim3((unsigned)j.nblk), dim3(1024), 0, st, j);
+    }
     return gspn_launch_status();
 }
 
@@ -1499,8 +1526,8 @@ extern "C" int gspn_mlp_bwd_dw(long rows, int cin, int cout, const gspn_dy_args*
     const double* red = reinterpret_cast<const double*>(wb);
     const float* g3 = reinterpret_cast<const float*>(wb + ws_off_g3(cout));
     const float* PP = reinterpret_cast<const float*>(wb + ws_off_pp(p.nch, cin, cout));
-    hipLaunchKernelGGL(wgrad_dw_kernel, dim3((unsigned)(((long)cin * cout + DW_OX - 1) / DW_OX)), dim3(1024), 0, (hipStream_t)stream, rows, cin, cout,
-                       (int)p.nslots, PP, red, g3, var, gamma, eps, use_bn, is_training, dW);
+    const DwJob j = dw_job(rows, cin, cout, p.nslots, PP, red, g3, var, gamma, eps, use_bn, is_training, dW);
+    hipLaunchKernelGGL(wgrad_dw_kernel, dim3((unsigned)j.nblk), dim3(1024), 0, (hipStream_t)stream, j);
     return gspn_launch_status();
 }
 
@@ -1508,9 +1535,12 @@ extern "C" int gspn_mlp_bwd_dw(long rows, int cin, int cout, const gspn_dy_args*
 // Backward pass B:  dX(rows, cin) = dY(rows, cout) . W^T      (M = rows, K = cout, N = cin)
 // A = dY rebuilt on the fly (dY = cA*dyh + cB*y + cC) while staging; B[k][n] = W[n][k] staged transposed.
 // ============================================================================================
-template <int BN, bool VEC, bool POOLED>
+// DW: the first dwj.nblk workgroups (of row blockIdx.y == 0) are not part of the GEMM: they reduce the layer's partial dW tiles (the
+// last kernel of pass A, which nothing in pass B depends on) while the rest of the grid computes dX -- one launch, no tail, instead of
+// a 15 us kernel of its own per layer.
+template <int BN, bool VEC, bool POOLED, bool DW>
 __global__ __launch_bounds__(256) void mlp_bwd_data_kernel(long rows, int cin, int cout, gspn_dy_args a, const float* __restrict__ W,
-                                                           float* __restrict__ dX, int ldx, int col0) {
+                                                           float* __restrict__ dX, int ldx, int col0, DwJob dwj) {
     // `cin` is the END of the column range [col0, cin) of dX this launch produces (gspn_mlp_bwd_data_cols)
     constexpr int NT = BN / 32;
     constexpr int LDBT = BN + 1;                 // B written transposed: odd pitch
@@ -1518,6 +1548,15 @@ __global__ __launch_bounds__(256) void mlp_bwd_data_kernel(long rows, int cin, i
     __shared__ __attribute__((aligned(16))) float sA[TK * LDT];
     __shared__ __attribute__((aligned(16))) float sB[TK * LDBT];
     __shared__ float sSc[MAXCH], sSh[MAXCH], sCA[MAXCH], sCB[MAXCH], sCC[MAXCH];
+    unsigned bx = blockIdx.x, gx = gridDim.x;
+    if constexpr (DW) {
+        if (bx < (unsigned)dwj.nblk) {
+            if (blockIdx.y == 0) wgrad_dw_block<256>(dwj, bx, reinterpret_cast<double*>(sA));
+            return;
+        }
+        bx -= (unsigned)dwj.nblk;
+        gx -= (unsigned)dwj.nblk;
+    }
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int n0 = col0 + blockIdx.y * BN;
     const long ntiles = (rows + TM - 1) / TM;
@@ -1583,13 +1622,13 @@ __global__ __launch_bounds__(256) void mlp_bwd_data_kernel(long rows, int cin, i
         }
     };
     f32x16 acc[NT];
-    const long my_tiles = blockIdx.x < ntiles ? (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    const long my_tiles = bx < ntiles ? (ntiles - bx + gx - 1) / gx : 0;
     const long nsteps = my_tiles * nchunks;
     for (long sidx = 0; sidx <= nsteps; ++sidx) {
-        if (sidx < nsteps) fetch(blockIdx.x + (sidx / nchunks) * gridDim.x, (int)(sidx % nchunks));
+        if (sidx < nsteps) fetch(bx + (sidx / nchunks) * gx, (int)(sidx % nchunks));
         if (sidx > 0) {
             const long ps = sidx - 1;
-            const long tile = blockIdx.x + (ps / nchunks) * gridDim.x;
+            const long tile = bx + (ps / nchunks) * gx;
             const int c = (int)(ps % nchunks);
             if (c == 0) {
 #pragma unroll
@@ -1633,31 +1672,60 @@ __global__ __launch_bounds__(256) void mlp_bwd_data_kernel(long rows, int cin, i
         __syncthreads();
     }
 }
-// columns [col0, col0 + ncols) of dX only: the rest of the row is left untouched (the caller does not need it -- e.g. the xyz columns
-// of a set-abstraction input, whose gradient pointnet_util.py never uses -- which can halve the N dimension of the GEMM)
-extern "C" int gspn_mlp_bwd_data_cols(long rows, int cin, int cout, const gspn_dy_args* a, const float* W, int col0, int ncols, float* dX, int ldx,
-                                      void* stream) {
-    if (rows < 0 || cin <= 0 || cout <= 0 || ldx < cin || !a || !a->Y || !a->scale || !a->shift || !a->cA || !a->cB || !a->cC) return GSPN_ERR_ARG;
-    if (!a->dZ && !(a->dPool && a->pool_arg && a->ns > 0)) return GSPN_ERR_ARG;
-    if (col0 < 0 || ncols <= 0 || col0 + ncols > cin) return GSPN_ERR_ARG;
-    if (cin > MAXCH || cout > MAXCH) return GSPN_ERR_UNSUPPORTED;
-    if (rows == 0) return 0;
-    hipStream_t st = (hipStream_t)stream;
-    if (rows >= (1L << 31)) return GSPN_ERR_UNSUPPORTED;
+static int bwd_data_launch(long rows, int cin, int cout, const gspn_dy_args* a, const float* W, int col0, int ncols, float* dX, int ldx, const DwJob* dwj,
+                           hipStream_t st) {
     const bool pooled = a->dZ == nullptr;
     const bool v = vec_ok(a->Y, a->ldy) && vec_ok(W, cout) &&
                    (pooled ? (((uintptr_t)a->dPool) % 16 == 0 && ((uintptr_t)a->pool_arg) % 16 == 0) : vec_ok(a->dZ, a->ldz));
     const int cend = col0 + ncols;
-#define BD_LAUNCH(BN_, V_, YT_)                                                                                                        \
+    const DwJob none = dw_job(0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0, 0, nullptr);
+    const unsigned extra = dwj ? (unsigned)dwj->nblk : 0u;
+#define BD_GO(BN_, V_, P_, YT_)                                                                                                       \
     do {                                                                                                                               \
-        if (pooled) hipLaunchKernelGGL((mlp_bwd_data_kernel<BN_, V_, true>), dim3(row_grid(rows, YT_, BN_ >= 128 ? 3 : 4), YT_), dim3(256), 0, st, rows, cend, cout, *a, W, dX, ldx, col0); \
-        else        hipLaunchKernelGGL((mlp_bwd_data_kernel<BN_, V_, false>), dim3(row_grid(rows, YT_, BN_ >= 128 ? 3 : 4), YT_), dim3(256), 0, st, rows, cend, cout, *a, W, dX, ldx, col0); \
+        const dim3 g(row_grid(rows, YT_, BN_ >= 128 ? 3 : 4) + extra, YT_);                                                            \
+        if (dwj) hipLaunchKernelGGL((mlp_bwd_data_kernel<BN_, V_, P_, true>), g, dim3(256), 0, st, rows, cend, cout, *a, W, dX, ldx, col0, *dwj);   \
+        else     hipLaunchKernelGGL((mlp_bwd_data_kernel<BN_, V_, P_, false>), g, dim3(256), 0, st, rows, cend, cout, *a, W, dX, ldx, col0, none);  \
     } while (0)
+#define BD_LAUNCH(BN_, V_, YT_) do { if (pooled) BD_GO(BN_, V_, true, YT_); else BD_GO(BN_, V_, false, YT_); } while (0)
     if (ncols <= 32) { if (v) BD_LAUNCH(32, true, 1); else BD_LAUNCH(32, false, 1); }
     else if (ncols <= 64) { if (v) BD_LAUNCH(64, true, 1); else BD_LAUNCH(64, false, 1); }
     else { const int yt = (ncols + 127) / 128; if (v) BD_LAUNCH(128, true, yt); else BD_LAUNCH(128, false, yt); }
 #undef BD_LAUNCH
+#undef BD_GO
     return gspn_launch_status();
+}
+static int bwd_data_check(long rows, int cin, int cout, const gspn_dy_args* a, int col0, int ncols, int ldx) {
+    if (rows < 0 || cin <= 0 || cout <= 0 || ldx < cin || !a || !a->Y || !a->scale || !a->shift || !a->cA || !a->cB || !a->cC) return GSPN_ERR_ARG;
+    if (!a->dZ && !(a->dPool && a->pool_arg && a->ns > 0)) return GSPN_ERR_ARG;
+    if (col0 < 0 || ncols <= 0 || col0 + ncols > cin) return GSPN_ERR_ARG;
+    if (cin > MAXCH || cout > MAXCH) return GSPN_ERR_UNSUPPORTED;
+    if (rows >= (1L << 31)) return GSPN_ERR_UNSUPPORTED;
+    return 0;
+}
+// columns [col0, col0 + ncols) of dX only: the rest of the row is left untouched (the caller does not need it -- e.g. the xyz columns
+// of a set-abstraction input, whose gradient pointnet_util.py never uses -- which can halve the N dimension of the GEMM)
+extern "C" int gspn_mlp_bwd_data_cols(long rows, int cin, int cout, const gspn_dy_args* a, const float* W, int col0, int ncols, float* dX, int ldx,
+                                      void* stream) {
+    const int rc = bwd_data_check(rows, cin, cout, a, col0, ncols, ldx);
+    if (rc) return rc;
+    if (rows == 0) return 0;
+    return bwd_data_launch(rows, cin, cout, a, W, col0, ncols, dX, ldx, nullptr, (hipStream_t)stream);
+}
+// gspn_mlp_bwd_data_cols and gspn_mlp_bwd_dw in ONE launch: pass B of a layer plus the dW reduction that gspn_mlp_bwd_wgrad(..., dW = NULL)
+// left undone (same rows/cin/cout/a/X/ldx_in as that call, so that the workspace layout is found again).  dX and dW are what the two
+// separate calls produce (dW: same sums, 16 instead of 64 slot slices per output).
+extern "C" int gspn_mlp_bwd_data_dw(long rows, int cin, int cout, const gspn_dy_args* a, const float* W, int col0, int ncols, float* dX, int ldx,
+                                    const float* X, int ldx_in, const float* var, const float* gamma, float eps, int use_bn, int is_training,
+                                    const float* work, float* dW, void* stream) {
+    const int rc = bwd_data_check(rows, cin, cout, a, col0, ncols, ldx);
+    if (rc) return rc;
+    if (rows <= 0 || !work || !dW || ldx_in < cin || (use_bn && !var)) return GSPN_ERR_ARG;
+    bool use_stream;
+    const WgradPlan p = wgrad_choose(rows, cin, cout, a, X, ldx_in, &use_stream);
+    const char* wb = reinterpret_cast<const char*>(work);
+    const DwJob j = dw_job(rows, cin, cout, p.nslots, reinterpret_cast<const float*>(wb + ws_off_pp(p.nch, cin, cout)), reinterpret_cast<const double*>(wb),
+                           reinterpret_cast<const float*>(wb + ws_off_g3(cout)), var, gamma, eps, use_bn, is_training, dW);
+    return bwd_data_launch(rows, cin, cout, a, W, col0, ncols, dX, ldx, &j, (hipStream_t)stream);
 }
 extern "C" int gspn_mlp_bwd_data(long rows, int cin, int cout, const gspn_dy_args* a, const float* W, float* dX, int ldx, void* stream) {
     return gspn_mlp_bwd_data_cols(rows, cin, cout, a, W, 0, cin, dX, ldx, stream);

@@ -245,8 +245,12 @@ __global__ __launch_bounds__(FPS_T) void fps_resident_kernel(int n, int m, const
 __device__ long long g_cell_prof[32];
 __device__ int g_cell_waves[16 * 4];      // per wave of scene 0: {applies, refreshes, -, -}
 __device__ long long g_cell_tl[3 * 16 * 8];   // timestamps of rounds 200, 300, 400 of scene 0: [round][wave][tick]
+#if FPS_PROFILE == 2     // timeline only: no per-phase accumulators (they cost registers the P=32 kernel then spills)
+#define CELL_TICK(i) do { if (blockIdx.x == 0 && lane == 0 && (tlround == 200 || tlround == 300 || tlround == 400)) g_cell_tl[((tlround / 100 - 2) * 16 + wave) * 8 + i] = clock64(); } while (0)
+#else
 #define CELL_TICK(i) do { const long long _n = clock64(); cprof[i] += _n - ctprev; ctprev = _n; \
         if (blockIdx.x == 0 && lane == 0 && (tlround == 200 || tlround == 300 || tlround == 400)) g_cell_tl[((tlround / 100 - 2) * 16 + wave) * 8 + i] = _n; } while (0)
+#endif
 #else
 #define CELL_TICK(i) do {} while (0)
 #endif
@@ -326,8 +330,10 @@ __global__ __launch_bounds__(FPS_T) void fps_cell_kernel(int n, int m, int csz, 
     int round = 0;
     int termk = 0;
 #ifdef FPS_PROFILE
+#if FPS_PROFILE != 2
     long long cprof[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long ctprev = clock64();
+#endif
     int napplied = 0, nrefresh = 0;
     int tlround = 0;
 #endif
@@ -593,12 +599,14 @@ __global__ __launch_bounds__(FPS_T) void fps_cell_kernel(int n, int m, int csz, 
         for (int jj = j + t; jj < m; jj += FPS_T) o[jj] = termk - 1;
 #ifdef FPS_PROFILE
     if (blockIdx.x == 0 && lane == 0) { g_cell_waves[wave * 4] = napplied; g_cell_waves[wave * 4 + 1] = nrefresh; }
+#if FPS_PROFILE != 2
     if (blockIdx.x == 0 && (t == 0 || t == FPS_T - 64)) {
         long long* d = g_cell_prof + (t ? 16 : 0);
         for (int i = 0; i < 4; ++i) d[i] = cprof[i];
         d[4] = round; d[5] = napplied; d[6] = nrefresh;
         for (int i = 4; i < 10; ++i) d[4 + i] = cprof[i];
     }
+#endif
 #endif
 }
 

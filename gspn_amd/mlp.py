@@ -8,6 +8,7 @@ once, the BN+ReLU of layer l is applied inside the operand load of layer l+1, an
 dY on the fly inside the two backward GEMMs.
 """
 import ctypes
+import os
 
 import torch
 
@@ -20,6 +21,8 @@ BN_EPS = 1e-3      # tf.contrib.layers.batch_norm default epsilon (tf_util.py:52
 # kernels.  Off by default: inside a captured step the fork becomes a multi-branch hipGraph, and ROCm 7.2 replays those far slower
 # than a linear graph (measured on MI355X: 3.9 -> 6.6 ms per step), which costs more than the ~0.2 ms of overlap gains.
 DEFER_DW = False
+# one launch for pass B + the dW reduction of the same layer (gspn_mlp_bwd_data_dw) instead of two
+FUSE_DW = os.environ.get("GSPN_FUSE_DW", "1") != "0"
 _side_streams = {}
 
 
@@ -145,10 +148,12 @@ class _MlpStack(torch.autograd.Function):
                 dbias = torch.empty(cout, dtype=torch.float32, device=dev)
                 dW = torch.empty_like(lp.weights)
                 work = torch.empty(int(lib.gspn_mlp_bwd_work_bytes(rows, cin, cout)) // 4 + 4, dtype=torch.float32, device=dev)
+                has_dx = li > 0 or ctx.x_needs_grad
+                fuse_dw = FUSE_DW and has_dx and not DEFER_DW      # the dW reduction rides in spare workgroups of this layer's pass B
                 L.check(lib.gspn_mlp_bwd_wgrad(rows, cin, cout, ctypes.byref(a), L.ptr(xin), xld, L.ptr(in_scale), L.ptr(in_shift),
                                                L.ptr(mean), L.ptr(var), L.ptr(lp.gamma if lp.bn else None), BN_EPS, int(lp.bn), int(is_training),
                                                L.ptr(work), L.ptr(cA), L.ptr(cB), L.ptr(cC), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dbias),
-                                               None if DEFER_DW else L.ptr(dW), st), "mlp_bwd_wgrad")
+                                               None if (DEFER_DW or fuse_dw) else L.ptr(dW), st), "mlp_bwd_wgrad")
                 if DEFER_DW:
                     if side is None:
                         side = _side_stream(dev)
@@ -162,16 +167,19 @@ class _MlpStack(torch.autograd.Function):
                 if lp.bn:
                     g += [dbeta, dgamma]
                 grads = g + grads
-                if li > 0 or ctx.x_needs_grad:
+                if has_dx:
                     dx = torch.empty((rows, xld), dtype=torch.float32, device=dev) if li == 0 else torch.empty((rows, cin), dtype=torch.float32, device=dev)
                     if li == 0 and xld > cin and spec.get("grad_cols") is None:
                         dx.zero_()
-                    gc = spec.get("grad_cols") if li == 0 else None
-                    if gc is not None:          # only these input columns feed a gradient upstream (e.g. not the xyz columns of an SA input)
+                    # only grad_cols of the input feed a gradient upstream (e.g. not the xyz columns of an SA input)
+                    gc = (spec.get("grad_cols") if li == 0 else None) or (0, cin)
+                    if fuse_dw:
+                        L.check(lib.gspn_mlp_bwd_data_dw(rows, cin, cout, ctypes.byref(a), L.ptr(lp.weights), int(gc[0]), int(gc[1]), L.ptr(dx), dx.shape[1],
+                                                         L.ptr(xin), xld, L.ptr(var), L.ptr(lp.gamma if lp.bn else None), BN_EPS, int(lp.bn),
+                                                         int(is_training), L.ptr(work), L.ptr(dW), st), "mlp_bwd_data_dw")
+                    else:
                         L.check(lib.gspn_mlp_bwd_data_cols(rows, cin, cout, ctypes.byref(a), L.ptr(lp.weights), int(gc[0]), int(gc[1]), L.ptr(dx),
                                                            dx.shape[1], st), "mlp_bwd_data_cols")
-                    else:
-                        L.check(lib.gspn_mlp_bwd_data(rows, cin, cout, ctypes.byref(a), L.ptr(lp.weights), L.ptr(dx), dx.shape[1], st), "mlp_bwd_data")
                     if li == 0:
                         dx0 = dx
                     dz, ldz = dx, dx.shape[1]

@@ -235,6 +235,12 @@ int gspn_mlp_bwd_data(long rows, int cin, int cout, const gspn_dy_args* a, const
  * channels need no gradient -- the xyz columns of a set-abstraction input, the raw colours of the last FP level. */
 int gspn_mlp_bwd_data_cols(long rows, int cin, int cout, const gspn_dy_args* a, const float* W, int col0, int ncols, float* dX, int ldx,
                            void* stream);
+/* gspn_mlp_bwd_data_cols + gspn_mlp_bwd_dw in one launch: the dW reduction that gspn_mlp_bwd_wgrad(..., dW = NULL) left undone runs in
+ * spare workgroups of pass B instead of a kernel of its own (X / ldx_in / var / gamma / eps / use_bn / is_training / work as in that
+ * call).  dX is bit-identical to gspn_mlp_bwd_data_cols'; dW is the same sum taken over 16 instead of 64 slot slices per output. */
+int gspn_mlp_bwd_data_dw(long rows, int cin, int cout, const gspn_dy_args* a, const float* W, int col0, int ncols, float* dX, int ldx,
+                         const float* X, int ldx_in, const float* var, const float* gamma, float eps, int use_bn, int is_training,
+                         const float* work, float* dW, void* stream);
 
 int gspn_fill_zero(void* ptr, long bytes, void* stream);
 

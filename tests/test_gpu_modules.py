@@ -241,27 +241,31 @@ def test_fp_concat_matches_interpolate_plus_concat(b, n1, n2, c1, c2):
         assert torch.equal(p1.grad, p1r.grad)
 
 
-def test_deferred_dw_matches_inline():
-    """gspn_mlp_bwd_dw on a side stream (mlp.DEFER_DW) gives the inline weight gradients"""
+def test_dw_reduction_placements_agree():
+    """the dW reduction as its own kernel, on a side stream (mlp.DEFER_DW), or inside pass B's launch (mlp.FUSE_DW, the default):
+    identical dX; identical dW for the two stand-alone placements, and the same sum with fewer slot slices for the fused one"""
     from gspn_amd import mlp as M
     from tests.test_gpu_mlp import make_params, to_layers
     g = torch.Generator().manual_seed(5)
     x64 = torch.randn(4096, 32, generator=g, dtype=torch.float64)
     res = []
-    for defer in (False, True):
-        layers = to_layers(make_params([32, 64], 32, seed=9))
+    for fuse, defer in ((False, False), (False, True), (True, False)):
+        layers = to_layers(make_params([32, 64, 48], 32, seed=9))
         x = x64.float().cuda().requires_grad_(True)
-        old = M.DEFER_DW
-        M.DEFER_DW = defer
+        old = (M.FUSE_DW, M.DEFER_DW)
+        M.FUSE_DW, M.DEFER_DW = fuse, defer
         try:
             out = M.mlp_stack(x, 32, layers, True, 0.7, pool_ns=32)
             out.square().sum().backward()
             torch.cuda.synchronize()
         finally:
-            M.DEFER_DW = old
+            M.FUSE_DW, M.DEFER_DW = old
         res.append([lp.weights.grad.clone() for lp in layers] + [x.grad.clone()])
-    for a_, b_ in zip(*res):
+    for a_, b_ in zip(res[0], res[1]):
         assert torch.equal(a_, b_)
+    assert torch.equal(res[0][-1], res[2][-1])
+    for a_, b_ in zip(res[0][:-1], res[2][:-1]):
+        assert rel_err(b_, a_) < 1e-6
 
 
 def test_fp_module_grad_cols_shortcut_is_exact():

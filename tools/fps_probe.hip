@@ -49,7 +49,7 @@ static void cell_probe(int n, int m, int ncell) {
             for (int r = 0; r < 3; ++r) { long long t0 = tl[r*128]; for (int w = 0; w < 16; ++w) t0 = std::min(t0, tl[(r*16+w)*8]);
                 printf("  round %d (cycles since the first wave finished its applies): wave: apply-end refresh-end barrier1 barrier2 scan-end\n", 200 + 100*r);
                 for (int w = 0; w < 16; ++w) { long long* q = tl + (r*16+w)*8; printf("    w%02d %6lld %6lld %6lld %6lld %6lld\n", w, q[0]-t0, q[1]-t0, q[2]-t0, q[4]-t0, q[3]-t0); } } }
-        for (int w = 0; w < 2; ++w) { long long* q = p + w*16; double R = (double)q[4];
+        if (FPS_PROFILE != 2) for (int w = 0; w < 2; ++w) { long long* q = p + w*16; double R = (double)q[4];
             if (w == 0) printf("  own-rank+barrier2 %.0f cycles/round\n", q[8]/R);
             printf("  wave %2d: rounds %lld (%.2f picks/round) applied %lld refreshed %lld | cycles/round: apply %.0f refresh %.0f publish+barrier %.0f batch %.0f\n", w*15, q[4], (m-1)/R, q[5], q[6], q[0]/R, q[1]/R, q[2]/R, q[3]/R); }
 #endif

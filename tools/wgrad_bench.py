@@ -4,8 +4,11 @@ sys.path.insert(0, '.')
 from gspn_amd import _lib as L
 lib = L.lib(); st = L.stream()
 shapes = [("SA1-L1", 524288, 8, 6, 32, False), ("SA1-L2", 524288, 32, 32, 32, False), ("SA1-L3p", 524288, 32, 32, 64, True),
-          ("SA2-L1", 131072, 68, 67, 64, False), ("SA2-L3p", 131072, 64, 64, 128, True), ("SA3-L2", 32768, 128, 128, 128, False),
-          ("FP3-L1", 262144, 68, 67, 64, False), ("FP3-L2", 262144, 64, 64, 64, False)]
+          ("SA2-L1", 131072, 68, 67, 64, False), ("SA2-L2", 131072, 64, 64, 64, False), ("SA2-L3p", 131072, 64, 64, 128, True),
+          ("SA3-L1", 32768, 132, 131, 128, False), ("SA3-L2", 32768, 128, 128, 128, False), ("SA3-L3p", 32768, 128, 128, 256, True),
+          ("FP1-L1", 4096, 384, 384, 256, False), ("FP1-L2", 4096, 256, 256, 128, False),
+          ("FP2-L1", 16384, 192, 192, 128, False), ("FP2-L2", 16384, 128, 128, 64, False),
+          ("FP3-L1", 262144, 68, 67, 64, False), ("FP3-L2", 262144, 64, 64, 64, False), ("FP3-L3", 262144, 64, 64, 64, False)]
 for name, rows, ldx, cin, cout, pooled in shapes:
     dev = 'cuda'
     X = torch.randn(rows, ldx, device=dev); Y = torch.randn(rows, cout, device=dev)
