@@ -22,6 +22,7 @@
 #include "common.h"
 #include <type_traits>
 #include <stdlib.h>
+#include <stdio.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -480,6 +481,24 @@ static inline unsigned row_grid(long rows, int ytiles, int per_cu) {
     if (cap < 64) cap = 64;
     return (unsigned)(ntiles < cap ? ntiles : cap);
 }
+// Column-tile width of the register-staged GEMM kernels (forward fallback, pass B) for `cols` output columns: the widest of 128/64/32
+// that still gives the chip one workgroup per CU, unless a narrower one wastes markedly fewer padded columns (131 columns: 3 x 64
+// instead of 2 x 128).  Short layers (<= 16384 rows) thus run 32-wide tiles in 4-8 column blocks instead of a quarter of the CUs
+// (tools/fwd_sweep.py on MI355X: 4096 x 384 -> 256 forward 44 -> 27 us, pass B 33 -> 26 us).  GSPN_FWD_FORCE_BN / GSPN_BWD_FORCE_BN
+// override it (tuning hooks).
+static inline int pick_bn(long rows, int cols, const char* env) {
+    {
+        const char* e = getenv(env);
+        const int f = e ? atoi(e) : 0;
+        if (f == 32 || f == 64 || f == 128) return f;
+    }
+    const long ntiles = (rows + TM - 1) / TM;
+    auto nblk = [&](int bn) { return ntiles * ((cols + bn - 1) / bn); };
+    auto pad = [&](int bn) { return (cols + bn - 1) / bn * bn; };
+    int bn = cols <= 32 ? 32 : (cols <= 64 ? 64 : 128);
+    while (bn > 32 && (nblk(bn) < GSPN_PLAN_CUS || 4 * pad(bn) > 5 * pad(bn / 2))) bn /= 2;
+    return bn;
+}
 // number of row-blocks (= partial-statistics rows) the forward launch of a (rows, cout) layer uses
 // (workgroups per CU = what the kernel's LDS footprint lets reside at once: a persistent grid larger than that runs a second wave)
 static inline unsigned fwd_blocks(long rows, int cout) { return row_grid(rows, cout <= 64 ? 1 : (cout + 127) / 128, cout <= 64 ? 4 : 3); }
@@ -544,9 +563,11 @@ extern "C" int gspn_mlp_fwd(long rows, int cin, int cout, const float* X, int ld
 #define FWD_LAUNCH(BN_, V_, YT_)                                                                                                   \
     hipLaunchKernelGGL((mlp_fwd_kernel<BN_, V_>), dim3(fwd_blocks(rows, cout), YT_), dim3(256), 0, st, rows, cin, cout, X, ldx, \
                        in_scale, in_shift, W, bias, Y, ldy, stats)
-    if (cout <= 32) { if (v) FWD_LAUNCH(32, true, 1); else FWD_LAUNCH(32, false, 1); }
-    else if (cout <= 64) { if (v) FWD_LAUNCH(64, true, 1); else FWD_LAUNCH(64, false, 1); }
-    else { const int yt = (cout + 127) / 128; if (v) FWD_LAUNCH(128, true, yt); else FWD_LAUNCH(128, false, yt); }
+    const int bn = pick_bn(rows, cout, "GSPN_FWD_FORCE_BN");
+    const int yt = (cout + bn - 1) / bn;
+    if (bn == 32) { if (v) FWD_LAUNCH(32, true, yt); else FWD_LAUNCH(32, false, yt); }
+    else if (bn == 64) { if (v) FWD_LAUNCH(64, true, yt); else FWD_LAUNCH(64, false, yt); }
+    else { if (v) FWD_LAUNCH(128, true, yt); else FWD_LAUNCH(128, false, yt); }
 #undef FWD_LAUNCH
     return gspn_launch_status();
 }
@@ -1238,14 +1259,37 @@ struct WgradPlan { int MTs, NTs, nrow, ncol, TKW, WK, shared; long rpc, nch, nsl
 static WgradPlan wgrad_plan(long rows, int cin, int cout, bool generic = false, bool pooled = false) {
     WgradPlan p;
     const int mt = (cin + 31) / 32, nt = (cout + 31) / 32;
-    p.nrow = (mt + 3) / 4; p.ncol = (nt + 3) / 4;
-    p.MTs = (mt + p.nrow - 1) / p.nrow;
-    if (!generic && p.MTs >= 3) p.ncol = (nt + 1) / 2;      // at most 8 tiles (128 accumulator registers with Gx) per workgroup
-    p.NTs = (nt + p.ncol - 1) / p.ncol;
-    if (p.NTs == 3) p.NTs = 4;                              // BN in {32, 64, 128}
+    if (generic) {
+        p.nrow = (mt + 3) / 4; p.ncol = (nt + 3) / 4;
+        p.MTs = (mt + p.nrow - 1) / p.nrow;
+        p.NTs = (nt + p.ncol - 1) / p.ncol;
+        if (p.NTs == 3) p.NTs = 4;
+    } else {
+        // Small tiles: one 32-row strip of dW per workgroup, 1-4 column tiles.  More tiles per layer means fewer row chunks for the same
+        // number of workgroups, i.e. fewer partial tiles to write and sum (that traffic rivals the inputs of the small-row layers), and
+        // a re-read input tile is an L2 hit.  Swept on MI355X over all 16 layers of the benchmark stack (tools/wgrad_sweep.py): MT = 1
+        // wins everywhere (by 10-25 % below 131072 rows); NT = 4 for the pooled kernel, 2 for the long layers, 1 for the short ones.
+        p.MTs = 1; p.nrow = mt;
+        int want = pooled ? 4 : (rows >= 131072 ? 2 : 1);
+        while (want > 1 && want / 2 >= nt) want /= 2;
+        p.NTs = want; p.ncol = (nt + want - 1) / want;
+    }
     // rows staged per iteration (streaming kernel): one stage is 14-24 KB of LDS, two stages per workgroup, 3 workgroups per CU
     static const int tkw[4][3] = {{64, 32, 16}, {32, 32, 16}, {32, 16, 16}, {32, 16, 16}};      // [MT-1][NT: 1,2,4]
     p.TKW = tkw[p.MTs - 1][p.NTs == 1 ? 0 : (p.NTs == 2 ? 1 : 2)];
+    // tuning hook (tools/wgrad_sweep.py): GSPN_WGRAD_FORCE="MTs,NTs,chunks" overrides the tile shape / the number of row chunks (0 = keep)
+    long forced_chunks = 0;
+    if (!generic) {
+        const char* e = getenv("GSPN_WGRAD_FORCE");
+        int fm = 0, fn = 0;
+        long fc = 0;
+        if (e && sscanf(e, "%d,%d,%ld", &fm, &fn, &fc) >= 2) {
+            if (fm >= 1 && fm <= 4) { p.MTs = fm; p.nrow = (mt + fm - 1) / fm; }
+            if (fn == 1 || fn == 2 || fn == 4) { p.NTs = fn; p.ncol = (nt + fn - 1) / fn; }
+            p.TKW = tkw[p.MTs - 1][p.NTs == 1 ? 0 : (p.NTs == 2 ? 1 : 2)];
+            forced_chunks = fc;
+        }
+    }
     if (generic) { p.nrow = (cin + 127) / 128; p.ncol = (cout + 127) / 128; p.MTs = 4; p.NTs = 4; p.TKW = 32; }
     const int T = p.MTs * p.NTs;
     p.WK = generic ? 1 : ((T % 4 == 0) ? 1 : ((T % 2 == 0) ? 2 : 4));
@@ -1273,6 +1317,7 @@ static WgradPlan wgrad_plan(long rows, int cin, int cout, bool generic = false, 
     long floor_ch = GSPN_PLAN_CUS / ntile;                            // but never fewer than one workgroup per CU (if the layer has the rows)
     if (floor_ch < 1) floor_ch = 1;
     if (chunks > by_size) chunks = by_size > floor_ch ? by_size : floor_ch;
+    if (forced_chunks > 0) chunks = forced_chunks;
     long rpc = (rows + chunks - 1) / chunks;
     if (rpc < 4L * p.TKW) rpc = 4L * p.TKW;
     p.rpc = (rpc + p.TKW - 1) / p.TKW * p.TKW;
@@ -1687,9 +1732,11 @@ static int bwd_data_launch(long rows, int cin, int cout, const gspn_dy_args* a, 
         else     hipLaunchKernelGGL((mlp_bwd_data_kernel<BN_, V_, P_, false>), g, dim3(256), 0, st, rows, cend, cout, *a, W, dX, ldx, col0, none);  \
     } while (0)
 #define BD_LAUNCH(BN_, V_, YT_) do { if (pooled) BD_GO(BN_, V_, true, YT_); else BD_GO(BN_, V_, false, YT_); } while (0)
-    if (ncols <= 32) { if (v) BD_LAUNCH(32, true, 1); else BD_LAUNCH(32, false, 1); }
-    else if (ncols <= 64) { if (v) BD_LAUNCH(64, true, 1); else BD_LAUNCH(64, false, 1); }
-    else { const int yt = (ncols + 127) / 128; if (v) BD_LAUNCH(128, true, yt); else BD_LAUNCH(128, false, yt); }
+    const int bn = pick_bn(rows, ncols, "GSPN_BWD_FORCE_BN");
+    const int yt = (ncols + bn - 1) / bn;
+    if (bn == 32) { if (v) BD_LAUNCH(32, true, yt); else BD_LAUNCH(32, false, yt); }
+    else if (bn == 64) { if (v) BD_LAUNCH(64, true, yt); else BD_LAUNCH(64, false, yt); }
+    else { if (v) BD_LAUNCH(128, true, yt); else BD_LAUNCH(128, false, yt); }
 #undef BD_LAUNCH
 #undef BD_GO
     return gspn_launch_status();
