@@ -65,7 +65,7 @@ def main():
     # inputs resident in HBM before the timed region; rank r owns scenes [8r, 8r+8) of the global batch; NB distinct batches rotate
     # (NB = 3 slots: the layers of step i read slot i%3 while the geometry of steps i+1 and i+2 is being written into the other two)
     NB = 3
-    DEPTH = 2                   # geometry runs this many steps ahead, on DEPTH side streams (FPS throughput: one CU per scene per stream)
+    DEPTH = int(os.environ.get('GSPN_BENCH_DEPTH', '2'))                   # geometry runs this many steps ahead, on DEPTH side streams (FPS throughput: one CU per scene per stream)
     batches = []
     for k in range(NB):
         xyz_np, col_np = synth(SCENES_PER_GPU, NPOINTS, seed0=(k * 1000 + rank) * SCENES_PER_GPU)
@@ -75,10 +75,11 @@ def main():
     gout = torch.from_numpy(np.random.default_rng(777).standard_normal((SCENES_PER_GPU, NPOINTS, 64)).astype(np.float32)).to(dev)
 
     store = tf_util.set_variable_store(tf_util.VariableStore(device=dev, seed=1234))   # same weights on every rank
-    state = {"bucket": None, "opt": None, "i": 0, "pend": None}
+    state = {"bucket": None, "opt": None, "i": 0, "pend": None, "t_wait": 0.0}
     geo = None if args.no_overlap else [GeometryStream(dev) for _ in range(DEPTH)]     # (default priority: a high-priority geometry queue starves the layers, 3.7 -> 8.1 ms per step)
     use_graph = geo is not None and not args.no_graph
     pend = {}                   # step index -> PendingGeometry
+    done = {}                   # step index -> event after its layers + optimiser step
 
     def fwd_bwd(k, g):
         """forward + loss + backward of batch k with geometry g, gradients gathered into the flat bucket"""
@@ -110,15 +111,66 @@ def main():
         for k in range(NB):
             graphs.append(CapturedStep(lambda k=k: captured(k), pool=graphs[0].pool() if graphs else None))
 
+    # the input batches are resident and never rewritten: the geometry of a later step has nothing to wait for on the main stream,
+    # except (graph mode) the layers that still READ the persistent geometry buffers of its slot -- NB = DEPTH + 1 slots keep those apart
+    AFTER = None
+
     def submit_geometry(j):
         """geometry of step j (batch slot j % NB) on side stream j % DEPTH"""
         kj = j % NB
         if use_graph:
-            pend[j] = geo[j % DEPTH].submit(lambda x: copy_into(G[kj], pn2_geometry(x)), batches[kj][0])
+            pend[j] = geo[j % DEPTH].submit(lambda x: copy_into(G[kj], pn2_geometry(x)), batches[kj][0], after=AFTER)
         else:
-            pend[j] = geo[j % DEPTH].submit(pn2_geometry, batches[kj][0])
+            pend[j] = geo[j % DEPTH].submit(pn2_geometry, batches[kj][0], after=AFTER)
 
-    if geo is not None:
+    # diagnostic only (the line it prints is NOT a benchmark result: the geometry of every step is skipped): layers graph alone
+    LAYERS_ONLY = use_graph and os.environ.get("GSPN_BENCH_LAYERS_ONLY") == "1"
+    SIDE = os.environ.get("GSPN_BENCH_SIDE", "") if LAYERS_ONLY else ""      # diagnostic: a chosen part of the geometry beside the layers
+
+    tiny = torch.zeros(64, device=dev)
+
+    def side_load(i):
+        from gspn_amd.geometry import fp_geometry, sa_geometry
+        from gspn_amd.tf_grouping import query_ball_point
+        kj = i % NB
+        xyz = batches[kj][0]
+
+        def part(x):
+            if "fps0" in SIDE:
+                tf_sampling.farthest_point_sample(2048, x)
+            if "rest" in SIDE:
+                l1 = G[kj]["sa"][0].new_xyz
+                query_ball_point(0.2, 32, x, l1)
+                s2 = sa_geometry(l1, 512, 0.4, 32)
+                s3 = sa_geometry(s2.new_xyz, 128, 0.8, 32)
+                fp_geometry(s2.new_xyz, s3.new_xyz); fp_geometry(l1, s2.new_xyz); fp_geometry(x, l1)
+            if SIDE.startswith("empty"):                       # N trivial kernels: what does a kernel boundary on another queue cost the layers?
+                for _ in range(int(SIDE[5:])):
+                    tiny.fill_(1.0)
+            if "inv" in SIDE:
+                from gspn_amd.geometry import inverse_lists
+                g = G[kj]
+                for lvl, n in ((1, 2048), (2, 512)):
+                    inverse_lists(g["sa"][lvl].idx.reshape(SCENES_PER_GPU, -1), n)
+                for f, n in ((0, 128), (1, 512), (2, 2048)):
+                    inverse_lists(g["fp"][f].idx.reshape(SCENES_PER_GPU, -1), n)
+            if "small" in SIDE:
+                l1 = G[kj]["sa"][0].new_xyz
+                s2 = sa_geometry(l1, 512, 0.4, 32, inverse=False)
+                sa_geometry(s2.new_xyz, 128, 0.8, 32, inverse=False)
+            if "nn" in SIDE:
+                l1 = G[kj]["sa"][0].new_xyz
+                from gspn_amd.tf_interpolate import three_nn
+                three_nn(x, l1)
+            return None
+        if SIDE.startswith("raw"):                             # the same tiny kernels without the submit() events
+            with torch.cuda.stream(geo[i % DEPTH].stream):
+                for _ in range(int(SIDE[3:])):
+                    tiny.fill_(1.0)
+            return
+        geo[i % DEPTH].submit(part, xyz)
+
+    if geo is not None and not LAYERS_ONLY:
         for j in range(DEPTH):
             submit_geometry(j)
 
@@ -127,9 +179,12 @@ def main():
         state["i"] = i + 1
         k = i % NB
         g = None
-        if geo is not None:
-            g = pend.pop(i).get()                             # geometry of THIS step (submitted DEPTH steps ago)
-            submit_geometry(i + DEPTH)                        # runs under the layers of steps i .. i+DEPTH-1
+        if LAYERS_ONLY and SIDE:
+            side_load(i)
+        if geo is not None and not LAYERS_ONLY:
+            tw = time.perf_counter()
+            g = pend.pop(i).get(host_wait=True)               # geometry of THIS step (submitted DEPTH steps ago: long complete)
+            state["t_wait"] += time.perf_counter() - tw
         if use_graph:
             graphs[k].replay()
         else:
@@ -137,6 +192,16 @@ def main():
                 state["opt"].zero_grad(set_to_none=True)      # backward assigns fresh grads; the bucket re-points them at its slices
             fwd_bwd(k, g)
         finish()
+        if geo is not None and not LAYERS_ONLY:
+            # Geometry of step i+DEPTH, to run under the layers of steps i+1 .. i+DEPTH.  In graph mode it refills the persistent buffers
+            # of slot (i+DEPTH) % NB = (i-1) % NB, which the layers of step i-1 read: the HOST waits for that step (step i is already
+            # queued behind it, so the GPU never idles) instead of making the side stream wait on the layers' stream.
+            done[i] = torch.cuda.current_stream().record_event()
+            if (i - 1) in done:
+                tw = time.perf_counter()
+                done.pop(i - 1).synchronize()
+                state["t_wait"] += time.perf_counter() - tw
+            submit_geometry(i + DEPTH)
 
     for _ in range(args.warmup):
         step()
@@ -148,10 +213,11 @@ def main():
 
     tf_sampling.PROFILE = []          # HIP-event pairs around every FPS launch on its stream
     sync()
+    state["t_wait"] = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    t_host = time.perf_counter() - t0                  # host time to enqueue the K steps (launch-bound if close to dt)
+    t_host = time.perf_counter() - t0 - state["t_wait"]   # host time to enqueue the K steps, net of its waits on the GPU (launch-bound if close to dt)
     sync()
     dt = time.perf_counter() - t0
     prof = tf_sampling.PROFILE
@@ -189,7 +255,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" if not LAYERS_ONLY else "DIAGNOSTIC RUN, NOT A RESULT: geometry skipped (GSPN_BENCH_LAYERS_ONLY)",
             "config": {"workload": "BASELINE configs[2]: batch 8 x 32768-pt scenes per GPU, 3-level SA + 3-level FP (three_nn/interpolate) fwd+bwd, "
                                    "pn2_fea_extractor layer spec, BN training mode, Adam step", "scenes_per_gpu": SCENES_PER_GPU,
                        "schedule": "geometry inline" if args.no_overlap else ("geometry of batches k+1, k+2 on two side streams under the layers of batch k"

@@ -63,6 +63,7 @@ SIGNATURES = {
     "gspn_mlp_bwd_data": [_L, _I, _I, _c.POINTER(DyArgs), _P, _P, _I, _P],
     "gspn_mlp_bwd_data_cols": [_L, _I, _I, _c.POINTER(DyArgs), _P, _I, _I, _P, _I, _P],
     "gspn_mlp_bwd_data_dw": [_L, _I, _I, _c.POINTER(DyArgs), _P, _I, _I, _P, _I, _P, _I, _P, _P, _F, _I, _I, _P, _P, _P],
+    "gspn_inverse_lists": [_I, _I, _I, _P, _P, _P, _P, _P],
     "gspn_fill_zero": [_P, _L, _P],
 }
 
@@ -93,6 +94,8 @@ def lib():
         h.gspn_mlp_fwd_stats_bytes.restype = _L
         h.gspn_fps_cells_ws_bytes.argtypes = [_I, _I]
         h.gspn_fps_cells_ws_bytes.restype = _L
+        h.gspn_inverse_lists_work_ints.argtypes = [_I, _I, _I]
+        h.gspn_inverse_lists_work_ints.restype = _L
         _lib = h
     return _lib
 

@@ -375,3 +375,110 @@ extern "C" int gspn_selectionsort(int b, int n, int m, int k, const float* dist,
     hipLaunchKernelGGL(selection_sort_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, rows, n, k, dist, outi, out);
     return gspn_launch_status();
 }
+
+// ============================================================================================
+// Inverse lists (CSR) of an index tensor: for idx (b, L) with values in [0, n), order (b, L) = the positions 0..L-1 grouped by value,
+// ascending inside a group, and offsets (b, n+1) = where each value's group starts.  This is what the gather-form gradients
+// (gspn_sa_group_concat_grad_csr, gspn_fp_concat_grad_csr) walk -- the same result as a stable sort of idx plus a searchsorted, in
+// four small kernels instead of a few dozen:
+//   count   (one thread per position)  histogram with global atomics
+//   scan    (one workgroup per scene)  exclusive scan of the n counts -> offsets, cursors
+//   fill    (one thread per position)  position -> its group, in whatever order the atomics produce
+//   sort    (one wave per value)       rank sort of the group (a handful to a few dozen entries): the final order is unique, so the
+//                                      result does not depend on the atomics' order
+// Positions whose value lies outside [0, n) are dropped (offsets[n] is then smaller than L).
+// ============================================================================================
+__global__ void csr_count_kernel(long total, int L, int n, const int* __restrict__ idx, int* __restrict__ cnt) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k = idx[i];
+        if ((unsigned)k < (unsigned)n) atomicAdd(&cnt[(i / L) * n + k], 1);
+    }
+}
+__global__ __launch_bounds__(1024) void csr_scan_kernel(int n, int* __restrict__ cnt, int* __restrict__ offsets) {
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    int* c = cnt + (size_t)blockIdx.x * n;
+    int* o = offsets + (size_t)blockIdx.x * (n + 1);
+    if (t == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int k = base + t;
+        const int v = k < n ? c[k] : 0;
+        int incl = v;
+#pragma unroll
+        for (int s = 1; s < 64; s <<= 1) { const int u = __shfl_up(incl, s, 64); if (lane >= s) incl += u; }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int before = carry;
+        for (int w = 0; w < wave; ++w) before += wsum[w];
+        const int excl = before + incl - v;
+        if (k < n) { o[k] = excl; c[k] = excl; }                  // cnt becomes the fill cursor
+        __syncthreads();
+        if (t == 1023) carry = excl + v;
+        __syncthreads();
+    }
+    if (t == 0) o[n] = carry;
+}
+__global__ void csr_fill_kernel(long total, int L, int n, const int* __restrict__ idx, int* __restrict__ cursor, int* __restrict__ tmp) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k = idx[i];
+        if ((unsigned)k >= (unsigned)n) continue;
+        const long scene = i / L;
+        const int pos = atomicAdd(&cursor[scene * n + k], 1);
+        tmp[scene * L + pos] = (int)(i - scene * L);
+    }
+}
+// one WAVE per value: rank sort of its group (the positions are distinct, so rank = number of smaller entries), tmp -> order.
+// Groups of up to 64 entries (the usual case: a handful to a few dozen) never touch memory again -- one entry per lane, compared through
+// v_readlane; longer groups count against the group re-read from L2.
+__global__ __launch_bounds__(256) void csr_sort_kernel(long nwaves, int L, int n, const int* __restrict__ offsets, const int* __restrict__ tmp,
+                                                       int* __restrict__ order) {
+    const int lane = threadIdx.x & 63;
+    const long w = blockIdx.x * 4L + (threadIdx.x >> 6);
+    if (w >= nwaves) return;
+    const long scene = w / n;
+    const int k = (int)(w - scene * n);
+    const int* o = offsets + scene * (n + 1);
+    const int e0 = __builtin_amdgcn_readfirstlane(o[k]), e1 = __builtin_amdgcn_readfirstlane(o[k + 1]);
+    const int cnt = e1 - e0;
+    const int* src = tmp + scene * L + e0;
+    int* dst = order + scene * L + e0;
+    if (cnt <= 64) {
+        const int v = lane < cnt ? src[lane] : 0x7FFFFFFF;
+        int rank = 0;
+        for (int j = 0; j < cnt; ++j) rank += (__builtin_amdgcn_readlane(v, j) < v) ? 1 : 0;
+        if (lane < cnt) dst[rank] = v;
+        return;
+    }
+    for (int i = lane; i < cnt; i += 64) {
+        const int v = src[i];
+        int rank = 0;
+        for (int j = 0; j < cnt; ++j) rank += (src[j] < v) ? 1 : 0;
+        dst[rank] = v;
+    }
+}
+// work: b*n ints (counts, then cursors) followed by b*L ints (the unsorted groups)
+extern "C" long gspn_inverse_lists_work_ints(int b, int L, int n) {
+    if (b < 0 || L < 0 || n <= 0) return GSPN_ERR_ARG;
+    return (long)b * n + (long)b * L;
+}
+extern "C" int gspn_inverse_lists(int b, int L, int n, const int* idx, int* work, int* order, int* offsets, void* stream) {
+    if (b < 0 || L < 0 || n <= 0) return GSPN_ERR_ARG;
+    if (b == 0) return 0;
+    if (!idx || !work || !order || !offsets) return GSPN_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(work, 0, sizeof(int) * (size_t)b * n, st);
+    if (e != hipSuccess) return (int)e;
+    const long total = (long)b * L;
+    if (total > 0) hipLaunchKernelGGL(csr_count_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, total, L, n, idx, work);
+    hipLaunchKernelGGL(csr_scan_kernel, dim3(b), dim3(1024), 0, st, n, work, offsets);
+    if (total > 0) {
+        int* tmp = work + (size_t)b * n;
+        const long nwaves = (long)b * n;
+        if ((nwaves + 3) / 4 > 0x7FFFFFFFl) return GSPN_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL(csr_fill_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, total, L, n, idx, work, tmp);
+        hipLaunchKernelGGL(csr_sort_kernel, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, st, nwaves, L, n, offsets, tmp, order);
+    }
+    return gspn_launch_status();
+}

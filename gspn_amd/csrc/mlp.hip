@@ -496,7 +496,9 @@ static inline int pick_bn(long rows, int cols, const char* env) {
     auto nblk = [&](int bn) { return ntiles * ((cols + bn - 1) / bn); };
     auto pad = [&](int bn) { return (cols + bn - 1) / bn * bn; };
     int bn = cols <= 32 ? 32 : (cols <= 64 ? 64 : 128);
-    while (bn > 32 && (nblk(bn) < GSPN_PLAN_CUS || 4 * pad(bn) > 5 * pad(bn / 2))) bn /= 2;
+    static int fill = 0;
+    if (!fill) { const char* e = getenv("GSPN_BN_FILL"); fill = e ? atoi(e) : 2 * GSPN_PLAN_CUS; if (fill <= 0) fill = 2 * GSPN_PLAN_CUS; }
+    while (bn > 32 && (nblk(bn) < fill || 4 * pad(bn) > 5 * pad(bn / 2))) bn /= 2;
     return bn;
 }
 // number of row-blocks (= partial-statistics rows) the forward launch of a (rows, cout) layer uses
@@ -531,7 +533,9 @@ extern "C" int gspn_mlp_fwd(long rows, int cin, int cout, const float* X, int ld
             const size_t dyn = (size_t)(trg == 4 ? lds4 : lds2) + 32u * QX;
             const long ntiles = (rows + 32 * trg - 1) / (32 * trg);
             long bpc = (160L * 1024) / (long)(dyn + 2 * trg * BNs * 4 + 512);
-            if (bpc > 4) bpc = 4;
+            static int bpc_cap = 0;
+            if (!bpc_cap) { const char* e = getenv("GSPN_FWD_BPC"); bpc_cap = e ? atoi(e) : 4; if (bpc_cap < 1) bpc_cap = 4; }
+            if (bpc > bpc_cap) bpc = bpc_cap;
             if (bpc < 1) bpc = 1;
             const unsigned nparts = fwd_blocks(rows, cout);
             long gx = (long)GSPN_PLAN_CUS * bpc / yt;

@@ -241,6 +241,9 @@ __global__ __launch_bounds__(FPS_T) void fps_resident_kernel(int n, int m, const
 //     duplicate of one) repeats the rank-minimal point, like the reference.
 // ============================================================================================
 #define FPS_AMAX 6        // max picks accepted per round
+#ifndef FPS_YIELD_SLEEP
+#define FPS_YIELD_SLEEP 1
+#endif
 #ifdef FPS_PROFILE
 __device__ long long g_cell_prof[32];
 __device__ int g_cell_waves[16 * 4];      // per wave of scene 0: {applies, refreshes, -, -}
@@ -385,7 +388,7 @@ __global__ __launch_bounds__(FPS_T) void fps_cell_kernel(int n, int m, int csz, 
                         td[pp][1] = vmin_f32(d[1], td[pp][1]);
                     }
                     zq = zn;
-                    if (yield) __builtin_amdgcn_s_sleep(1);      // background mode: see gspn_fps_background
+                    if (yield) __builtin_amdgcn_s_sleep(FPS_YIELD_SLEEP);      // background mode: see gspn_fps_background
                 }
             } else {
 #pragma unroll

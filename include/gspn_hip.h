@@ -242,6 +242,14 @@ int gspn_mlp_bwd_data_dw(long rows, int cin, int cout, const gspn_dy_args* a, co
                          const float* X, int ldx_in, const float* var, const float* gamma, float eps, int use_bn, int is_training,
                          const float* work, float* dW, void* stream);
 
+/* Inverse lists (CSR) of an index tensor -- what the gather-form gradients walk.  idx (b,L) int32 with values in [0,n):
+ * order (b,L) = positions 0..L-1 grouped by value, ascending inside a group; offsets (b,n+1) = start of every group (offsets[n] = L).
+ * Same result as a stable sort of idx + searchsorted.  work: gspn_inverse_lists_work_ints(b,L,n) ints.  Positions with a value
+ * outside [0,n) are dropped.
+ * (Extension: the reference scatters with atomicAdd -- tf_grouping_g.cu:78-86, tf_interpolate.cpp:119-143 -- and needs no such lists.) */
+long gspn_inverse_lists_work_ints(int b, int L, int n);
+int gspn_inverse_lists(int b, int L, int n, const int* idx, int* work, int* order, int* offsets, void* stream);
+
 int gspn_fill_zero(void* ptr, long bytes, void* stream);
 
 #ifdef __cplusplus

@@ -324,3 +324,19 @@ def test_training_step_is_bit_reproducible():
     assert torch.equal(res[0][0], res[1][0])
     for n in res[0][1]:
         assert torch.equal(res[0][1][n], res[1][1][n]), n
+
+
+@pytest.mark.parametrize("b,ln,n", [(8, 98304, 2048), (8, 16384, 2048), (2, 6144, 512), (3, 1000, 128), (1, 5, 3), (2, 4096, 5000), (1, 70000, 1)])
+def test_inverse_lists_match_stable_sort(b, ln, n):
+    """gspn_inverse_lists == stable sort of the indices + searchsorted (the order the gather-form gradients sum in)"""
+    from gspn_amd.geometry import inverse_lists
+    g = torch.Generator().manual_seed(ln + n)
+    idx = torch.randint(0, n, (b, ln), generator=g, dtype=torch.int32)
+    if n > 4:
+        idx[:, : ln // 3] = idx[:, : ln // 3] % 3             # a few crowded values: long groups
+    order, offsets = inverse_lists(idx.cuda(), n)
+    keys, ref_order = torch.sort(idx.long(), dim=1, stable=True)
+    bounds = torch.arange(n + 1).unsqueeze(0).expand(b, -1).contiguous()
+    ref_off = torch.searchsorted(keys.contiguous(), bounds)
+    assert torch.equal(offsets.cpu().long(), ref_off)
+    assert torch.equal(order.cpu().long(), ref_order)
