@@ -64,6 +64,8 @@ SIGNATURES = {
     "gspn_mlp_bwd_data_cols": [_L, _I, _I, _c.POINTER(DyArgs), _P, _I, _I, _P, _I, _P],
     "gspn_mlp_bwd_data_dw": [_L, _I, _I, _c.POINTER(DyArgs), _P, _I, _I, _P, _I, _P, _I, _P, _P, _F, _I, _I, _P, _P, _P],
     "gspn_inverse_lists": [_I, _I, _I, _P, _P, _P, _P, _P],
+    "gspn_multi_copy": [_I, _P, _P, _P, _P],
+    "gspn_three_nn_weights": [_L, _P, _P, _P],
     "gspn_fill_zero": [_P, _L, _P],
 }
 

@@ -327,3 +327,25 @@ extern "C" int gspn_fp_concat_grad_csr(int b, int n, int m, int c2, int c1, int 
                        weight, grad_points2, grad_points1, nwaves2, copy_total);
     return gspn_launch_status();
 }
+
+// ============================================================================================
+// Inverse-distance weights of the three neighbours (utils/pointnet_util.py:157-160):
+//   dist = max(dist, 1e-10); norm = sum_k 1/dist_k; weight_k = (1/dist_k) / norm          -- one kernel instead of five element-wise ones
+// ============================================================================================
+__global__ void three_nn_weights_kernel(long total, const float* __restrict__ dist, float* __restrict__ weight) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const float d0 = fmaxf(dist[i * 3 + 0], 1e-10f), d1 = fmaxf(dist[i * 3 + 1], 1e-10f), d2 = fmaxf(dist[i * 3 + 2], 1e-10f);
+        const float r0 = 1.0f / d0, r1 = 1.0f / d1, r2 = 1.0f / d2;
+        const float norm = (r0 + r1) + r2;
+        weight[i * 3 + 0] = r0 / norm;
+        weight[i * 3 + 1] = r1 / norm;
+        weight[i * 3 + 2] = r2 / norm;
+    }
+}
+extern "C" int gspn_three_nn_weights(long total, const float* dist, float* weight, void* stream) {
+    if (total < 0) return GSPN_ERR_ARG;
+    if (total == 0) return 0;
+    if (!dist || !weight) return GSPN_ERR_ARG;
+    hipLaunchKernelGGL(three_nn_weights_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, total, dist, weight);
+    return gspn_launch_status();
+}

@@ -75,9 +75,10 @@ def sa_geometry(xyz, npoint, radius, nsample, knn=False, inverse=True):
 def fp_geometry(xyz1, xyz2):
     """pointnet_util.py:155-160: three nearest sparse points of every dense point and their normalised 1/d weights."""
     dist, idx = three_nn(xyz1.detach(), xyz2.detach())
-    dist = torch.clamp(dist, min=1e-10)                               # :157
-    norm = (1.0 / dist).sum(dim=2, keepdim=True)                      # :158
-    weight = (1.0 / dist) / norm                                      # :160
+    # :157-160 -- dist = max(dist, 1e-10); norm = sum(1/dist); weight = (1/dist)/norm, in one kernel
+    weight = torch.empty_like(dist)
+    with torch.cuda.device(dist.device):
+        L.check(L.lib().gspn_three_nn_weights(dist.numel() // 3, L.ptr(dist), L.ptr(weight), L.stream()), "three_nn_weights")
     # inverse lists for the gradient (three_interpolate_grad as a gather in the reference's own summation order)
     b, n1, _ = idx.shape
     order, offsets = inverse_lists(idx.reshape(b, 3 * n1), xyz2.shape[1])

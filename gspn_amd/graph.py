@@ -38,17 +38,38 @@ class CapturedStep:
         return self.result
 
 
-def copy_into(dst, src):
-    """Copy a (nested) geometry result into persistent buffers of the same structure (on the current stream)."""
+def _pairs(dst, src, out):
     if isinstance(dst, torch.Tensor):
-        dst.copy_(src, non_blocking=True)
+        out.append((dst, src))
     elif isinstance(dst, dict):
         for k in dst:
-            copy_into(dst[k], src[k])
+            _pairs(dst[k], src[k], out)
     elif isinstance(dst, (list, tuple)):
         for d, s in zip(dst, src):
-            copy_into(d, s)
+            _pairs(d, s, out)
     elif hasattr(dst, "tensors"):
-        for d, s in zip(dst.tensors(), src.tensors()):
-            d.copy_(s, non_blocking=True)
+        out.extend(zip(dst.tensors(), src.tensors()))
+    return out
+
+
+def copy_into(dst, src):
+    """Copy a (nested) geometry result into persistent buffers of the same structure, on the current stream, in ONE launch
+    (gspn_multi_copy) instead of one copy kernel per tensor."""
+    import ctypes
+    from . import _lib as L
+    pairs = _pairs(dst, src, [])
+    keep = []
+    ps, pd, pb = [], [], []
+    for d, s in pairs:
+        if d.shape != s.shape or d.dtype != s.dtype or d.device != s.device:
+            raise ValueError("copy_into: mismatched tensors %s %s vs %s %s" % (tuple(d.shape), d.dtype, tuple(s.shape), s.dtype))
+        if not d.is_contiguous():
+            raise ValueError("copy_into: destination buffers must be contiguous")
+        s = s.contiguous()
+        keep.append(s)
+        ps.append(s.data_ptr()); pd.append(d.data_ptr()); pb.append(s.numel() * s.element_size())
+    n = len(ps)
+    if n:
+        with torch.cuda.device(pairs[0][0].device):
+            L.check(L.lib().gspn_multi_copy(n, (ctypes.c_void_p * n)(*ps), (ctypes.c_void_p * n)(*pd), (ctypes.c_long * n)(*pb), L.stream()), "multi_copy")
     return dst

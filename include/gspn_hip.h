@@ -250,6 +250,14 @@ int gspn_mlp_bwd_data_dw(long rows, int cin, int cout, const gspn_dy_args* a, co
 long gspn_inverse_lists_work_ints(int b, int L, int n);
 int gspn_inverse_lists(int b, int L, int n, const int* idx, int* work, int* order, int* offsets, void* stream);
 
+/* utils/pointnet_util.py:157-160 in one kernel: dist (total,3) squared distances of three_nn -> weight (total,3):
+ * d = max(d, 1e-10); weight_k = (1/d_k) / ((1/d_0 + 1/d_1) + 1/d_2) */
+int gspn_three_nn_weights(long total, const float* dist, float* weight, void* stream);
+
+/* n device-to-device copies (src[i] -> dst[i], bytes[i] bytes; the three arrays live on the HOST) in one launch per 40 segments:
+ * refills the persistent buffers a captured step reads (extension: scheduling helper, no reference counterpart). */
+int gspn_multi_copy(int n, const void* const* src, void* const* dst, const long* bytes, void* stream);
+
 int gspn_fill_zero(void* ptr, long bytes, void* stream);
 
 #ifdef __cplusplus

@@ -326,7 +326,7 @@ def test_training_step_is_bit_reproducible():
         assert torch.equal(res[0][1][n], res[1][1][n]), n
 
 
-@pytest.mark.parametrize("b,ln,n", [(8, 98304, 2048), (8, 16384, 2048), (2, 6144, 512), (3, 1000, 128), (1, 5, 3), (2, 4096, 5000), (1, 70000, 1)])
+@pytest.mark.parametrize("b,ln,n", [(8, 98304, 2048), (8, 16384, 2048), (2, 6144, 512), (3, 1000, 128), (1, 5, 3), (2, 4096, 5000), (1, 70000, 1), (2, 30000, 9000)])
 def test_inverse_lists_match_stable_sort(b, ln, n):
     """gspn_inverse_lists == stable sort of the indices + searchsorted (the order the gather-form gradients sum in)"""
     from gspn_amd.geometry import inverse_lists
@@ -340,3 +340,34 @@ def test_inverse_lists_match_stable_sort(b, ln, n):
     ref_off = torch.searchsorted(keys.contiguous(), bounds)
     assert torch.equal(offsets.cpu().long(), ref_off)
     assert torch.equal(order.cpu().long(), ref_order)
+
+
+def test_copy_into_multi_copy():
+    """graph.copy_into refills a nested structure of persistent buffers with one gspn_multi_copy launch: odd sizes, unaligned views, > 40 tensors"""
+    from gspn_amd.graph import copy_into
+    g = torch.Generator().manual_seed(0)
+    sizes = [1, 3, 17, 4096, 65536 // 4 + 5, 300001] + [7 + i for i in range(45)]
+    src = {"a": [torch.randn(n, generator=g).cuda() for n in sizes], "b": (torch.randint(0, 1000, (8, 33, 5), generator=g, dtype=torch.int32).cuda(),)}
+    base = torch.zeros(1000, device="cuda")
+    src["a"].append(base[1:998])                               # 4-byte aligned only
+    dst = {"a": [torch.zeros_like(t) for t in src["a"]], "b": (torch.zeros_like(src["b"][0]),)}
+    dst["a"][-1] = torch.zeros(999, device="cuda")[2:999]
+    src["a"][-1].copy_(torch.randn(997, generator=g))
+    copy_into(dst, src)
+    torch.cuda.synchronize()
+    for d, s_ in zip(dst["a"], src["a"]):
+        assert torch.equal(d, s_)
+    assert torch.equal(dst["b"][0], src["b"][0])
+
+
+def test_three_nn_weights_formula():
+    from gspn_amd import _lib as L
+    g = torch.Generator().manual_seed(1)
+    dist = torch.rand(5000, 3, generator=g).cuda() ** 4
+    dist[::7, 0] = 0.0                                         # coincident points: clamped at 1e-10
+    w = torch.empty_like(dist)
+    L.check(L.lib().gspn_three_nn_weights(dist.shape[0], L.ptr(dist), L.ptr(w), L.stream()), "w")
+    d = torch.clamp(dist, min=1e-10)
+    ref = (1.0 / d) / (1.0 / d).sum(dim=1, keepdim=True)
+    assert rel_err(w, ref) < 1e-6
+    assert torch.allclose(w.sum(dim=1), torch.ones(5000, device="cuda"), atol=1e-6)
