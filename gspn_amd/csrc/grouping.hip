@@ -482,3 +482,57 @@ extern "C" int gspn_inverse_lists(int b, int L, int n, const int* idx, int* work
     }
     return gspn_launch_status();
 }
+
+// ============================================================================================
+// Many small device-to-device copies in ONE launch (refilling the persistent geometry buffers a captured step reads: ~30 tensors of a
+// few KB to a few MB per batch -- 30 copy kernels otherwise).  Segment table by value in the kernel arguments; every segment is split
+// into 64 KB pieces and the pieces are spread over the grid.  16-byte aligned segments move as uint4, the rest bytewise.
+// ============================================================================================
+#define MC_MAX 40
+struct McTable {
+    const char* src[MC_MAX];
+    char* dst[MC_MAX];
+    long bytes[MC_MAX];
+    long first_piece[MC_MAX + 1];          // prefix sum of ceil(bytes / 65536)
+    int n;
+};
+__global__ __launch_bounds__(256) void multi_copy_kernel(McTable t) {
+    const long npieces = t.first_piece[t.n];
+    for (long p = blockIdx.x; p < npieces; p += gridDim.x) {
+        int s = 0;
+        while (s + 1 < t.n && t.first_piece[s + 1] <= p) ++s;
+        const long off = (p - t.first_piece[s]) * 65536L;
+        const long len = t.bytes[s] - off < 65536L ? t.bytes[s] - off : 65536L;
+        const char* a = t.src[s] + off;
+        char* d = t.dst[s] + off;
+        if ((((uintptr_t)a | (uintptr_t)d) & 15) == 0) {
+            const long nv = len >> 4;
+            for (long i = threadIdx.x; i < nv; i += 256) reinterpret_cast<uint4*>(d)[i] = reinterpret_cast<const uint4*>(a)[i];
+            for (long i = (nv << 4) + threadIdx.x; i < len; i += 256) d[i] = a[i];
+        } else {
+            for (long i = threadIdx.x; i < len; i += 256) d[i] = a[i];
+        }
+    }
+}
+extern "C" int gspn_multi_copy(int n, const void* const* src, void* const* dst, const long* bytes, void* stream) {
+    if (n < 0 || (n > 0 && (!src || !dst || !bytes))) return GSPN_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    for (int base = 0; base < n; base += MC_MAX) {
+        McTable t;
+        t.n = 0;
+        t.first_piece[0] = 0;
+        for (int i = base; i < n && i < base + MC_MAX; ++i) {
+            if (bytes[i] < 0 || (bytes[i] > 0 && (!src[i] || !dst[i]))) return GSPN_ERR_ARG;
+            if (bytes[i] == 0) continue;
+            t.src[t.n] = static_cast<const char*>(src[i]);
+            t.dst[t.n] = static_cast<char*>(dst[i]);
+            t.bytes[t.n] = bytes[i];
+            t.first_piece[t.n + 1] = t.first_piece[t.n] + (bytes[i] + 65535) / 65536;
+            ++t.n;
+        }
+        if (t.n == 0) continue;
+        const long np = t.first_piece[t.n];
+        hipLaunchKernelGGL(multi_copy_kernel, dim3((unsigned)(np < 2048 ? np : 2048)), dim3(256), 0, st, t);
+    }
+    return gspn_launch_status();
+}
