@@ -237,7 +237,9 @@ def main():
     pmc = os.path.join(ROOT, "profiles", "r01_fps_pmc.json")
     if os.path.exists(pmc):
         try:
-            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            pj = json.load(open(pmc))
+            # the timed bracket holds the sampling kernel alone: its own HBM bytes (the whole call incl. the sort pre-pass: pj["hbm_bytes_per_launch"])
+            traffic = next((v["hbm_bytes_per_launch"] for k, v in pj.get("kernels", {}).items() if "fps_cell_kernel" in k), pj.get("hbm_bytes_per_launch"))
         except Exception:
             traffic = None
 
