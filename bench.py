@@ -90,7 +90,7 @@ def main():
         if state["bucket"] is None:
             params = store.parameters()
             state["bucket"] = parallel.FlatGradBucket(params)
-            state["opt"] = torch.optim.Adam(params, lr=1e-3, fused=True)     # one multi-tensor kernel for the whole update
+            state["opt"] = parallel.FlatAdam(state["bucket"], lr=1e-3)       # one kernel for the whole update (parameters live in one flat buffer)
         state["bucket"].flatten()
         return loss.detach()          # (a live loss would keep the autograd graph -- and its AccumulateGrad nodes -- alive across captures)
 

@@ -71,3 +71,38 @@ class FlatGradBucket:
     def all_reduce_mean(self):
         self.flatten()
         return self.all_reduce()
+
+
+class FlatAdam:
+    """Adam over the bucket's parameters as ONE buffer: the parameters are moved into a flat fp32 tensor (each `p.data` becomes a view of
+    it -- do this before anything captures their addresses), the gradients are the bucket's flat tensor, and step() is a single
+    gspn_adam_flat launch (torch.optim.Adam's update rule; tested against it) instead of a multi-tensor launch per ~50 tensors."""
+
+    def __init__(self, bucket, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        self.bucket = bucket
+        self.lr, self.betas, self.eps, self.weight_decay = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
+        self.flat = torch.empty_like(bucket.flat)
+        off = 0
+        with torch.no_grad():
+            for p, s in zip(bucket.params, bucket.sizes):
+                view = self.flat[off:off + s].view_as(p)
+                view.copy_(p)
+                p.data = view
+                off += s
+        self.m = torch.zeros_like(self.flat)
+        self.v = torch.zeros_like(self.flat)
+        self.t = 0
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.bucket.params:
+            if set_to_none:
+                p.grad = None
+            elif p.grad is not None:
+                p.grad.zero_()
+
+    def step(self):
+        from . import _lib as L
+        self.t += 1
+        with torch.cuda.device(self.flat.device):
+            L.check(L.lib().gspn_adam_flat(self.flat.numel(), L.ptr(self.flat), L.ptr(self.bucket.flat), L.ptr(self.m), L.ptr(self.v), self.lr,
+                                           self.betas[0], self.betas[1], self.eps, self.weight_decay, self.t, L.stream()), "adam_flat")

@@ -371,3 +371,28 @@ def test_three_nn_weights_formula():
     ref = (1.0 / d) / (1.0 / d).sum(dim=1, keepdim=True)
     assert rel_err(w, ref) < 1e-6
     assert torch.allclose(w.sum(dim=1), torch.ones(5000, device="cuda"), atol=1e-6)
+
+
+def test_flat_adam_matches_torch_adam():
+    """parallel.FlatAdam (one gspn_adam_flat launch over the flat parameter / gradient buffers) follows torch.optim.Adam"""
+    from gspn_amd.parallel import FlatAdam, FlatGradBucket
+    g = torch.Generator().manual_seed(3)
+    shapes = [(6, 32), (32,), (32, 64), (64,), (1, 1, 67, 64), (5,)]
+    init = [torch.randn(*s_, generator=g) for s_ in shapes]
+    pa = [torch.nn.Parameter(t.clone().cuda()) for t in init]
+    pb = [torch.nn.Parameter(t.clone().cuda()) for t in init]
+    ref = torch.optim.Adam(pa, lr=1e-2)
+    bucket = FlatGradBucket(pb)
+    opt = FlatAdam(bucket, lr=1e-2)
+    for step in range(6):
+        grads = [torch.randn(*s_, generator=g).cuda() * (10.0 ** (step - 3)) for s_ in shapes]
+        for p_, q_, gr in zip(pa, pb, grads):
+            p_.grad = gr.clone()
+            q_.grad = gr.clone()
+        bucket.flatten()
+        ref.step()
+        opt.step()
+    torch.cuda.synchronize()
+    for p_, q_ in zip(pa, pb):
+        assert q_.data_ptr() >= opt.flat.data_ptr() and q_.data_ptr() < opt.flat.data_ptr() + opt.flat.numel() * 4
+        assert rel_err(q_.detach(), p_.detach()) < 2e-6
