@@ -108,7 +108,9 @@ __device__ __forceinline__ DzRaw dz4_raw(const gspn_dy_args& a, long row, int co
     if constexpr (!POOLED) {
         r.v = load4_raw<VEC>(a.dZ, row, a.ldz, col, c);
     } else {
-        const int g = (int)row / a.ns;                       // rows < 2^31 (checked by the launcher)
+        // rows < 2^31 (checked by the launcher).  Pool groups of 2^k rows (the usual nsample = 16/32/64) take a shift: a 32-bit integer
+        // division is ~25 VALU instructions, and this runs per row quad of every chunk
+        const int g = ((a.ns & (a.ns - 1)) == 0) ? ((int)row >> __builtin_ctz(a.ns)) : ((int)row / a.ns);
         const int last = c - 1;
         const int* ar = a.pool_arg + (size_t)g * c;
         const float* dp = a.dPool + (size_t)g * c;
@@ -126,7 +128,7 @@ __device__ __forceinline__ DzRaw dz4_raw(const gspn_dy_args& a, long row, int co
 template <bool POOLED>
 __device__ __forceinline__ float4 dz4_resolve(const gspn_dy_args& a, const DzRaw& r, long row) {
     if constexpr (!POOLED) return r.v;
-    const int off = (int)row % a.ns;
+    const int off = ((a.ns & (a.ns - 1)) == 0) ? ((int)row & (a.ns - 1)) : ((int)row % a.ns);
     float4 v;
     v.x = r.arg.x == off ? r.v.x : 0.f;
     v.y = r.arg.y == off ? r.v.y : 0.f;
