@@ -163,6 +163,14 @@ def main():
                 from gspn_amd.tf_interpolate import three_nn
                 three_nn(x, l1)
             return None
+        if SIDE.startswith("spin"):                            # spin:<which>:<blocks>:<threads>:<amount> -- resident workgroups of tools/spin_probe.hip beside the layers
+            import ctypes
+            if "spin" not in state:
+                state["spin"] = ctypes.CDLL(os.path.join(ROOT, "tools", "libspin_probe.so"))
+            _, which, blocks, threads, amount = SIDE.split(":")          # amount: shader-clock cycles (spin_*/hold_*) or iterations (loop_*)
+            state["spin"].launch_spin(int(which), int(blocks), int(threads), ctypes.c_longlong(int(amount)), ctypes.c_void_p(tiny.data_ptr()),
+                                      ctypes.c_void_p(geo[i % DEPTH].stream.cuda_stream))
+            return
         if SIDE.startswith("raw"):                             # the same tiny kernels without the submit() events
             with torch.cuda.stream(geo[i % DEPTH].stream):
                 for _ in range(int(SIDE[3:])):
