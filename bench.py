@@ -95,8 +95,8 @@ def main():
         return loss.detach()          # (a live loss would keep the autograd graph -- and its AccumulateGrad nodes -- alive across captures)
 
     def finish():
-        state["bucket"].all_reduce()                 # one flat RCCL all-reduce (no-op at world 1)
-        state["opt"].step()
+        state["bucket"].all_reduce(average=False)    # one flat RCCL all-reduce (SUM; no-op at world 1)
+        state["opt"].step(grad_scale=1.0 / world)    # the division by the world size rides in the Adam kernel
 
     graphs = None
     if use_graph:

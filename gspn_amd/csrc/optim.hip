@@ -6,9 +6,9 @@
 #include "common.h"
 
 __global__ void adam_flat_kernel(long n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                                 float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt, float weight_decay) {
+                                 float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt, float weight_decay, float grad_scale) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        float gi = g[i];
+        float gi = g[i] * grad_scale;
         const float pi = p[i];
         if (weight_decay != 0.f) gi = fmaf(weight_decay, pi, gi);
         const float mi = fmaf(1.f - b1, gi - m[i], m[i]);                  // lerp, as torch does
@@ -20,13 +20,14 @@ __global__ void adam_flat_kernel(long n, float* __restrict__ p, const float* __r
     }
 }
 // step >= 1 is the number of this update (bias corrections 1 - b^step are computed on the host in double)
+// grad_scale multiplies every gradient first (1/world_size after a SUM all-reduce: saves the separate division kernel)
 extern "C" int gspn_adam_flat(long n, float* p, const float* g, float* m, float* v, float lr, float b1, float b2, float eps, float weight_decay,
-                              long step, void* stream) {
+                              float grad_scale, long step, void* stream) {
     if (n < 0 || step < 1) return GSPN_ERR_ARG;
     if (n == 0) return 0;
     if (!p || !g || !m || !v) return GSPN_ERR_ARG;
     const double bc1 = 1.0 - pow((double)b1, (double)step), bc2 = 1.0 - pow((double)b2, (double)step);
     hipLaunchKernelGGL(adam_flat_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, n, p, g, m, v, lr, b1, b2, eps, (float)bc1,
-                       (float)sqrt(bc2), weight_decay);
+                       (float)sqrt(bc2), weight_decay, grad_scale);
     return gspn_launch_status();
 }

@@ -62,10 +62,13 @@ class FlatGradBucket:
             p.grad = v
         return self.flat
 
-    def all_reduce(self):
+    def all_reduce(self, average=True):
+        """SUM all-reduce of the bucket over the ranks; average=False leaves the sum (FlatAdam.step(grad_scale=1/world) folds the division
+        into the update)."""
         if dist.is_initialized() and dist.get_world_size() > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-            self.flat.div_(dist.get_world_size())
+            if average:
+                self.flat.div_(dist.get_world_size())
         return self.flat
 
     def all_reduce_mean(self):
@@ -100,9 +103,9 @@ class FlatAdam:
             elif p.grad is not None:
                 p.grad.zero_()
 
-    def step(self):
+    def step(self, grad_scale=1.0):
         from . import _lib as L
         self.t += 1
         with torch.cuda.device(self.flat.device):
             L.check(L.lib().gspn_adam_flat(self.flat.numel(), L.ptr(self.flat), L.ptr(self.bucket.flat), L.ptr(self.m), L.ptr(self.v), self.lr,
-                                           self.betas[0], self.betas[1], self.eps, self.weight_decay, self.t, L.stream()), "adam_flat")
+                                           self.betas[0], self.betas[1], self.eps, self.weight_decay, float(grad_scale), self.t, L.stream()), "adam_flat")

@@ -259,9 +259,10 @@ int gspn_three_nn_weights(long total, const float* dist, float* weight, void* st
 int gspn_multi_copy(int n, const void* const* src, void* const* dst, const long* bytes, void* stream);
 
 /* Adam (torch.optim.Adam's rule; the reference trains with tf.train.AdamOptimizer) over one flat fp32 buffer of n parameters:
- * p, g (gradients), m, v (moments) all flat; step >= 1 = number of this update.  One launch for the whole model. */
+ * p, g (gradients), m, v (moments) all flat; g is multiplied by grad_scale first (1/world after a SUM all-reduce); step >= 1 = number of
+ * this update.  One launch for the whole model. */
 int gspn_adam_flat(long n, float* p, const float* g, float* m, float* v, float lr, float b1, float b2, float eps, float weight_decay,
-                   long step, void* stream);
+                   float grad_scale, long step, void* stream);
 
 int gspn_fill_zero(void* ptr, long bytes, void* stream);
 
