@@ -33,6 +33,12 @@ def _worker(rank, world, port, out):
     # equal shard sizes: mean of rank means == global mean over all 16 scenes
     expect = float((scenes + 1).mean())
     ok = all(torch.allclose(p.grad, torch.full_like(p, expect)) for p in ps)
+    # the form bench.py uses: SUM all-reduce, the 1/world scale is applied later (inside the Adam kernel on the GPU)
+    for p, g in zip(ps, local_g):
+        p.grad = g.clone()
+    bk.flatten()
+    bk.all_reduce(average=False)
+    ok = ok and all(torch.allclose(p.grad / w, torch.full_like(p, expect)) for p in ps)
     out[rank] = (ok, lo, hi)
     dist.barrier()
     dist.destroy_process_group()
