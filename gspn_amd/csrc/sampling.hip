@@ -1,6 +1,7 @@
 // sampling.hip -- tf_ops/sampling on gfx950: farthest point sampling, gather_point (+grad),
 // prob_sample.  Reference semantics: tf_ops/sampling/tf_sampling_g.cu (cited per kernel).
 #include "common.h"
+#include <stdlib.h>
 
 // ============================================================================================
 // Farthest point sampling (reference: tf_sampling_g.cu:105-170)
@@ -865,11 +866,84 @@ extern "C" int gspn_farthestpointsampling_cells(int b, int n, int m, const float
     return gspn_fps_cells_sample(b, n, m, inp, ws, out, stream);
 }
 
+// ============================================================================================
+// Small scenes (n <= 2048: the second and third SA level): the same on-chip scheme with FOUR waves instead of sixteen.  A round of
+// fps_resident_kernel at these sizes is all synchronisation (8 VALU instructions of distance update per wave against a 16-wave
+// barrier and a 16-candidate exchange); 256 threads with 2C points each (C = ceil(n/512) <= 4) halve the round time and leave the rest
+// of the CU to other workgroups.  Thread t, slot p hold the point of reference tie rank q = t*2C + p, i.e. k = (q % C)*512 + q / C, so
+// "lowest (wave, lane, slot)" is again (k mod 512 asc, k asc).  Each lane carries its best slot's coordinates and index along with
+// the maximum, so the winner needs no second look-up.
+// ============================================================================================
+template <int C>
+__global__ __launch_bounds__(256) void fps_small_kernel(int n, int m, const float* __restrict__ inp, int* __restrict__ out) {
+    constexpr int P = 2 * C;
+    __shared__ int4 s_cand[2][4];            // {max bits, x, y, z} per wave, double buffered
+    __shared__ int s_k[2][4];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const float* xyz = inp + (size_t)blockIdx.x * n * 3;
+    int* o = out + (size_t)blockIdx.x * m;
+    float x[P], y[P], z[P], td[P];
+    int kk[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const int q = t * P + p;
+        const int k = (q % C) * 512 + q / C;
+        const int kc = k < n ? k : n - 1;
+        kk[p] = k;
+        x[p] = xyz[kc * 3 + 0]; y[p] = xyz[kc * 3 + 1]; z[p] = xyz[kc * 3 + 2];
+        td[p] = k < n ? 1e38f : -1.0f;        // tf_sampling_g.cu:117-119; padding never wins (real candidates are >= 0)
+    }
+    if (t == 0) o[0] = 0;                      // :114-116
+    float cx = xyz[0], cy = xyz[1], cz = xyz[2];
+    for (int j = 1; j < m; ++j) {
+        int best = NEG_ONE_BITS, bk = 0;
+        float bx = 0.f, by = 0.f, bz = 0.f;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const float d = dist2_cuda(x[p] - cx, y[p] - cy, z[p] - cz);          // :139-142
+            td[p] = vmin_f32(d, td[p]);                                          // :143
+            const int v = __float_as_int(td[p]);
+            const bool up = v > best;                                             // strict: the lowest slot keeps a tie (:146-149)
+            best = up ? v : best;
+            bx = up ? x[p] : bx; by = up ? y[p] : by; bz = up ? z[p] : bz;
+            bk = up ? kk[p] : bk;
+        }
+        const int wmax = wave_max_i32(best);
+        const int lw = __builtin_ctzll(__ballot(best == wmax));                  // lowest lane on ties
+        const int buf = j & 1;
+        if (lane == lw) {
+            s_cand[buf][wave] = make_int4(wmax, __float_as_int(bx), __float_as_int(by), __float_as_int(bz));
+            s_k[buf][wave] = bk;
+        }
+        __syncthreads();
+        const int4 c0 = s_cand[buf][0], c1 = s_cand[buf][1], c2 = s_cand[buf][2], c3 = s_cand[buf][3];
+        int w = 0, mv = c0.x;
+        if (c1.x > mv) { mv = c1.x; w = 1; }                                      // lowest wave on ties
+        if (c2.x > mv) { mv = c2.x; w = 2; }
+        if (c3.x > mv) { mv = c3.x; w = 3; }
+        const int4 cw = w == 0 ? c0 : (w == 1 ? c1 : (w == 2 ? c2 : c3));
+        cx = __int_as_float(cw.y); cy = __int_as_float(cw.z); cz = __int_as_float(cw.w);
+        if (t == 0) o[j] = s_k[buf][w];                                          // :166-168
+    }
+}
+template <int C>
+static int launch_fps_small(int b, int n, int m, const float* inp, int* out, hipStream_t st) {
+    hipLaunchKernelGGL((fps_small_kernel<C>), dim3(b), dim3(256), 0, st, n, m, inp, out);
+    return gspn_launch_status();
+}
+
 extern "C" int gspn_farthestpointsampling(int b, int n, int m, const float* inp, float* temp, int* out, void* stream) {
     if (b < 0 || n <= 0 || m <= 0) return GSPN_ERR_ARG;          // tf_sampling.cpp:99,105
     if (b == 0) return 0;
     if (!inp || !out) return GSPN_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
+    if (n <= 2048 && !(getenv("GSPN_FPS_NO_SMALL") && getenv("GSPN_FPS_NO_SMALL")[0])) {
+        if (n <= 512) return launch_fps_small<1>(b, n, m, inp, out, st);
+        if (n <= 1024) return launch_fps_small<2>(b, n, m, inp, out, st);
+        if (n <= 1536) return launch_fps_small<3>(b, n, m, inp, out, st);
+        return launch_fps_small<4>(b, n, m, inp, out, st);
+    }
     if (n <= 2048) return launch_fps_resident<2, false>(b, n, m, inp, out, st);
     if (n <= 4096) return launch_fps_resident<4, false>(b, n, m, inp, out, st);
     if (n <= 8192) return launch_fps_resident<8, false>(b, n, m, inp, out, st);
