@@ -62,8 +62,16 @@ extern "C" __global__ __launch_bounds__(1024) void hold_vgpr(long long cycles, f
     while (clock64() - t0 < cycles) { __builtin_amdgcn_s_sleep(64); }
     if (cycles == 1) out[0] = 1.f;
 }
+// only the workgroups with blockIdx % 8 == 0 spin: with the round-robin workgroup -> XCD mapping all of them sit on ONE XCD
+extern "C" __global__ void spin_valu_one_xcd(long long cycles, float* out) {
+    if (blockIdx.x % 8 != 0) return;
+    long long t0 = clock64(); float a = threadIdx.x;
+    while (clock64() - t0 < cycles) { for (int i = 0; i < 64; ++i) a = a * 1.0001f + 0.5f; }
+    if (a == 1.2345f) out[0] = a;
+}
 extern "C" int launch_spin(int which, int blocks, int threads, long long cycles, float* out, void* stream) {
     hipStream_t st = (hipStream_t)stream;
+    if (which == 11) { hipLaunchKernelGGL(spin_valu_one_xcd, dim3(blocks), dim3(threads), 0, st, cycles, out); return (int)hipGetLastError(); }
     if (which == 9) { hipFuncSetAttribute(reinterpret_cast<const void*>(&hold_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 131072); hipLaunchKernelGGL(hold_lds, dim3(blocks), dim3(threads), 131072, st, cycles, out); }
     else if (which == 10) hipLaunchKernelGGL(hold_vgpr, dim3(blocks), dim3(threads), 0, st, cycles, out);
     else if (which == 6) hipLaunchKernelGGL(loop_valu_yield<0>, dim3(blocks), dim3(threads), 0, st, cycles, out);
