@@ -29,11 +29,14 @@ SIGNATURES = {
     "gspn_dist_policy": [],
     "gspn_abi_version": [],
     "gspn_farthestpointsampling": [_I, _I, _I, _P, _P, _P, _P],
-    "gspn_fps_background": [_I],
     "gspn_fps_cells": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
     "gspn_farthestpointsampling_cells": [_I, _I, _I, _P, _P, _P, _P],
     "gspn_fps_cells_prepass": [_I, _I, _P, _P, _P],
     "gspn_fps_cells_sample": [_I, _I, _I, _P, _P, _P, _P],
+    "gspn_fps_multi_prepass": [_I, _I, _I, _P, _P, _P],
+    "gspn_fps_multi_sample": [_I, _I, _I, _I, _P, _P, _P, _P],
+    "gspn_farthestpointsampling_multi": [_I, _I, _I, _I, _P, _P, _P, _P],
+    "gspn_fps_multi_status": [_P, _I, _I, _P],
     "gspn_gatherpoint": [_I, _I, _I, _P, _P, _P, _P],
     "gspn_scatteraddpoint": [_I, _I, _I, _P, _P, _P, _P],
     "gspn_probsample": [_I, _I, _I, _P, _P, _P, _P, _P],
@@ -70,6 +73,16 @@ SIGNATURES = {
     "gspn_fill_zero": [_P, _L, _P],
 }
 
+# entry points that do not return an int status: symbol -> (argtypes, restype)
+SPECIAL = {
+    "gspn_ball_threshold": ([_F], _F),
+    "gspn_mlp_bwd_work_bytes": ([_L, _I, _I], _L),
+    "gspn_mlp_fwd_stats_bytes": ([_L, _I], _L),
+    "gspn_fps_cells_ws_bytes": ([_I, _I], _L),
+    "gspn_fps_multi_ws_bytes": ([_I, _I], _L),
+    "gspn_inverse_lists_work_ints": ([_I, _I, _I], _L),
+}
+
 _lib = None
 
 
@@ -89,16 +102,10 @@ def lib():
             fn = getattr(h, name)          # AttributeError if the ABI and the binding drift apart
             fn.argtypes = args
             fn.restype = _I
-        h.gspn_ball_threshold.argtypes = [_F]
-        h.gspn_ball_threshold.restype = _F
-        h.gspn_mlp_bwd_work_bytes.argtypes = [_L, _I, _I]
-        h.gspn_mlp_bwd_work_bytes.restype = _L
-        h.gspn_mlp_fwd_stats_bytes.argtypes = [_L, _I]
-        h.gspn_mlp_fwd_stats_bytes.restype = _L
-        h.gspn_fps_cells_ws_bytes.argtypes = [_I, _I]
-        h.gspn_fps_cells_ws_bytes.restype = _L
-        h.gspn_inverse_lists_work_ints.argtypes = [_I, _I, _I]
-        h.gspn_inverse_lists_work_ints.restype = _L
+        for name, (args, res) in SPECIAL.items():
+            fn = getattr(h, name)
+            fn.argtypes = args
+            fn.restype = res
         _lib = h
     return _lib
 

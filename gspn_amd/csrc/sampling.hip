@@ -1,7 +1,6 @@
 // sampling.hip -- tf_ops/sampling on gfx950: farthest point sampling, gather_point (+grad),
 // prob_sample.  Reference semantics: tf_ops/sampling/tf_sampling_g.cu (cited per kernel).
-#include "common.h"
-#include <stdlib.h>
+#include "fps_common.h"
 
 // ============================================================================================
 // Farthest point sampling (reference: tf_sampling_g.cu:105-170)
@@ -29,11 +28,6 @@
 //     max3 tree yields for free, wave-uniform switches and v_readlane.
 // ============================================================================================
 
-#define FPS_T 1024
-#define FPS_W (FPS_T / 64)
-typedef float v4f __attribute__((ext_vector_type(4)));
-typedef float v2f __attribute__((ext_vector_type(2)));
-#define NEG_ONE_BITS ((int)0xBF800000)
 #ifdef FPS_PROFILE
 __device__ long long g_fps_prof[8];
 __device__ long long g_fps_tl[16 * 8];
@@ -42,33 +36,9 @@ __device__ long long g_fps_tl[16 * 8];
 #define FPS_TICK(i) do {} while (0)
 #endif
 
-// Background mode.  A CU whose four wave slots per SIMD issue VALU instructions without a break slows every bandwidth-bound kernel
-// running elsewhere on the chip by ~10 % (measured on MI355X with tools/queue_probe2.py: a pure-VALU workgroup of 16 waves on ONE CU
-// costs a concurrent HBM-streaming chain +9 %; one s_sleep 1 per ~64 VALU instructions removes the effect for +4 % on the spinning
-// kernel).  FPS is exactly such a kernel, and in the intended schedule it runs beside the MLP layers on a side stream with time to
-// spare -- so launches made while background mode is on yield once per 8 points.  Process-wide switch, consulted at launch.
-static int g_fps_yield = 0;
-extern "C" int gspn_fps_background(int on) {
-    const int prev = g_fps_yield;
-    g_fps_yield = on ? 1 : 0;
-    return prev;
-}
-
-template <int P>
-struct FpsGroup {
-    static constexpr int G = (P >= 8) ? 8 : P;   // points per resolve group
-    static constexpr int NG = P / G;
-};
-
-__device__ __forceinline__ int vmax3_i32(int a, int b, int c) {
-    int r;
-    asm("v_max3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-
 // P = points per thread (even), ZLDS = z plane in LDS instead of VGPRs
 template <int P, bool ZLDS>
-__global__ __launch_bounds__(FPS_T) void fps_resident_kernel(int n, int m, const float* __restrict__ inp, int* __restrict__ out, int yield) {
+__global__ __launch_bounds__(FPS_T) void fps_resident_kernel(int n, int m, const float* __restrict__ inp, int* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // [0,512)    : candidates, 2 buffers x 16 waves x int4 {max bits, x, y, z}
     // [512,640)  : candidate indices, 2 buffers x 16 waves x int
@@ -148,7 +118,6 @@ __global__ __launch_bounds__(FPS_T) void fps_resident_kernel(int n, int m, const
                 gm = vmax3_i32(gm, __float_as_int(td[pp][0]), __float_as_int(td[pp][1]));
             }
             g[q] = gm;
-            if (yield) __builtin_amdgcn_s_sleep(1);   // background mode: see gspn_fps_background
             __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from interleaving groups (VGPR pressure)
         }
         int best = g[0];
@@ -242,9 +211,6 @@ __global__ __launch_bounds__(FPS_T) void fps_resident_kernel(int n, int m, const
 //     duplicate of one) repeats the rank-minimal point, like the reference.
 // ============================================================================================
 #define FPS_AMAX 6        // max picks accepted per round
-#ifndef FPS_YIELD_SLEEP
-#define FPS_YIELD_SLEEP 1
-#endif
 #ifdef FPS_PROFILE
 __device__ long long g_cell_prof[32];
 __device__ int g_cell_waves[16 * 4];      // per wave of scene 0: {applies, refreshes, -, -}
@@ -261,7 +227,7 @@ __device__ long long g_cell_tl[3 * 16 * 8];   // timestamps of rounds 200, 300, 
 
 template <int P, bool ZLDS>
 __global__ __launch_bounds__(FPS_T) void fps_cell_kernel(int n, int m, int csz, const float* __restrict__ sxyz, const int* __restrict__ perm,
-                                                         const float* __restrict__ inp0, int inp0_stride, int* __restrict__ out, int yield) {
+                                                         const float* __restrict__ inp0, int inp0_stride, int* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // [0,1024)   : candidates, 2 buffers x 16 waves x {int4 {v bits, x, y, z}, int4 {sorted position, bound bits, -, -}}
     // [1024,1040): batch record written by wave 0
@@ -389,7 +355,6 @@ __global__ __launch_bounds__(FPS_T) void fps_cell_kernel(int n, int m, int csz, 
                         td[pp][1] = vmin_f32(d[1], td[pp][1]);
                     }
                     zq = zn;
-                    if (yield) __builtin_amdgcn_s_sleep(FPS_YIELD_SLEEP);      // background mode: see gspn_fps_background
                 }
             } else {
 #pragma unroll
@@ -614,62 +579,6 @@ __global__ __launch_bounds__(FPS_T) void fps_cell_kernel(int n, int m, int csz, 
 #endif
 }
 
-// Fallback for scenes that do not fit one CU (n > 32768): one 1024-thread workgroup per scene
-// slot, min-dist in the caller's scratch (L2 resident), 64-bit (dist, tie-rank) keys.
-// Thread t visits k = t, t+1024, ... so k mod 512 == t mod 512 for all of its points.
-__global__ __launch_bounds__(1024) void fps_streaming_kernel(int b, int n, int m, const float* __restrict__ inp,
-                                                             float* __restrict__ temp, int* __restrict__ out) {
-    __shared__ unsigned long long s_key[16];
-    __shared__ int s_old;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    for (int i = blockIdx.x; i < b; i += gridDim.x) {
-        const float* xyz = inp + (size_t)i * n * 3;
-        float* td = temp + (size_t)blockIdx.x * n;
-        int* o = out + (size_t)i * m;
-        for (int k = t; k < n; k += 1024) td[k] = 1e38f;
-        if (t == 0) o[0] = 0;
-        int old = 0;
-        __syncthreads();
-        for (int j = 1; j < m; ++j) {
-            const float cx = xyz[old * 3 + 0], cy = xyz[old * 3 + 1], cz = xyz[old * 3 + 2];
-            unsigned long long key = 0;   // (dist bits << 32) | ~rank ; larger is better
-            for (int k = t; k < n; k += 1024) {
-                const float d = dist2_cuda(xyz[k * 3 + 0] - cx, xyz[k * 3 + 1] - cy, xyz[k * 3 + 2] - cz);
-                const float o0 = td[k];
-                const float nt = __builtin_fminf(d, o0);
-                if (nt != o0) td[k] = nt;
-                const unsigned rank = ((unsigned)(k & 511) << 22) | (unsigned)(k >> 9);
-                const unsigned long long kk = ((unsigned long long)(unsigned)__float_as_int(nt) << 32) | (unsigned)(~rank);
-                key = kk > key ? kk : key;
-            }
-#pragma unroll
-            for (int s = 32; s >= 1; s >>= 1) {
-                const unsigned long long other = __shfl_xor(key, s, 64);
-                key = other > key ? other : key;
-            }
-            if (lane == 0) s_key[wave] = key;
-            __syncthreads();
-            if (wave == 0) {
-                unsigned long long v = s_key[lane & 15];
-#pragma unroll
-                for (int s = 8; s >= 1; s >>= 1) {
-                    const unsigned long long other = __shfl_xor(v, s, 64);
-                    v = other > v ? other : v;
-                }
-                if (lane == 0) {
-                    const unsigned rank = ~(unsigned)(v & 0xFFFFFFFFull);
-                    const int k = (int)(((rank & 0x3FFFFFu) << 9) | (rank >> 22));
-                    s_old = k;
-                    o[j] = k;
-                }
-            }
-            __syncthreads();
-            old = s_old;
-        }
-        __syncthreads();
-    }
-}
-
 template <int P, bool ZLDS>
 static int launch_fps_resident(int b, int n, int m, const float* inp, int* out, hipStream_t st) {
     const size_t lds = 1024 + (ZLDS ? (size_t)P * FPS_T * sizeof(float) : 0);
@@ -678,7 +587,7 @@ static int launch_fps_resident(int b, int n, int m, const float* inp, int* out, 
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL((fps_resident_kernel<P, ZLDS>), dim3(b), dim3(FPS_T), lds, st, n, m, inp, out, g_fps_yield);
+    hipLaunchKernelGGL((fps_resident_kernel<P, ZLDS>), dim3(b), dim3(FPS_T), lds, st, n, m, inp, out);
     return gspn_launch_status();
 }
 
@@ -751,19 +660,19 @@ __global__ __launch_bounds__(1024) void fps_bin_kernel(int n, const float* __res
     // ---- scatter the reference tie ranks into voxel order ----
     for (int k = t; k < n; k += 1024) {
         const int pos = atomicAdd(&hist[voxel(k)], 1);
-        out[pos] = ((unsigned)(k & 511) << 22) | (unsigned)(k >> 9);
+        out[pos] = fps_tie_rank(k);
     }
 }
 
 template <int SZ>      // SZ = power of two >= csz, <= 2048; block = SZ/2 threads
-__global__ void fps_cellsort_kernel(int n, int csz, const float* __restrict__ inp, const unsigned* __restrict__ keys,
-                                    float* __restrict__ sxyz, int* __restrict__ perm) {
+__global__ void fps_cellsort_kernel(int n, int csz, const float* __restrict__ inp, int* perm, float* __restrict__ sxyz) {
     __shared__ unsigned sk[SZ];
     const int cell = blockIdx.x, scene = blockIdx.y;
     const int t = threadIdx.x;
     const int begin = cell * csz;
     const int cnt = min(csz, n - begin) > 0 ? min(csz, n - begin) : 0;
-    const unsigned* src = keys + (size_t)scene * n + begin;
+    // the rank keys of this cell sit in the cell's own slice of perm (fps_bin_kernel): read all of them, then overwrite the slice
+    const unsigned* src = reinterpret_cast<const unsigned*>(perm) + (size_t)scene * n + begin;
     for (int i = t; i < SZ; i += SZ / 2) sk[i] = i < cnt ? src[i] : 0xFFFFFFFFu;
     __syncthreads();
     for (int k = 2; k <= SZ; k <<= 1) {
@@ -778,14 +687,25 @@ __global__ void fps_cellsort_kernel(int n, int csz, const float* __restrict__ in
     }
     const float* xyz = inp + (size_t)scene * n * 3;
     for (int i = t; i < cnt; i += SZ / 2) {
-        const unsigned r = sk[i];
-        const int k = (int)(((r & 0x3FFFFFu) << 9) | (r >> 22));
+        const int k = fps_tie_rank_inv(sk[i]);
         const size_t pos = (size_t)scene * n + begin + i;
         perm[pos] = k;
         sxyz[pos * 3 + 0] = xyz[k * 3 + 0];
         sxyz[pos * 3 + 1] = xyz[k * 3 + 1];
         sxyz[pos * 3 + 2] = xyz[k * 3 + 2];
     }
+}
+
+int gspn_fps_prepass_cells(int b, int n, int ncell, int csz, const float* inp, int* perm, float* sxyz, hipStream_t st) {
+    if (csz > 2048 || (long long)ncell * csz < n || b > 65535) return GSPN_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(fps_bin_kernel, dim3(b), dim3(1024), 0, st, n, inp, reinterpret_cast<unsigned*>(perm));
+    const dim3 g2(ncell, b);
+    if (csz <= 128) hipLaunchKernelGGL(fps_cellsort_kernel<128>, g2, dim3(64), 0, st, n, csz, inp, perm, sxyz);
+    else if (csz <= 256) hipLaunchKernelGGL(fps_cellsort_kernel<256>, g2, dim3(128), 0, st, n, csz, inp, perm, sxyz);
+    else if (csz <= 512) hipLaunchKernelGGL(fps_cellsort_kernel<512>, g2, dim3(256), 0, st, n, csz, inp, perm, sxyz);
+    else if (csz <= 1024) hipLaunchKernelGGL(fps_cellsort_kernel<1024>, g2, dim3(512), 0, st, n, csz, inp, perm, sxyz);
+    else hipLaunchKernelGGL(fps_cellsort_kernel<2048>, g2, dim3(1024), 0, st, n, csz, inp, perm, sxyz);
+    return gspn_launch_status();
 }
 
 template <int P, bool ZLDS>
@@ -796,7 +716,7 @@ static int launch_fps_cell(int b, int n, int m, int csz, const float* sxyz, cons
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL((fps_cell_kernel<P, ZLDS>), dim3(b), dim3(FPS_T), lds, st, n, m, csz, sxyz, perm, inp0, stride0, out, g_fps_yield);
+    hipLaunchKernelGGL((fps_cell_kernel<P, ZLDS>), dim3(b), dim3(FPS_T), lds, st, n, m, csz, sxyz, perm, inp0, stride0, out);
     return gspn_launch_status();
 }
 // FPS on a spatially pre-sorted scene (see fps_cell_kernel): sxyz (b,n,3) = inp gathered by perm (b,n) [sorted position -> original
@@ -818,10 +738,11 @@ extern "C" int gspn_fps_cells(int b, int n, int m, int csz, const float* sxyz, c
     return gspn_fps_cells_strided(b, n, m, csz, sxyz, perm, inp0, 3, out, stream);
 }
 
-// workspace of gspn_farthestpointsampling_cells: [keys: b*n u32][perm: b*n i32][sxyz: b*n*3 f32]
+// workspace of gspn_farthestpointsampling_cells: [perm: b*n i32][sxyz: b*n*3 f32] = 16 bytes per point.  The reference's own FPS
+// scratch, temp (32,n) f32 (tf_sampling.cpp:111-115), is 128*n bytes: large enough for b <= 8 scenes.
 extern "C" long gspn_fps_cells_ws_bytes(int b, int n) {
     if (b < 0 || n <= 0) return GSPN_ERR_ARG;
-    return (long)b * n * (4 + 4 + 12);
+    return (long)b * n * 16;
 }
 // The two halves of gspn_farthestpointsampling_cells, separately callable (so that a caller can time the sampling kernel alone):
 // the spatial pre-pass that fills `ws` ...
@@ -830,19 +751,9 @@ extern "C" int gspn_fps_cells_prepass(int b, int n, const float* inp, void* ws, 
     if (b == 0) return 0;
     if (!inp || !ws) return GSPN_ERR_ARG;
     if (n > GSPN_FPS_RESIDENT_MAX || b > 65535) return GSPN_ERR_UNSUPPORTED;
-    hipStream_t st = (hipStream_t)stream;
-    unsigned* keys = reinterpret_cast<unsigned*>(ws);
-    int* perm = reinterpret_cast<int*>(keys + (size_t)b * n);
+    int* perm = reinterpret_cast<int*>(ws);
     float* sxyz = reinterpret_cast<float*>(perm + (size_t)b * n);
-    const int csz = (n + 15) / 16;
-    hipLaunchKernelGGL(fps_bin_kernel, dim3(b), dim3(1024), 0, st, n, inp, keys);
-    const dim3 g2(16, b);
-    if (csz <= 128) hipLaunchKernelGGL(fps_cellsort_kernel<128>, g2, dim3(64), 0, st, n, csz, inp, keys, sxyz, perm);
-    else if (csz <= 256) hipLaunchKernelGGL(fps_cellsort_kernel<256>, g2, dim3(128), 0, st, n, csz, inp, keys, sxyz, perm);
-    else if (csz <= 512) hipLaunchKernelGGL(fps_cellsort_kernel<512>, g2, dim3(256), 0, st, n, csz, inp, keys, sxyz, perm);
-    else if (csz <= 1024) hipLaunchKernelGGL(fps_cellsort_kernel<1024>, g2, dim3(512), 0, st, n, csz, inp, keys, sxyz, perm);
-    else hipLaunchKernelGGL(fps_cellsort_kernel<2048>, g2, dim3(1024), 0, st, n, csz, inp, keys, sxyz, perm);
-    return gspn_launch_status();
+    return gspn_fps_prepass_cells(b, n, 16, (n + 15) / 16, inp, perm, sxyz, (hipStream_t)stream);
 }
 // ... and the sampling kernel on a workspace the pre-pass has filled for the same (b, n, inp)
 extern "C" int gspn_fps_cells_sample(int b, int n, int m, const float* inp, const void* ws, int* out, void* stream) {
@@ -850,8 +761,7 @@ extern "C" int gspn_fps_cells_sample(int b, int n, int m, const float* inp, cons
     if (b == 0) return 0;
     if (!inp || !ws || !out) return GSPN_ERR_ARG;
     if (n > GSPN_FPS_RESIDENT_MAX || b > 65535) return GSPN_ERR_UNSUPPORTED;
-    const unsigned* keys = reinterpret_cast<const unsigned*>(ws);
-    const int* perm = reinterpret_cast<const int*>(keys + (size_t)b * n);
+    const int* perm = reinterpret_cast<const int*>(ws);
     const float* sxyz = reinterpret_cast<const float*>(perm + (size_t)b * n);
     // original point 0 of scene i is inp[i*n*3 ..]: a strided view, the kernel only needs a pointer + stride -> pass inp with stride n*3
     return gspn_fps_cells_strided(b, n, m, (n + 15) / 16, sxyz, perm, inp, n * 3, out, stream);
@@ -933,26 +843,41 @@ static int launch_fps_small(int b, int n, int m, const float* inp, int* out, hip
     return gspn_launch_status();
 }
 
+// The drop-in symbol.  `temp` is the reference's own FPS scratch, (32,n) f32 = 128*n bytes (tf_sampling.cpp:111-115): it is used as
+// the workspace of the cell kernels (8192 <= n <= 32768: 8 scenes per pass; n > 32768: as many scenes per pass as fit), so a caller
+// that binds this symbol the way the reference binds farthestpointsamplingLauncher gets the fast paths.  temp == NULL is accepted
+// for n <= 32768 (plain on-chip kernel, no scratch).
 extern "C" int gspn_farthestpointsampling(int b, int n, int m, const float* inp, float* temp, int* out, void* stream) {
     if (b < 0 || n <= 0 || m <= 0) return GSPN_ERR_ARG;          // tf_sampling.cpp:99,105
     if (b == 0) return 0;
     if (!inp || !out) return GSPN_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    if (n <= 2048 && !(getenv("GSPN_FPS_NO_SMALL") && getenv("GSPN_FPS_NO_SMALL")[0])) {
-        if (n <= 512) return launch_fps_small<1>(b, n, m, inp, out, st);
-        if (n <= 1024) return launch_fps_small<2>(b, n, m, inp, out, st);
-        if (n <= 1536) return launch_fps_small<3>(b, n, m, inp, out, st);
-        return launch_fps_small<4>(b, n, m, inp, out, st);
+    if (n <= 512) return launch_fps_small<1>(b, n, m, inp, out, st);
+    if (n <= 1024) return launch_fps_small<2>(b, n, m, inp, out, st);
+    if (n <= 1536) return launch_fps_small<3>(b, n, m, inp, out, st);
+    if (n <= 2048) return launch_fps_small<4>(b, n, m, inp, out, st);
+    if (n >= 8192 && n <= GSPN_FPS_RESIDENT_MAX && temp) {
+        for (int s0 = 0; s0 < b; s0 += 8) {                     // 16 bytes per point: 8 scenes fit the 128*n bytes of temp
+            const int bs = b - s0 < 8 ? b - s0 : 8;
+            const int rc = gspn_farthestpointsampling_cells(bs, n, m, inp + (size_t)s0 * n * 3, temp, out + (size_t)s0 * m, stream);
+            if (rc) return rc;
+        }
+        return 0;
     }
-    if (n <= 2048) return launch_fps_resident<2, false>(b, n, m, inp, out, st);
     if (n <= 4096) return launch_fps_resident<4, false>(b, n, m, inp, out, st);
     if (n <= 8192) return launch_fps_resident<8, false>(b, n, m, inp, out, st);
     if (n <= 16384) return launch_fps_resident<16, false>(b, n, m, inp, out, st);
     if (n <= GSPN_FPS_RESIDENT_MAX) return launch_fps_resident<32, true>(b, n, m, inp, out, st);
     if (!temp) return GSPN_ERR_ARG;
-    if ((long long)n >= (1ll << 31) / 3) return GSPN_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(fps_streaming_kernel, dim3(b < 32 ? b : 32), dim3(1024), 0, st, b, n, m, inp, temp, out);
-    return gspn_launch_status();
+    int per = 8;
+    while (per > 1 && gspn_fps_multi_ws_bytes(per, n) > 128l * n) --per;
+    if (gspn_fps_multi_ws_bytes(per, n) > 128l * n) return GSPN_ERR_UNSUPPORTED;
+    for (int s0 = 0; s0 < b; s0 += per) {
+        const int bs = b - s0 < per ? b - s0 : per;
+        const int rc = gspn_farthestpointsampling_multi(bs, n, m, 0, inp + (size_t)s0 * n * 3, temp, out + (size_t)s0 * m, stream);
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 // ============================================================================================

@@ -119,11 +119,6 @@ def _tensors_of(v):
     return []
 
 
-# FPS background (yield) mode for launches made from a GeometryStream: off by default -- with the current sampling kernel it no longer
-# changes what the layers lose (3.07 ms per step either way) and costs FPS 6 %; GSPN_FPS_BACKGROUND=1 turns it on
-_BACKGROUND = 1 if os.environ.get('GSPN_FPS_BACKGROUND') == '1' else 0
-
-
 class GeometryStream:
     """A side HIP stream for coordinate-only work.  submit(fn, *tensors) runs fn on it after the tensors'
     producer (the caller's current stream) and returns a PendingGeometry."""
@@ -143,12 +138,7 @@ class GeometryStream:
             for a in args:
                 if isinstance(a, torch.Tensor):
                     a.record_stream(self.stream)
-            # FPS launched from here runs beside the layers: optionally in background mode (it yields, see gspn_fps_background)
-            prev = L.lib().gspn_fps_background(_BACKGROUND)
-            try:
-                with torch.no_grad():
-                    value = fn(*args, **kwargs)
-            finally:
-                L.lib().gspn_fps_background(prev)
+            with torch.no_grad():
+                value = fn(*args, **kwargs)
             done = self.stream.record_event()
         return PendingGeometry(value, done, self.stream)

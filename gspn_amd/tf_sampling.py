@@ -15,6 +15,9 @@ PROFILE = None
 # 'resident': always the plain on-chip kernel; 'cells_torch': cell kernel on a torch-side pre-sort (tests: arbitrary partitions)
 FPS_MODE = os.environ.get("GSPN_FPS_MODE", "cells")
 FPS_CELLS_MIN_N = int(os.environ.get("GSPN_FPS_CELLS_MIN_N", "8192"))
+# workgroups (CUs) per scene for n > 32768 (0 = the library's choice); any n goes multi-CU when FPS_MULTI_FORCE is set (tests)
+FPS_MULTI_G = int(os.environ.get("GSPN_FPS_MULTI_G", "0"))
+FPS_MULTI_FORCE = False
 
 
 def _spread10(v):
@@ -54,30 +57,38 @@ def farthest_point_sample(npoint, inp):
         raise ValueError("FarthestPointSample expects (batch_size,num_points,3) inp shape")   # tf_sampling.cpp:105
     b, n, _ = inp.shape
     out = torch.empty((b, npoint), dtype=torch.int32, device=inp.device)
-    temp = None
-    if n > 32768:   # GSPN_FPS_RESIDENT_MAX: only the streaming kernel needs the (32,n) scratch of tf_sampling.cpp:115
-        temp = torch.empty((min(b, 32), n), dtype=torch.float32, device=inp.device)
+    lib = L.lib()
     with torch.cuda.device(inp.device):
         ev = None
-        if FPS_MODE == "cells" and FPS_CELLS_MIN_N <= n <= 32768:
-            ws = torch.empty(int(L.lib().gspn_fps_cells_ws_bytes(b, n)) // 4, dtype=torch.float32, device=inp.device)
-            L.check(L.lib().gspn_fps_cells_prepass(b, n, L.ptr(inp), L.ptr(ws), L.stream()), "farthest_point_sample(cells pre-pass)")
+
+        def tic():
+            nonlocal ev
             if PROFILE is not None:           # events around the sampling kernel alone (the pre-pass is 3 % of the call)
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 ev[0].record()
-            L.check(L.lib().gspn_fps_cells_sample(b, n, npoint, L.ptr(inp), L.ptr(ws), L.ptr(out), L.stream()), "farthest_point_sample(cells)")
+
+        if n > 32768 or FPS_MULTI_FORCE:
+            # several CUs per scene (sampling_multi.hip); the reference's kernel takes any n (tf_sampling_g.cu:137-141)
+            ws = torch.empty((int(lib.gspn_fps_multi_ws_bytes(b, n)) + 3) // 4, dtype=torch.float32, device=inp.device)
+            L.check(lib.gspn_fps_multi_prepass(b, n, FPS_MULTI_G, L.ptr(inp), L.ptr(ws), L.stream()), "farthest_point_sample(multi pre-pass)")
+            tic()
+            L.check(lib.gspn_fps_multi_sample(b, n, npoint, FPS_MULTI_G, L.ptr(inp), L.ptr(ws), L.ptr(out), L.stream()),
+                    "farthest_point_sample(multi)")
+        elif FPS_MODE == "cells" and FPS_CELLS_MIN_N <= n:
+            ws = torch.empty(int(lib.gspn_fps_cells_ws_bytes(b, n)) // 4, dtype=torch.float32, device=inp.device)
+            L.check(lib.gspn_fps_cells_prepass(b, n, L.ptr(inp), L.ptr(ws), L.stream()), "farthest_point_sample(cells pre-pass)")
+            tic()
+            L.check(lib.gspn_fps_cells_sample(b, n, npoint, L.ptr(inp), L.ptr(ws), L.ptr(out), L.stream()), "farthest_point_sample(cells)")
+        elif FPS_MODE == "cells_torch" and 64 <= n:
+            tic()
+            sxyz, perm, csz = _cell_prepass(inp)
+            inp0 = inp[:, 0, :].contiguous()
+            L.check(lib.gspn_fps_cells(b, n, npoint, csz, L.ptr(sxyz), L.ptr(perm), L.ptr(inp0), L.ptr(out), L.stream()),
+                    "farthest_point_sample(cells)")
         else:
-            if PROFILE is not None:
-                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                ev[0].record()
-            if FPS_MODE == "cells_torch" and 64 <= n <= 32768:
-                sxyz, perm, csz = _cell_prepass(inp)
-                inp0 = inp[:, 0, :].contiguous()
-                L.check(L.lib().gspn_fps_cells(b, n, npoint, csz, L.ptr(sxyz), L.ptr(perm), L.ptr(inp0), L.ptr(out), L.stream()),
-                        "farthest_point_sample(cells)")
-            else:
-                L.check(L.lib().gspn_farthestpointsampling(b, n, npoint, L.ptr(inp), L.ptr(temp), L.ptr(out), L.stream()),
-                        "farthest_point_sample")
+            tic()
+            L.check(lib.gspn_farthestpointsampling(b, n, npoint, L.ptr(inp), L.ptr(None), L.ptr(out), L.stream()),
+                    "farthest_point_sample")
         if ev is not None:
             ev[1].record()
             PROFILE.append((ev[0], ev[1], b, n, npoint))

@@ -16,7 +16,7 @@
  * entry points zero their output themselves (stream-ordered), replacing the reference's
  * cudaMemset calls (tf_sampling.cpp:174, tf_grouping.cpp:234,307, tf_nndistance_g.cu:153-154).
  * All pointers are device pointers; tensors are dense row-major float32 / int32.
- * Thread safety: the library holds no mutable global state.
+ * Thread safety: the library holds no mutable global state (tuning knobs are read from the environment once, on first use).
  */
 #ifndef GSPN_HIP_H
 #define GSPN_HIP_H
@@ -35,14 +35,11 @@ int gspn_abi_version(void);
 /* ---------------- tf_ops/sampling ---------------------------------------------------- */
 
 /* farthestpointsamplingLauncher(b,n,m,inp,temp,out)  tf_sampling.cpp:94, tf_sampling_g.cu:203-205.
- * inp (b,n,3) f32 -> out (b,m) i32.  temp: scratch of min(b,32)*n floats, used only when
- * n > GSPN_FPS_RESIDENT_MAX (the on-chip kernel needs none; may be NULL below that). */
+ * inp (b,n,3) f32 -> out (b,m) i32.  temp: the reference's scratch, (32,n) f32 = 128*n bytes (tf_sampling.cpp:111-115).  It is
+ * the workspace of the cell kernels below (n >= 8192); required for n > GSPN_FPS_RESIDENT_MAX, may be NULL below that (the plain
+ * on-chip kernel then runs: same output, about half the speed at n = 32768). */
 #define GSPN_FPS_RESIDENT_MAX 32768
 int gspn_farthestpointsampling(int b, int n, int m, const float* inp, float* temp, int* out, void* stream);
-/* Background mode for the FPS kernels (process-wide, read at launch; returns the previous setting).  When on, the sampling loop
- * yields (s_sleep 1) once per 8 points: ~4 % slower, but it no longer slows bandwidth-bound kernels running next to it on other
- * streams (a CU issuing VALU work without a break costs them ~10 % chip-wide on MI355X).  Results are unaffected. */
-int gspn_fps_background(int on);
 
 /* Same result as gspn_farthestpointsampling, several times fewer serial rounds: FPS on a scene that the caller has sorted into
  * 16 spatial cells (csz = ceil(n/16) points each, Morton order; inside a cell by the reference tie rank (k mod 512, k)):
@@ -58,6 +55,19 @@ int gspn_farthestpointsampling_cells(int b, int n, int m, const float* inp, void
  * sort inside each cell) and the sampling kernel proper.  Calling them one after the other on one stream equals the combined call. */
 int gspn_fps_cells_prepass(int b, int n, const float* inp, void* ws, void* stream);
 int gspn_fps_cells_sample(int b, int n, int m, const float* inp, const void* ws, int* out, void* stream);
+
+/* Scenes that do not fit one CU (n > 32768; tf_sampling_g.cu:137-141 is the reference's any-n path, data_prep.py:64-83 its caller
+ * at n ~ 1e5, m = 30000): the same cell scheme on G workgroups (CUs) per scene, 16*G cells, candidates exchanged between the CUs
+ * once per round (gspn_amd/csrc/sampling_multi.hip).  Output identical to gspn_farthestpointsampling.  G = 0 picks the fewest
+ * workgroups that hold the scene (ceil(n/32768)); a larger G (<= 32) means smaller cells and shorter rounds.  Works for any
+ * n >= 1 (also below 32768, e.g. one large scene spread over several CUs).  ws: gspn_fps_multi_ws_bytes(b,n) bytes.
+ * prepass + sample = the combined call, as for the single-CU cell kernel.  gspn_fps_multi_status synchronises the stream and returns
+ * 0, or 1 if a bounded inter-workgroup wait expired (the workgroups of a scene were not co-resident; output invalid). */
+long gspn_fps_multi_ws_bytes(int b, int n);
+int gspn_fps_multi_prepass(int b, int n, int G, const float* inp, void* ws, void* stream);
+int gspn_fps_multi_sample(int b, int n, int m, int G, const float* inp, void* ws, int* out, void* stream);
+int gspn_farthestpointsampling_multi(int b, int n, int m, int G, const float* inp, void* ws, int* out, void* stream);
+int gspn_fps_multi_status(const void* ws, int b, int n, void* stream);
 
 /* gatherpointLauncher(b,n,m,inp,idx,out)  tf_sampling.cpp:125, tf_sampling_g.cu:206-208 */
 int gspn_gatherpoint(int b, int n, int m, const float* inp, const int* idx, float* out, void* stream);
