@@ -42,6 +42,7 @@ SIGNATURES = {
     "gspn_probsample": [_I, _I, _I, _P, _P, _P, _P, _P],
     "gspn_queryballpoint": [_I, _I, _I, _F, _I, _P, _P, _P, _P, _P],
     "gspn_selectionsort": [_I, _I, _I, _I, _P, _P, _P, _P],
+    "gspn_knn_point": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
     "gspn_grouppoint": [_I, _I, _I, _I, _I, _P, _P, _P, _P],
     "gspn_grouppoint_grad": [_I, _I, _I, _I, _I, _P, _P, _P, _P],
     "gspn_groupmaxpool": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P],

@@ -355,6 +355,7 @@ __global__ __launch_bounds__(FPS_T) void fps_cell_kernel(int n, int m, int csz, 
                         td[pp][1] = vmin_f32(d[1], td[pp][1]);
                     }
                     zq = zn;
+                    __builtin_amdgcn_sched_barrier(0);     // keeps the z double-buffer from being hoisted across quads (VGPR budget: no spill)
                 }
             } else {
 #pragma unroll
@@ -925,95 +926,140 @@ extern "C" int gspn_scatteraddpoint(int b, int n, int m, const float* out_g, con
 }
 
 // ============================================================================================
-// prob_sample (tf_sampling_g.cu:7-104): per-row inclusive prefix sum + inverse-CDF lookup.
-// Not reached from the model; kept for API completeness.  One workgroup per row; the tile
-// arithmetic follows the reference's 8192-element tiles (groups of 4, tree over group totals,
-// compensated carry between tiles) so the cumulative sums round identically.
+// prob_sample (tf_sampling_g.cu:7-104): per-row inclusive prefix sum + inverse-CDF lookup.  Not reached from the model.
+//
+// What has to match the reference is the ROUNDING of the prefix sums, i.e. the association order of its scan:
+//   * a row is cut into tiles of 8192 values, a tile into groups of 4: (v1, v1+v2, (v1+v2)+v3, (v3+v4)+(v1+v2)); a ragged last group
+//     is summed left to right (:19-42);
+//   * over the group totals the reference runs a Brent-Kung scan (:43-65), which amounts to: the sum of an aligned block of 2^u groups
+//     is the sum of its two halves, and the prefix over c groups adds those block sums in the order of the set bits of c, from the
+//     most significant down;
+//   * element = group-local prefix + prefix of the groups before it, + carry of the earlier tiles; the carry is compensated
+//     (Kahan-style pair) across tiles (:72-78).
+// This kernel builds exactly those quantities in a wave64-native way: a wave owns 64 consecutive groups, forms the block sums of
+// 2..64 groups with xor-shuffles (a + b == b + a bit for bit, so both partners hold the same value), one wave finishes the five levels
+// above, every level is kept in LDS (4095 floats), and each lane then folds the <= 12 block sums its group count selects.  Group-local
+// prefixes stay in registers; there is no element buffer in LDS.
 // ============================================================================================
-#define CS_BLOCK 2048
-#define CS_PAD 5
-__global__ __launch_bounds__(512) void cumsum_kernel(int b, int n, const float* __restrict__ inp, float* __restrict__ out) {
-    __shared__ float buffer4[CS_BLOCK * 4];
-    __shared__ float buffer[CS_BLOCK + (CS_BLOCK >> CS_PAD)];
-    for (int i = blockIdx.x; i < b; i += gridDim.x) {
-        float runningsum = 0, runningsum2 = 0;
-        for (int j = 0; j < n; j += CS_BLOCK * 4) {
-            const int n24_i = min(n - j, CS_BLOCK * 4);
-            const int n24 = (n24_i + 3) & ~3;
-            const int n2 = n24 >> 2;
-            for (int k = threadIdx.x * 4; k < n24_i; k += blockDim.x * 4) {
-                if (k + 3 < n24_i) {
-                    float v1 = inp[(size_t)i * n + j + k];
-                    float v2 = inp[(size_t)i * n + j + k + 1];
-                    v2 += v1;
-                    float v3 = inp[(size_t)i * n + j + k + 2];
-                    float v4 = inp[(size_t)i * n + j + k + 3];
-                    v4 += v3;
-                    v3 += v2;
-                    v4 += v2;
-                    buffer4[k] = v1; buffer4[k + 1] = v2; buffer4[k + 2] = v3; buffer4[k + 3] = v4;
-                    buffer[(k >> 2) + (k >> (2 + CS_PAD))] = v4;
+#define PS_THREADS 512
+#define PS_GROUPS 2048                   // groups of 4 per tile
+#define PS_LEVELS 12                     // block sizes 1 .. 2048 groups
+__device__ __forceinline__ int ps_level_off(int u) { return 2 * PS_GROUPS - ((2 * PS_GROUPS) >> u); }      // 0, 2048, 3072, ...
+
+// prefix over the first c groups (1 <= c <= PS_GROUPS) from the per-level block sums
+__device__ __forceinline__ float ps_fold(const float* lv, int c) {
+    float acc = 0.f;
+    bool first = true;
+#pragma unroll
+    for (int u = PS_LEVELS - 1; u >= 0; --u) {
+        if ((c >> u) & 1) {
+            const float blk = lv[ps_level_off(u) + (c >> u) - 1];
+            acc = first ? blk : acc + blk;
+            first = false;
+        }
+    }
+    return acc;
+}
+
+__global__ __launch_bounds__(PS_THREADS) void prefix_rows_kernel(int b, int n, const float* __restrict__ inp, float* __restrict__ out) {
+    __shared__ float lv[2 * PS_GROUPS];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    constexpr int CH = PS_GROUPS / 64 / (PS_THREADS / 64);        // 64-group chunks per wave and tile (4)
+    for (int row = blockIdx.x; row < b; row += gridDim.x) {
+        const float* src = inp + (size_t)row * n;
+        float* dst = out + (size_t)row * n;
+        float carry = 0.f, comp = 0.f;
+        for (int base = 0; base < n; base += 4 * PS_GROUPS) {
+            const int cnt = min(n - base, 4 * PS_GROUPS);          // values in this tile
+            const int ng = (cnt + 3) >> 2;                         // groups in this tile
+            float g[CH][4];
+#pragma unroll
+            for (int q = 0; q < CH; ++q) {
+                const int grp = (wave + q * (PS_THREADS / 64)) * 64 + lane;
+                const int e0 = grp * 4;
+                float tot = 0.f;
+                if (e0 + 3 < cnt) {
+                    const float a0 = src[base + e0], a1 = src[base + e0 + 1], a2 = src[base + e0 + 2], a3 = src[base + e0 + 3];
+                    const float s01 = a1 + a0;
+                    g[q][0] = a0;
+                    g[q][1] = s01;
+                    g[q][2] = a2 + s01;
+                    g[q][3] = (a3 + a2) + s01;
+                    tot = g[q][3];
                 } else {
-                    float v = 0;
-                    for (int k2 = k; k2 < n24_i; k2++) { v += inp[(size_t)i * n + j + k2]; buffer4[k2] = v; }
-                    for (int k2 = n24_i; k2 < n24; k2++) buffer4[k2] = v;
-                    buffer[(k >> 2) + (k >> (2 + CS_PAD))] = v;
+                    float v = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (e0 + e < cnt) v += src[base + e0 + e];
+                        g[q][e] = v;
+                    }
+                    tot = v;
                 }
-            }
-            int u = 0;
-            for (; (2 << u) <= n2; u++) {
-                __syncthreads();
-                for (int k = threadIdx.x; k < (n2 >> (u + 1)); k += blockDim.x) {
-                    int i1 = (((k << 1) + 2) << u) - 1, i2 = (((k << 1) + 1) << u) - 1;
-                    i1 += i1 >> CS_PAD; i2 += i2 >> CS_PAD;
-                    buffer[i1] += buffer[i2];
-                }
-            }
-            u--;
-            for (; u >= 0; u--) {
-                __syncthreads();
-                for (int k = threadIdx.x; k < ((n2 - (1 << u)) >> (u + 1)); k += blockDim.x) {
-                    int i1 = (((k << 1) + 3) << u) - 1, i2 = (((k << 1) + 2) << u) - 1;
-                    i1 += i1 >> CS_PAD; i2 += i2 >> CS_PAD;
-                    buffer[i1] += buffer[i2];
+                // block sums of 1, 2, 4, ... 64 groups inside the wave
+                lv[grp] = tot;
+#pragma unroll
+                for (int u = 1; u <= 6; ++u) {
+                    tot = tot + __shfl_xor(tot, 1 << (u - 1), 64);
+                    if ((lane & ((1 << u) - 1)) == 0) lv[ps_level_off(u) + (grp >> u)] = tot;
                 }
             }
             __syncthreads();
-            for (int k = threadIdx.x * 4; k < n24; k += blockDim.x * 4) {
-                if (k != 0) {
-                    const int k2 = ((k >> 2) - 1) + (((k >> 2) - 1) >> CS_PAD);
-                    buffer4[k] += buffer[k2]; buffer4[k + 1] += buffer[k2]; buffer4[k + 2] += buffer[k2]; buffer4[k + 3] += buffer[k2];
+            if (wave == 0) {                                       // levels 7..11 over the 32 chunk sums
+                float tot = lane < PS_GROUPS / 64 ? lv[ps_level_off(6) + lane] : 0.f;
+#pragma unroll
+                for (int u = 7; u < PS_LEVELS; ++u) {
+                    tot = tot + __shfl_xor(tot, 1 << (u - 7), 64);
+                    if (lane < PS_GROUPS / 64 && (lane & ((1 << (u - 6)) - 1)) == 0) lv[ps_level_off(u) + (lane >> (u - 6))] = tot;
                 }
             }
             __syncthreads();
-            for (int k = threadIdx.x; k < n24_i; k += blockDim.x) out[(size_t)i * n + j + k] = buffer4[k] + runningsum;
-            const float tt = buffer[(n2 - 1) + ((n2 - 1) >> CS_PAD)] + runningsum2;
-            const float r2 = runningsum + tt;
-            runningsum2 = tt - (r2 - runningsum);
-            runningsum = r2;
+#pragma unroll
+            for (int q = 0; q < CH; ++q) {
+                const int grp = (wave + q * (PS_THREADS / 64)) * 64 + lane;
+                if (grp < ng) {
+                    const float before = grp > 0 ? ps_fold(lv, grp) : 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (grp * 4 + e < cnt) {
+                            const float v = grp > 0 ? g[q][e] + before : g[q][e];
+                            dst[base + grp * 4 + e] = v + carry;
+                        }
+                    }
+                }
+            }
+            // compensated carry into the next tile (tf_sampling_g.cu:72-78)
+            const float tt = ps_fold(lv, ng) + comp;
+            const float nc = carry + tt;
+            comp = tt - (nc - carry);
+            carry = nc;
             __syncthreads();
         }
     }
 }
-__global__ void binarysearch_kernel(int b, int n, int m, const float* __restrict__ dataset, const float* __restrict__ query, int* __restrict__ result) {
-    int base = 1;
-    while (base < n) base <<= 1;
-    const int i = blockIdx.y;
+
+// Inverse-CDF lookup (tf_sampling_g.cu:82-99): descending power-of-two steps from the last index.  The probe sequence is part of the
+// result (the rounded prefix sums need not be monotone), so it is kept: step = 2^ceil(log2 n), ..., 1; move down while cdf >= q.
+__global__ void inverse_cdf_kernel(int n, int m, int top, const float* __restrict__ cdf, const float* __restrict__ u, int* __restrict__ pick) {
+    const int row = blockIdx.y;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m) return;
-    const float* ds = dataset + (size_t)i * n;
-    const float q = query[(size_t)i * m + j] * ds[n - 1];
-    int r = n - 1;
-    for (int k = base; k >= 1; k >>= 1)
-        if (r >= k && ds[r - k] >= q) r -= k;
-    result[(size_t)i * m + j] = r;
+    const float* c = cdf + (size_t)row * n;
+    const float q = u[(size_t)row * m + j] * c[n - 1];
+    int pos = n - 1;
+    for (int step = top; step > 0; step >>= 1) {
+        const int cand = pos - step;
+        if (cand >= 0 && c[cand] >= q) pos = cand;
+    }
+    pick[(size_t)row * m + j] = pos;
 }
 extern "C" int gspn_probsample(int b, int n, int m, const float* inp_p, const float* inp_r, float* temp, int* out, void* stream) {
     if (b < 0 || n <= 0 || m < 0) return GSPN_ERR_ARG;
     if (b == 0 || m == 0) return 0;
     if (b > 65535) return GSPN_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(cumsum_kernel, dim3(b < 1024 ? b : 1024), dim3(512), 0, (hipStream_t)stream, b, n, inp_p, temp);
-    hipLaunchKernelGGL(binarysearch_kernel, dim3((m + 255) / 256, b), dim3(256), 0, (hipStream_t)stream, b, n, m, temp, inp_r, out);
+    hipLaunchKernelGGL(prefix_rows_kernel, dim3(b < 2048 ? b : 2048), dim3(PS_THREADS), 0, (hipStream_t)stream, b, n, inp_p, temp);
+    int top = 1;
+    while (top < n) top <<= 1;
+    hipLaunchKernelGGL(inverse_cdf_kernel, dim3((m + 255) / 256, b), dim3(256), 0, (hipStream_t)stream, n, m, top, temp, inp_r, out);
     return gspn_launch_status();
 }
 

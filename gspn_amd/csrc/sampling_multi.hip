@@ -178,6 +178,7 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(int b, int n, int m, i
                         td[pp][1] = vmin_f32(d[1], td[pp][1]);
                     }
                     zq = zn;
+                    __builtin_amdgcn_sched_barrier(0);     // keeps the z double-buffer from being hoisted across quads (VGPR budget)
                 }
             } else {
 #pragma unroll

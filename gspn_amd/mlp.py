@@ -25,6 +25,25 @@ DEFER_DW = False
 FUSE_DW = os.environ.get("GSPN_FUSE_DW", "1") != "0"
 _side_streams = {}
 
+# bench.py sets this to a list to collect (kind, rows, cin, cout, start_event, end_event) around every GEMM-kernel launch of the stack
+# ("fwd", "wgrad" = pass A incl. its finalize kernels, "bwd" = pass B (+ the dW reduction riding in it)); None = no events
+PROFILE = None
+
+
+def _tic():
+    if PROFILE is None:
+        return None
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
+
+def _toc(e0, kind, rows, cin, cout):
+    if e0 is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        PROFILE.append((kind, rows, cin, cout, e0, e1))
+
 
 def _side_stream(dev):
     key = (dev.type, dev.index)
@@ -59,7 +78,6 @@ class _MlpStack(torch.autograd.Function):
         """x: (rows, ld) float32 contiguous; spec: dict(layers=[LayerParams], is_training, decay, pool_ns);
         params: flat list of the differentiable tensors (w, b[, beta, gamma]) per layer, for autograd."""
         lib = L.lib()
-        st = L.stream()
         dev = x.device
         rows, ld = x.shape
         layers = spec["layers"]
@@ -70,13 +88,16 @@ class _MlpStack(torch.autograd.Function):
         cur, cur_ld, cin = x, ld, cin0
         in_scale = in_shift = None
         with torch.cuda.device(dev):
+            st = L.stream()                      # the current stream of x's device (not of whatever device was current outside)
             for lp in layers:
                 cout = lp.weights.shape[1]
                 y = torch.empty((rows, cout), dtype=torch.float32, device=dev)
                 use_stats = lp.bn and is_training
                 stats = torch.empty(int(lib.gspn_mlp_fwd_stats_bytes(rows, cout)) // 4, dtype=torch.float32, device=dev) if use_stats else None
+                ev = _tic()
                 L.check(lib.gspn_mlp_fwd(rows, cin, cout, L.ptr(cur), cur_ld, L.ptr(in_scale), L.ptr(in_shift),
                                          L.ptr(lp.weights), L.ptr(lp.biases), L.ptr(y), cout, L.ptr(stats), st), "mlp_fwd")
+                _toc(ev, "fwd", rows, cin, cout)
                 mean = torch.empty(cout, dtype=torch.float32, device=dev)
                 var = torch.empty(cout, dtype=torch.float32, device=dev)
                 scale = torch.empty(cout, dtype=torch.float32, device=dev)
@@ -104,6 +125,9 @@ class _MlpStack(torch.autograd.Function):
                 out = torch.empty((rows, cl), dtype=torch.float32, device=dev)
                 L.check(lib.gspn_bnrelu_apply(rows, cl, L.ptr(cur), cur_ld, L.ptr(in_scale), L.ptr(in_shift), L.ptr(out), cl, st), "bnrelu_apply")
         ctx.saved = saved
+        # backward re-reads the weights and gamma: an in-place update between forward and backward would silently change the result
+        # (autograd's own check only covers save_for_backward tensors; these are kept as attributes so the layer list stays one object)
+        ctx.versions = [(lp.weights._version, lp.gamma._version if lp.bn else 0) for lp in layers]
         ctx.arg = arg
         ctx.spec = spec
         ctx.rows = rows
@@ -113,9 +137,11 @@ class _MlpStack(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_out):
         lib = L.lib()
-        st = L.stream()
         spec = ctx.spec
         layers = spec["layers"]
+        for lp, (vw, vg) in zip(layers, ctx.versions):
+            if lp.weights._version != vw or (lp.bn and lp.gamma._version != vg):
+                raise RuntimeError("mlp_stack: a weight or gamma tensor was modified in place between forward and backward")
         is_training = bool(spec["is_training"])
         pool_ns = spec["pool_ns"]
         rows = ctx.rows
@@ -128,6 +154,7 @@ class _MlpStack(torch.autograd.Function):
         side = main = None
         keep = []
         with torch.cuda.device(dev):
+            st = L.stream()
             for li in range(len(layers) - 1, -1, -1):
                 lp = layers[li]
                 (xin, xld, cin, in_scale, in_shift, y, mean, var, scale, shift) = ctx.saved[li]
@@ -150,10 +177,12 @@ class _MlpStack(torch.autograd.Function):
                 work = torch.empty(int(lib.gspn_mlp_bwd_work_bytes(rows, cin, cout)) // 4 + 4, dtype=torch.float32, device=dev)
                 has_dx = li > 0 or ctx.x_needs_grad
                 fuse_dw = FUSE_DW and has_dx and not DEFER_DW      # the dW reduction rides in spare workgroups of this layer's pass B
+                ev = _tic()
                 L.check(lib.gspn_mlp_bwd_wgrad(rows, cin, cout, ctypes.byref(a), L.ptr(xin), xld, L.ptr(in_scale), L.ptr(in_shift),
                                                L.ptr(mean), L.ptr(var), L.ptr(lp.gamma if lp.bn else None), BN_EPS, int(lp.bn), int(is_training),
                                                L.ptr(work), L.ptr(cA), L.ptr(cB), L.ptr(cC), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dbias),
                                                None if (DEFER_DW or fuse_dw) else L.ptr(dW), st), "mlp_bwd_wgrad")
+                _toc(ev, "wgrad", rows, cin, cout)
                 if DEFER_DW:
                     if side is None:
                         side = _side_stream(dev)
@@ -173,6 +202,7 @@ class _MlpStack(torch.autograd.Function):
                         dx.zero_()
                     # only grad_cols of the input feed a gradient upstream (e.g. not the xyz columns of an SA input)
                     gc = (spec.get("grad_cols") if li == 0 else None) or (0, cin)
+                    ev = _tic()
                     if fuse_dw:
                         L.check(lib.gspn_mlp_bwd_data_dw(rows, cin, cout, ctypes.byref(a), L.ptr(lp.weights), int(gc[0]), int(gc[1]), L.ptr(dx), dx.shape[1],
                                                          L.ptr(xin), xld, L.ptr(var), L.ptr(lp.gamma if lp.bn else None), BN_EPS, int(lp.bn),
@@ -180,6 +210,7 @@ class _MlpStack(torch.autograd.Function):
                     else:
                         L.check(lib.gspn_mlp_bwd_data_cols(rows, cin, cout, ctypes.byref(a), L.ptr(lp.weights), int(gc[0]), int(gc[1]), L.ptr(dx),
                                                            dx.shape[1], st), "mlp_bwd_data_cols")
+                    _toc(ev, "bwd", rows, cin, cout)
                     if li == 0:
                         dx0 = dx
                     dz, ldz = dx, dx.shape[1]

@@ -109,6 +109,11 @@ def fp_concat(points2, idx, weight, points1, order=None, offsets=None):
 
 
 def group_concat(xyz, new_xyz, points, idx, xyz_first=True, order=None, offsets=None):
+    """fused group + centre-subtract + concat.  The coordinates are treated as constants (they are inputs of the network in the
+    set-abstraction path); a caller whose xyz / new_xyz carry a gradient must take the unfused ops (group_point / gather_point have
+    the reference's gradients) -- refusing here keeps that gradient from being dropped silently."""
+    if xyz.requires_grad or new_xyz.requires_grad:
+        raise ValueError("group_concat: xyz / new_xyz require a gradient; use the unfused path (group_point, gather_point)")
     xyz = L.need(xyz.detach(), torch.float32, 3, "xyz")
     new_xyz = L.need(new_xyz.detach(), torch.float32, 3, "new_xyz")
     idx = L.need(idx, torch.int32, 3, "idx")
@@ -169,7 +174,10 @@ def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_al
     None computes it inline, with identical results."""
     with tf_util.variable_scope(scope):
         b = xyz.shape[0]
-        fused = (pooling == 'max') and not group_all and not knn and tnet_spec is None and len(mlp) > 0 and (points is None or use_xyz)
+        # the fused path treats coordinates as constants; predicted / shifted coordinates (xyz.requires_grad) take the reference's
+        # composition below, whose group_point / gather_point gradients reach xyz (tf_grouping.py:63-67, tf_sampling.py:43-47)
+        fused = ((pooling == 'max') and not group_all and not knn and tnet_spec is None and len(mlp) > 0 and (points is None or use_xyz)
+                 and not xyz.requires_grad)
         if geometry is not None and (not fused or geometry.npoint != npoint or geometry.nsample != nsample):
             raise ValueError("pointnet_sa_module: precomputed geometry does not match this module")
         if fused:

@@ -27,7 +27,7 @@ def multi_encoding_net(xyz, points, npoint, radius_list, nsample_list, mlp_list,
         for i in range(len(radius_list)):
             radius, nsample = radius_list[i], nsample_list[i]
             idx, pts_cnt = query_ball_point(radius, nsample, xyz, new_xyz)      # :53
-            if shift_pred is None and (points is None or use_xyz):
+            if shift_pred is None and (points is None or use_xyz) and not xyz.requires_grad:
                 # fused: concat([points[idx], xyz[idx] - new_xyz]) written straight into the MLP's input matrix (:54-63)
                 rows = group_concat(xyz, new_xyz, points, idx, xyz_first=False)
                 c = 0 if points is None else points.shape[2]

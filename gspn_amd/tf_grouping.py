@@ -3,6 +3,10 @@ import torch
 
 from . import _lib as L
 
+# bench.py sets this to a list to collect (start_event, end_event, b, n, m, radius, nsample) around every ball-query launch, recorded
+# on the stream the kernel is launched on
+PROFILE = None
+
 
 def query_ball_point(radius, nsample, xyz1, xyz2):
     """tf_grouping.py:8-21 -- xyz1 (b,n,3) data, xyz2 (b,m,3) queries ->
@@ -24,8 +28,15 @@ def query_ball_point(radius, nsample, xyz1, xyz2):
     idx = torch.empty((b, m, nsample), dtype=torch.int32, device=xyz1.device)
     cnt = torch.empty((b, m), dtype=torch.int32, device=xyz1.device)
     with torch.cuda.device(xyz1.device):
+        ev = None
+        if PROFILE is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         L.check(L.lib().gspn_queryballpoint(b, n, m, radius, nsample, L.ptr(xyz1), L.ptr(xyz2), L.ptr(idx), L.ptr(cnt), L.stream()),
                 "query_ball_point")
+        if ev is not None:
+            ev[1].record()
+            PROFILE.append((ev[0], ev[1], b, n, m, radius, nsample))
     return idx, cnt
 
 
@@ -112,13 +123,29 @@ def group_point(points, idx):
     return _GroupPoint.apply(points, idx)
 
 
+KNN_DIRECT_MAX_K = 32
+
+
 def knn_point(k, xyz1, xyz2):
     """tf_grouping.py:71-96 -- xyz1 (b,n,c) data, xyz2 (b,m,c) queries -> val (b,m,k), idx (b,m,k).
-    Same construction as the reference (dense squared-distance matrix, selection sort, slice) so the
-    tie order of the in-place selection sort is reproduced; O(b*m*n) memory like the reference."""
+    3-D points and k <= 32: one direct kernel (LDS-tiled scan, 64 candidates per query, replay of the reference's selection sort on
+    them: same result as the reference's dense matrix + sort + slice, ties included, without the O(b*m*n) tensor).  Anything else
+    takes the reference's own construction (dense squared-distance matrix, selection sort, slice)."""
     k = int(k)
     xyz1 = L.need(xyz1.detach(), torch.float32, 3, "xyz1")
     xyz2 = L.need(xyz2.detach(), torch.float32, 3, "xyz2")
+    b, n, c = xyz1.shape
+    m = xyz2.shape[1]
+    if xyz2.shape[0] != b or xyz2.shape[2] != c:
+        raise ValueError("knn_point expects xyz1 (b,n,c) and xyz2 (b,m,c)")
+    if k <= 0 or k > n:
+        raise ValueError("knn_point expects 0 < k <= ndataset")       # tf.slice(outi, [0,0,0], [-1,-1,k]) of an (b,m,n) tensor
+    if c == 3 and k <= KNN_DIRECT_MAX_K:
+        val = torch.empty((b, m, k), dtype=torch.float32, device=xyz1.device)
+        idx = torch.empty((b, m, k), dtype=torch.int32, device=xyz1.device)
+        with torch.cuda.device(xyz1.device):
+            L.check(L.lib().gspn_knn_point(b, n, m, k, L.ptr(xyz1), L.ptr(xyz2), L.ptr(val), L.ptr(idx), L.stream()), "knn_point")
+        return val, idx
     # tf.reduce_sum((tile(xyz1)-tile(xyz2))**2, -1)  (:85-87): data minus query, summed over the last axis
     diff = xyz1[:, None, :, :] - xyz2[:, :, None, :]
     sq = diff * diff

@@ -20,6 +20,7 @@ class VariableStore:
     def __init__(self, device=None, seed=None):
         self.vars = {}
         self.trainable = []
+        self.losses = {}            # tf.get_collection('losses'): full variable name -> (variable, weight decay)
         self.device = device
         self.generator = None
         if seed is not None:
@@ -105,20 +106,19 @@ def _variable_on_cpu(name, shape, initializer, use_fp16=False):
     return get_variable(name, shape, initializer)
 
 
-_losses = []
-
-
 def _variable_with_weight_decay(name, shape, stddev, wd, use_xavier=True):
-    """tf_util.py:24-49"""
+    """tf_util.py:24-49.  The decay term joins the 'losses' collection once per variable (TF builds the graph once; this eager mirror
+    passes here on every forward), keyed by the variable's full name in the store that owns it."""
     init = xavier_initializer() if use_xavier else truncated_normal_initializer(stddev)
     var = _variable_on_cpu(name, shape, init)
     if wd is not None:
-        _losses.append((var, float(wd)))          # tf.add_to_collection('losses', l2_loss(var)*wd)
+        _store.losses["/".join(_scopes + [name])] = (var, float(wd))          # tf.add_to_collection('losses', l2_loss(var)*wd)
     return var
 
 
 def weight_decay_loss():
-    return sum((0.5 * (v * v).sum() * wd for v, wd in _losses), torch.zeros((), device=_store.dev()))
+    """sum of the 'losses' collection of the current store: wd * l2_loss(var) = wd * sum(var**2) / 2 per decayed variable"""
+    return sum((0.5 * (v * v).sum() * wd for v, wd in _store.losses.values()), torch.zeros((), device=_store.dev()))
 
 
 # --------------------------------------------------------------------------- layers

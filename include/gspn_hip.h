@@ -95,6 +95,12 @@ float gspn_ball_threshold(float radius);
 /* selectionSortLauncher(b,n,m,k,dist,outi,out)  tf_grouping.cpp:138, tf_grouping_g.cu:190-193 */
 int gspn_selectionsort(int b, int n, int m, int k, const float* dist, int* outi, float* out, void* stream);
 
+/* knn_point(k, xyz1, xyz2) of tf_grouping.py:71-96 as ONE call, for 3-D points: the reference composes it in TensorFlow from a dense
+ * (b,m,n) squared-distance tensor (:85-87), selectionSortLauncher and a slice (:88-92).  Same val (b,m,k) / idx (b,m,k), ties
+ * included, without the matrix (gspn_amd/csrc/knn.hip).  k <= 32 here (GSPN_ERR_UNSUPPORTED beyond: use gspn_selectionsort);
+ * k > n is rejected like the slice would be. */
+int gspn_knn_point(int b, int n, int m, int k, const float* xyz1, const float* xyz2, float* val, int* idx, void* stream);
+
 /* knn_point (tf_grouping.py:71-96) is composed on the host side exactly as the reference does:
  * dense squared-distance matrix + gspn_selectionsort + slice (see gspn_amd/tf_grouping.py). */
 

@@ -61,7 +61,17 @@ class _Interp(torch.autograd.Function):
 
 
 def run_step(xyz, feat, seed=1234, mt=False):
-    """one fwd+bwd pass of the 3xSA + 3xFP stack on CPU; xyz (b,n,3), feat (b,n,c) float32 numpy. Returns seconds."""
+    """one fwd+bwd pass of the 3xSA + 3xFP stack on CPU; xyz (b,n,3), feat (b,n,c) float32 numpy. Returns seconds.
+    mt: OpenMP inside the oracle loops (scenes for FPS and the scatter-add gradients, scene x query for ball query / grouping /
+    3-NN / interpolation); the torch thread count for the MLP stand-in is the caller's (torch.set_num_threads)."""
+    O.set_mt(mt)
+    try:
+        return _run_step(xyz, feat, seed, mt)
+    finally:
+        O.set_mt(False)
+
+
+def _run_step(xyz, feat, seed, mt):
     gen = torch.Generator().manual_seed(seed)
     t0 = time.perf_counter()
     b = xyz.shape[0]

@@ -54,6 +54,12 @@ static inline float dist2_host(float a, float b, float c) {
 
 int oracle_dist_policy(void) { return GSPN_DIST_POLICY; }
 
+/* bench.py's cpu_baseline "all cores" leg: OpenMP over scene x query.  Off by default (the faithful single-thread form of
+ * the reference's own CPU loops); every output element is computed by one thread with the same arithmetic, so results do not change.
+ * The scatter-add gradients keep their sequential order inside a scene and spread over scenes only. */
+static int g_mt = 0;
+void oracle_set_mt(int on) { g_mt = on ? 1 : 0; }
+
 /* debug: expose the two distance forms so GPU arithmetic can be bit-compared */
 void oracle_dist2(int cnt, const float *p, const float *q, float *out_cuda, float *out_host) {
     for (int i = 0; i < cnt; i++) {
@@ -147,6 +153,7 @@ void oracle_gather_point_grad(int b, int n, int m, const float *out_g, const int
  * ---------------------------------------------------------------------------------------- */
 static void ball_one(int n, int m, float radius, int nsample, const float *xyz1, const float *xyz2,
                      int *idx, int *pts_cnt, int *visited) {
+#pragma omp parallel for schedule(dynamic, 16) if (g_mt)
     for (int j = 0; j < m; j++) {
         int cnt = 0, k;
         for (int l = 0; l < nsample; l++) idx[j * nsample + l] = 0;
@@ -174,7 +181,7 @@ void oracle_query_ball_point(int b, int n, int m, float radius, int nsample, con
 }
 void oracle_query_ball_point_mt(int b, int n, int m, float radius, int nsample, const float *xyz1,
                                 const float *xyz2, int *idx, int *pts_cnt, int *visited) {
-#pragma omp parallel for schedule(dynamic, 1)
+#pragma omp parallel for schedule(dynamic, 1) if (!g_mt)
     for (int i = 0; i < b; i++)
         ball_one(n, m, radius, nsample, xyz1 + (size_t)i * n * 3, xyz2 + (size_t)i * m * 3,
                  idx + (size_t)i * m * nsample, pts_cnt + (size_t)i * m, visited ? visited + (size_t)i * m : 0);
@@ -182,6 +189,7 @@ void oracle_query_ball_point_mt(int b, int n, int m, float radius, int nsample, 
 
 /* A5 group_point -- tf_grouping_g.cu:43-60 */
 void oracle_group_point(int b, int n, int c, int m, int nsample, const float *points, const int *idx, float *out) {
+#pragma omp parallel for collapse(2) schedule(static) if (g_mt)
     for (int i = 0; i < b; i++)
         for (int j = 0; j < m; j++)
             for (int k = 0; k < nsample; k++) {
@@ -193,6 +201,7 @@ void oracle_group_point(int b, int n, int c, int m, int nsample, const float *po
 /* A6 group_point_grad -- tf_grouping_g.cu:66-83 (+ memset tf_grouping.cpp:234); sums in (j,k) order */
 void oracle_group_point_grad(int b, int n, int c, int m, int nsample, const float *grad_out, const int *idx, float *grad_points) {
     memset(grad_points, 0, sizeof(float) * (size_t)b * n * c);
+#pragma omp parallel for schedule(static) if (g_mt)
     for (int i = 0; i < b; i++)
         for (int j = 0; j < m; j++)
             for (int k = 0; k < nsample; k++) {
@@ -277,9 +286,13 @@ void oracle_knn_dist(int b, int n, int c, int m, const float *xyz1, const float 
  * A8 three_nn -- tf_ops/3d_interpolation/tf_interpolate.cpp:60-103 (host arithmetic: unfused
  * fp32, compared as double; strict '<' cascade; init 1e40 -> +inf when cast to float)
  * ---------------------------------------------------------------------------------------- */
-void oracle_three_nn(int b, int n, int m, const float *xyz1, const float *xyz2, float *dist, int *idx) {
+void oracle_three_nn(int b, int n, int m, const float *xyz1_, const float *xyz2_, float *dist_, int *idx_) {
+#pragma omp parallel for collapse(2) schedule(static) if (g_mt)
     for (int i = 0; i < b; ++i) {
         for (int j = 0; j < n; ++j) {
+            const float *xyz1 = xyz1_ + (size_t)i * n * 3, *xyz2 = xyz2_ + (size_t)i * m * 3;
+            float *dist = dist_ + (size_t)i * n * 3;
+            int *idx = idx_ + (size_t)i * n * 3;
             float x1 = xyz1[j * 3 + 0], y1 = xyz1[j * 3 + 1], z1 = xyz1[j * 3 + 2];
             double best1 = 1e40, best2 = 1e40, best3 = 1e40;
             int besti1 = 0, besti2 = 0, besti3 = 0;
@@ -294,25 +307,31 @@ void oracle_three_nn(int b, int n, int m, const float *xyz1, const float *xyz2, 
             dist[j * 3 + 1] = (float)best2; idx[j * 3 + 1] = besti2;
             dist[j * 3 + 2] = (float)best3; idx[j * 3 + 2] = besti3;
         }
-        xyz1 += n * 3; xyz2 += m * 3; dist += n * 3; idx += n * 3;
     }
 }
 /* A9 three_interpolate -- tf_interpolate.cpp:107-127 */
-void oracle_three_interpolate(int b, int m, int c, int n, const float *points, const int *idx, const float *weight, float *out) {
+void oracle_three_interpolate(int b, int m, int c, int n, const float *points_, const int *idx_, const float *weight_, float *out_) {
+#pragma omp parallel for collapse(2) schedule(static) if (g_mt)
     for (int i = 0; i < b; ++i) {
         for (int j = 0; j < n; ++j) {
+            const float *points = points_ + (size_t)i * m * c, *weight = weight_ + (size_t)i * n * 3;
+            const int *idx = idx_ + (size_t)i * n * 3;
+            float *out = out_ + (size_t)i * n * c;
             float w1 = weight[j * 3], w2 = weight[j * 3 + 1], w3 = weight[j * 3 + 2];
             int i1 = idx[j * 3], i2 = idx[j * 3 + 1], i3 = idx[j * 3 + 2];
             for (int l = 0; l < c; ++l)
                 out[(size_t)j * c + l] = points[(size_t)i1 * c + l] * w1 + points[(size_t)i2 * c + l] * w2 + points[(size_t)i3 * c + l] * w3;
         }
-        points += (size_t)m * c; idx += n * 3; weight += n * 3; out += (size_t)n * c;
     }
 }
 /* A10 three_interpolate_grad -- tf_interpolate.cpp:131-153 (+ memset :258) */
-void oracle_three_interpolate_grad(int b, int n, int c, int m, const float *grad_out, const int *idx, const float *weight, float *grad_points) {
-    memset(grad_points, 0, sizeof(float) * (size_t)b * m * c);
+void oracle_three_interpolate_grad(int b, int n, int c, int m, const float *grad_out_, const int *idx_, const float *weight_, float *grad_points_) {
+    memset(grad_points_, 0, sizeof(float) * (size_t)b * m * c);
+#pragma omp parallel for schedule(static) if (g_mt)
     for (int i = 0; i < b; ++i) {
+        const float *grad_out = grad_out_ + (size_t)i * n * c, *weight = weight_ + (size_t)i * n * 3;
+        const int *idx = idx_ + (size_t)i * n * 3;
+        float *grad_points = grad_points_ + (size_t)i * m * c;
         for (int j = 0; j < n; ++j) {
             float w1 = weight[j * 3], w2 = weight[j * 3 + 1], w3 = weight[j * 3 + 2];
             int i1 = idx[j * 3], i2 = idx[j * 3 + 1], i3 = idx[j * 3 + 2];
@@ -322,7 +341,6 @@ void oracle_three_interpolate_grad(int b, int n, int c, int m, const float *grad
                 grad_points[(size_t)i3 * c + l] += grad_out[(size_t)j * c + l] * w3;
             }
         }
-        grad_out += (size_t)n * c; idx += n * 3; weight += n * 3; grad_points += (size_t)m * c;
     }
 }
 

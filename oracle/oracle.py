@@ -66,6 +66,11 @@ def _i32(a):
     return np.ascontiguousarray(a, dtype=np.int32)
 
 
+def set_mt(on):
+    """bench.py's cpu_baseline "all cores" leg: OpenMP over scene x query inside the oracle loops (results unchanged)"""
+    lib().oracle_set_mt(int(bool(on)))
+
+
 def dist_policy():
     return lib().oracle_dist_policy()
 

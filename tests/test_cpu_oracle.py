@@ -229,3 +229,27 @@ def test_selection_sort_and_knn():
             np.testing.assert_array_equal(np.sort(oi[b, j]), np.arange(40))           # a permutation
             np.testing.assert_array_equal(dist[b, j][oi[b, j]], od[b, j])
             assert od[b, j, 6] <= od[b, j, 7:].min()
+
+
+def test_openmp_mode_does_not_change_results():
+    """oracle_set_mt (bench.py's all-cores baseline): same bits with and without OpenMP over scene x query"""
+    rng = np.random.default_rng(8)
+    xyz = rng.random((3, 700, 3)).astype(np.float32)
+    q = O.gather_point(xyz, O.farthest_point_sample(90, xyz))
+    pts = rng.standard_normal((3, 700, 5)).astype(np.float32)
+    res = []
+    for on in (False, True):
+        O.set_mt(on)
+        try:
+            idx, cnt = O.query_ball_point(0.2, 16, xyz, q)
+            d, i3 = O.three_nn(xyz, q)
+            gp = O.group_point(pts, idx)
+            gg = O.group_point_grad(pts, idx, gp)
+            w = np.full(d.shape, 1 / 3, np.float32)
+            ip = O.three_interpolate(pts[:, :90].copy(), i3, w)
+            ig = O.three_interpolate_grad(pts[:, :90].copy(), i3, w, ip)
+            res.append((idx, cnt, d, i3, gp, gg, ip, ig))
+        finally:
+            O.set_mt(False)
+    for a, b_ in zip(*res):
+        np.testing.assert_array_equal(a, b_)

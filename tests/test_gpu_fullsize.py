@@ -132,3 +132,101 @@ def test_multi_encoding_net_config4_shape(scenes):
     ridx, rcnt = O.query_ball_point(1.5, 512, x4, new_xyz.cpu().numpy(), mt=True)
     np.testing.assert_array_equal(idx.cpu().numpy(), ridx)
     np.testing.assert_array_equal(cnt.cpu().numpy(), rcnt)
+
+
+def test_knn_full_size_without_the_matrix(scenes):
+    """(8, 32768, 2048, k=32): the reference's construction would need a 2 GiB distance tensor.  Every query is independent, so a
+    sample of them is checked against the oracle's dense construction; all of them against properties of a k-NN result."""
+    from gspn_amd.tf_grouping import knn_point
+    from gspn_amd.tf_sampling import farthest_point_sample, gather_point
+    xyz, t = scenes
+    q = gather_point(t, farthest_point_sample(2048, t))
+    val, idx = knn_point(32, t, q)
+    assert val.shape == (B, 2048, 32) and idx.shape == (B, 2048, 32)
+    qn = q.cpu().numpy()
+    pick = np.arange(0, 2048, 97)
+    for s in (0, 5):
+        rv, ri = O.knn_point(32, xyz[s:s + 1], qn[s:s + 1, pick])
+        np.testing.assert_array_equal(idx[s, pick].cpu().numpy(), ri[0])
+        np.testing.assert_array_equal(val[s, pick].cpu().numpy(), rv[0])
+    # queries are data points: the nearest neighbour is the query itself at distance 0; distances ascend; indices are distinct
+    assert (val[..., 0] == 0).all()
+    assert (val[..., 1:] >= val[..., :-1]).all()
+    srt = idx.long().sort(dim=-1).values
+    assert (srt[..., 1:] != srt[..., :-1]).all()
+    g = torch.gather(t.unsqueeze(1).expand(-1, 2048, -1, -1), 2, idx.long().unsqueeze(-1).expand(-1, -1, -1, 3))
+    d = ((g - q.unsqueeze(2)) ** 2)
+    np.testing.assert_array_equal(((d[..., 0] + d[..., 1]) + d[..., 2]).cpu().numpy(), val.cpu().numpy())
+
+
+def _ref_layers(store, scope, names, h, device):
+    """inference-mode conv2d+BN+ReLU stack of oracle/mlp_ref.py (float64) with the store's parameters and moving statistics"""
+    from oracle import mlp_ref as R
+    from tests.test_gpu_modules import ref_params
+    for p in ref_params(store, scope, names):
+        q = {k: (v.detach().to(device) if torch.is_tensor(v) else v) for k, v in p.items()}
+        h, _, _ = R.layer(h, q["w"], q["b"], q["gamma"], q["beta"], q["moving_mean"], q["moving_var"], False, 0.5)
+    return h
+
+
+def test_fea_extractor_full_size_forward_backward(scenes):
+    """BASELINE configs[2] as bench.py runs it: 8 x 32768 points through pn2_fea_extractor (3 SA + 3 FP), forward + backward.
+    (a) every index the geometry produces equals the oracle's; (b) one training step is bit-reproducible and all gradients are
+    finite; (c) in inference mode (moving statistics: scenes independent) the output of one scene equals the float64 composition
+    of oracle/mlp_ref.py over the same indices within 1e-5."""
+    from oracle import mlp_ref as R
+    from gspn_amd import tf_util
+    from gspn_amd.fea_extractor import PN2_SA_SPEC, pn2_fea_extractor, pn2_geometry
+    xyz, t = scenes
+    col = torch.rand(B, N, 3, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+    geo = pn2_geometry(t)
+    # (a) geometry vs oracle
+    cur, levels = xyz, [xyz]
+    for lvl, (npoint, radius, ns) in enumerate(PN2_SA_SPEC):
+        new = O.gather_point(cur, O.farthest_point_sample(npoint, cur, mt=True))
+        ridx, rcnt = O.query_ball_point(radius, ns, cur, new, mt=True)
+        np.testing.assert_array_equal(geo["sa"][lvl].new_xyz.cpu().numpy(), new)
+        np.testing.assert_array_equal(geo["sa"][lvl].idx.cpu().numpy(), ridx)
+        cur = new
+        levels.append(new)
+    for fpg, (dense, sparse, nsc) in zip(geo["fp"], [(levels[2], levels[3], B), (levels[1], levels[2], B), (levels[0], levels[1], 1)]):
+        rd, ri = O.three_nn(dense[:nsc], sparse[:nsc])                    # the 32768 <- 2048 level: one scene (single-threaded oracle)
+        np.testing.assert_array_equal(fpg.idx[:nsc].cpu().numpy(), ri)
+        w = R.fp_weights(torch.from_numpy(rd).double())
+        assert float((fpg.weight[:nsc].cpu().double() - w).abs().max()) < 1e-6
+    # (b) one training step, twice from the same initial state
+    runs = []
+    for _ in range(2):
+        store = tf_util.set_variable_store(tf_util.VariableStore(seed=21))
+        out = pn2_fea_extractor(t, col, 'fea', True, 0.5, geometry=geo)
+        assert out.shape == (B, N, 64)
+        out.square().mean().backward()
+        torch.cuda.synchronize()
+        runs.append((out.detach().clone(), {n: p.grad.detach().clone() for n, p in store.named_parameters()}))
+    assert torch.isfinite(runs[0][0]).all()
+    assert torch.equal(runs[0][0], runs[1][0])
+    for n, g in runs[0][1].items():
+        assert torch.isfinite(g).all(), n
+        assert torch.equal(g, runs[1][1][n]), n
+    # (c) inference mode on scene 2 vs the float64 composition (parameters + the moving statistics the training step left)
+    s = 2
+    with torch.no_grad():
+        got = pn2_fea_extractor(t[s:s + 1].contiguous(), col[s:s + 1].contiguous(), 'fea', False, None)
+    dev = t.device
+    pts = [t[s].double(), None, None, None]
+    feats = [col[s].double()]
+    for lvl, (npoint, radius, ns) in enumerate(PN2_SA_SPEC):
+        gi = geo["sa"][lvl].idx[s].long()
+        new = geo["sa"][lvl].new_xyz[s].double()
+        rows = torch.cat([pts[lvl][gi] - new[:, None, :], feats[lvl][gi]], -1).reshape(npoint * ns, -1)
+        h = _ref_layers(store, 'fea/layer%d' % (lvl + 1), ['conv0', 'conv1', 'conv2'], rows, dev)
+        feats.append(h.view(npoint, ns, -1).max(1).values)
+        pts[lvl + 1] = new
+    up = feats[3]
+    for k, (dl, names) in enumerate([(2, ['conv_0', 'conv_1']), (1, ['conv_0', 'conv_1']), (0, ['conv_0', 'conv_1', 'conv_2'])]):
+        fpg = geo["fp"][k]
+        w = fpg.weight[s].double()
+        interp = (up[fpg.idx[s].long()] * w[..., None]).sum(1)
+        up = _ref_layers(store, 'fea/fa_layer%d' % (k + 1), names, torch.cat([interp, feats[dl]], -1), dev)
+    err = float((got[0].double() - up).abs().max() / up.abs().max())
+    assert err < 1e-5, err

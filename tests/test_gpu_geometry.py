@@ -236,8 +236,65 @@ def test_prob_sample():
         np.testing.assert_array_equal(got, O.prob_sample(w, r))
 
 
+@pytest.mark.parametrize("b,n", [(2, 1), (2, 3), (3, 4), (2, 5), (3, 1000), (2, 8191), (2, 8192), (2, 8193), (2, 20000), (1, 8192 * 3 + 6), (5, 70001)])
+def test_prob_sample_prefix_sums_round_like_the_reference(b, n):
+    """the cumulative sums (the op's temp buffer) carry the reference's association order bit for bit (tf_sampling_g.cu:7-80):
+    groups of 4, Brent-Kung tree over the group totals, compensated carry across 8192-element tiles"""
+    from gspn_amd import _lib as L
+    rng = np.random.default_rng(n)
+    w = (rng.random((b, n)) ** 3).astype(np.float32)
+    r = rng.random((b, 7)).astype(np.float32)
+    tw, tr = dev(w), dev(r)
+    temp = torch.empty((b, n), dtype=torch.float32, device="cuda")
+    out = torch.empty((b, 7), dtype=torch.int32, device="cuda")
+    L.check(L.lib().gspn_probsample(b, n, 7, L.ptr(tw), L.ptr(tr), L.ptr(temp), L.ptr(out), L.stream()), "prob_sample")
+    np.testing.assert_array_equal(temp.cpu().numpy().view(np.uint32), O.cumsum(w).view(np.uint32))
+    np.testing.assert_array_equal(out.cpu().numpy(), O.prob_sample(w, r))
+
+
 def test_cpu_tensor_is_rejected_loudly():
     from gspn_amd import _lib
     from gspn_amd.tf_sampling import farthest_point_sample
     with pytest.raises(_lib.GspnHipError):
         farthest_point_sample(4, torch.zeros(1, 16, 3))
+
+
+@pytest.mark.parametrize("kind,b,n,m,k", [("U", 2, 8192, 512, 32), ("D", 2, 3000, 100, 16), ("U", 1, 70, 33, 32), ("U", 2, 40, 9, 7),
+                                          ("S", 1, 5000, 64, 1), ("U", 3, 2048, 2048, 3), ("U", 1, 33, 40, 32)])
+def test_knn_direct_matches_reference_construction(kind, b, n, m, k):
+    """knn_point without the (b,m,n) matrix == dense matrix + selection sort + slice of the oracle (tf_grouping.py:71-96)"""
+    from gspn_amd.tf_grouping import knn_point
+    x1 = D.batch(kind, b, n)
+    x2 = D.batch(kind, b, m, 50)
+    v, i = knn_point(k, dev(x1), dev(x2))
+    rv, ri = O.knn_point(k, x1, x2)
+    np.testing.assert_array_equal(i.cpu().numpy(), ri)
+    np.testing.assert_array_equal(v.cpu().numpy(), rv)
+
+
+@pytest.mark.parametrize("n,m,k,grid", [(500, 64, 32, 3), (4000, 128, 32, 5), (4000, 50, 9, 2), (100, 30, 32, 2), (64, 10, 32, 4), (70, 10, 20, 1)])
+def test_knn_direct_ties_follow_the_selection_sort(n, m, k, grid):
+    """integer lattice: most distances are tied, so the order inside the first k depends on where the in-place selection sort has
+    moved the elements it displaced (tf_grouping_g.cu:162-183) -- the direct kernel replays exactly that"""
+    from gspn_amd.tf_grouping import knn_point
+    rng = np.random.default_rng(n + k)
+    x1 = rng.integers(0, grid, size=(2, n, 3)).astype(np.float32)
+    x2 = rng.integers(0, grid, size=(2, m, 3)).astype(np.float32)
+    v, i = knn_point(k, dev(x1), dev(x2))
+    rv, ri = O.knn_point(k, x1, x2)
+    np.testing.assert_array_equal(i.cpu().numpy(), ri)
+    np.testing.assert_array_equal(v.cpu().numpy(), rv)
+
+
+def test_knn_dense_fallback_and_validation():
+    from gspn_amd.tf_grouping import knn_point
+    x1 = D.batch("U", 1, 300)
+    x2 = D.batch("U", 1, 20, 9)
+    v, i = knn_point(40, dev(x1), dev(x2))                  # k > 32: the reference's own construction
+    rv, ri = O.knn_point(40, x1, x2)
+    np.testing.assert_array_equal(i.cpu().numpy(), ri)
+    np.testing.assert_array_equal(v.cpu().numpy(), rv)
+    with pytest.raises(ValueError):
+        knn_point(301, dev(x1), dev(x2))
+    with pytest.raises(ValueError):
+        knn_point(0, dev(x1), dev(x2))

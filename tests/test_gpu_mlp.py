@@ -44,17 +44,8 @@ def to_layers(ps):
     return layers
 
 
-@pytest.mark.parametrize("rows,ld,cin,chans,ns", [
-    (4096, 6, 6, [32, 32, 64], 32),        # SA1-shaped
-    (2048, 67, 67, [64, 64, 128], 32),     # SA2-shaped
-    (1024, 131, 131, [128, 128, 256], 32), # SA3-shaped
-    (768, 384, 384, [256, 128], None),     # FP1-shaped
-    (1000, 67, 67, [64, 64, 64], None),    # FP3-shaped, ragged rows
-    (512, 8, 5, [20], 16),                 # padded pitch, odd channel counts
-    (130, 3, 3, [7, 33], 2),
-])
-@pytest.mark.parametrize("training", [True, False])
-def test_mlp_stack_forward_backward(rows, ld, cin, chans, ns, training):
+def check_stack(rows, ld, cin, chans, ns, training, ref_device="cpu"):
+    """mlp_stack forward + backward against oracle/mlp_ref.py evaluated in float64 on `ref_device`"""
     from gspn_amd.mlp import mlp_stack
     g = torch.Generator().manual_seed(rows + cin)
     x64 = torch.randn(rows, ld, generator=g, dtype=torch.float64)
@@ -68,29 +59,85 @@ def test_mlp_stack_forward_backward(rows, ld, cin, chans, ns, training):
     x = x64.float().cuda().requires_grad_(True)
     out = mlp_stack(x, cin, layers, training, 0.7, pool_ns=ns)
 
-    xr = x64[:, :cin].clone().requires_grad_(True)
+    xr = x64[:, :cin].to(ref_device).clone().requires_grad_(True)
     for p in ps:
+        for k in p:
+            if torch.is_tensor(p[k]):
+                p[k] = p[k].to(ref_device)
         for k in ("w", "b", "gamma", "beta"):
             p[k] = p[k].clone().requires_grad_(True)
-    ref, moving = R.stack(xr, ps, training, 0.7, ns)
+    # float64 restatement, layer by layer (oracle/mlp_ref.py), keeping the pre-activations.  An element whose BN output lies within
+    # fp32 rounding of the ReLU kink -- or a pool group whose two largest activations agree to fp32 rounding -- may fall on the other
+    # side in float32.  One such flip moves dW by a single row's contribution, which at 1e5 rows is already 1e-3 of |dW| (the sum over
+    # rows of a random-sign gradient grows like sqrt(rows), not rows).  So the upstream gradient is set to ZERO on the rows (groups)
+    # that hold a fragile element: their masks then matter to no weight gradient in either precision.  Their own dX rows still see the
+    # flip through the batch-norm mean terms (a 1/sqrt(rows) effect, measured 2e-4 of max|dX| at 131072 rows: tools/mlp_bigcheck.py),
+    # so those rows -- and only those -- are left out of the dX comparison.  The forward comparison covers all rows.
+    h, moving = xr, []
+    fragile = torch.zeros(rows, dtype=torch.bool, device=ref_device)
+    for p in ps:
+        z, mm, mv = R.layer(h, p["w"], p["b"], p.get("gamma"), p.get("beta"), p.get("moving_mean"), p.get("moving_var"), training, 0.7,
+                            p.get("bn", True), relu=False)
+        fragile |= (z.detach().abs() < 2e-5).any(dim=1)
+        h = torch.relu(z)
+        moving.append((mm, mv))
+    ref = h
+    if ns:
+        full = ref.view(rows // ns, ns, -1)
+        top2 = full.detach().topk(2, dim=1).values
+        near = ((top2[:, 0] - top2[:, 1]) < 1e-5 * (top2[:, 0].abs() + 1e-3)) & (top2[:, 0] > 0)
+        fragile = fragile.view(rows // ns, ns).any(dim=1) | near.any(dim=1)
+        ref = full.max(dim=1).values
+    assert int(fragile.sum()) <= max(4, fragile.numel() // 4), "too many fragile rows/groups: %d of %d" % (int(fragile.sum()), fragile.numel())
     assert out.shape == ref.shape
     assert rel_err(out, ref) < 1e-5
     if training:
         for lp, (mm, mv) in zip(layers, moving):
             assert rel_err(lp.moving_mean, mm) < 1e-5 and rel_err(lp.moving_variance, mv) < 1e-5
 
-    go = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+    go = torch.randn(ref.shape, generator=g, dtype=torch.float64).to(ref_device)
+    go[fragile] = 0
     ref.backward(go)
     out.backward(go.float().cuda())
     tol = 1e-4
-    assert rel_err(x.grad[:, :cin], xr.grad) < tol
+    keep = ~(fragile.repeat_interleave(ns) if ns else fragile)
+    assert rel_err(x.grad[:, :cin][keep.to(x.device)], xr.grad[keep]) < tol
     for lp, p in zip(layers, ps):
         assert rel_err(lp.weights.grad, p["w"].grad) < tol
         assert rel_err(lp.gamma.grad, p["gamma"].grad) < tol
         assert rel_err(lp.beta.grad, p["beta"].grad) < tol
         # bias feeds a batch-normalised layer: its true gradient is ~0 in training mode
         scale = max(float(p["w"].grad.abs().max()), 1e-6)
-        assert float((lp.biases.grad.double().cpu() - p["b"].grad).abs().max()) < tol * max(scale, float(p["b"].grad.abs().max()))
+        assert float((lp.biases.grad.double().cpu() - p["b"].grad.cpu()).abs().max()) < tol * max(scale, float(p["b"].grad.abs().max()))
+
+
+@pytest.mark.parametrize("rows,ld,cin,chans,ns", [
+    (4096, 6, 6, [32, 32, 64], 32),        # SA1-shaped
+    (2048, 67, 67, [64, 64, 128], 32),     # SA2-shaped
+    (1024, 131, 131, [128, 128, 256], 32), # SA3-shaped
+    (768, 384, 384, [256, 128], None),     # FP1-shaped
+    (1000, 67, 67, [64, 64, 64], None),    # FP3-shaped, ragged rows
+    (512, 8, 5, [20], 16),                 # padded pitch, odd channel counts
+    (130, 3, 3, [7, 33], 2),
+])
+@pytest.mark.parametrize("training", [True, False])
+def test_mlp_stack_forward_backward(rows, ld, cin, chans, ns, training):
+    check_stack(rows, ld, cin, chans, ns, training)
+
+
+@pytest.mark.parametrize("rows,ld,cin,chans,ns", [
+    (524288, 8, 6, [32, 32, 64], 32),          # SA1 of BASELINE configs[2]: 8 scenes x 2048 groups x 32 samples
+    (131072, 68, 67, [64, 64, 128], 32),       # SA2
+    (32768, 132, 131, [128, 128, 256], 32),    # SA3
+    (4096, 384, 384, [256, 128], None),        # FP1
+    (16384, 192, 192, [128, 64], None),        # FP2
+    (262144, 68, 67, [64, 64, 64], None),      # FP3
+    (262144, 8, 6, [64, 64, 128], 32),         # SA of BASELINE configs[1]: SA(1024, 0.1, 32, [64,64,128])
+])
+def test_mlp_stack_at_bench_sizes(rows, ld, cin, chans, ns):
+    """the row counts, pitches and channel widths bench.py runs (other template instances, multi-chunk partial-tile reduction,
+    persistent grids than the small cases select), against the float64 restatement evaluated on the device"""
+    check_stack(rows, ld, cin, chans, ns, True, ref_device="cuda")
 
 
 def test_mlp_stack_no_bn():
