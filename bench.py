@@ -49,6 +49,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="geometry inline on the main stream instead of prefetched on a side stream")
     ap.add_argument("--no-graph", action="store_true", help="enqueue the layers kernel by kernel instead of replaying a captured hipGraph")
+    ap.add_argument("--sync-bn", action="store_true", help="optional SyncBN (global-batch statistics, SURVEY 8e): unfused layers + two small "
+                    "all-reduces per layer, no hipGraph; NOT the headline configuration")
     ap.add_argument("--no-extra", action="store_true", help="skip the post-run legs (per-kernel rooflines of the layers / ball query, other_configs)")
     args = ap.parse_args()
 
@@ -69,6 +71,9 @@ def main():
     from gspn_amd.geometry import GeometryStream
     from gspn_amd.graph import CapturedStep, copy_into
 
+    if args.sync_bn:
+        mlp_mod.SYNC_BN = True
+        args.no_graph = True                      # collectives inside the layers: not captured
     rank, local, world = parallel.init_from_env()
     if world != args.gpus:
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d): the line would report n_gpus != --gpus" % (world, args.gpus))
@@ -299,7 +304,7 @@ def main():
                                    "pn2_fea_extractor layer spec, BN training mode, Adam step", "scenes_per_gpu": SCENES_PER_GPU,
                        "schedule": "geometry inline" if args.no_overlap else ("geometry of batches k+1, k+2 on two side streams under the layers of batch k"
                                                                                + ("; fwd+bwd replayed from a hipGraph" if use_graph else "")),
-                       "global_batch": global_batch, "npoints": NPOINTS, "parallelism": "dp%d (scenes sharded, one flat RCCL grad all-reduce)" % world},
+                       "global_batch": global_batch, "npoints": NPOINTS, "parallelism": "dp%d (scenes sharded, one flat RCCL grad all-reduce)%s" % (world, "; SyncBN" if args.sync_bn else "")},
             # SURVEY 8(d)'s yardstick: `achieved` = ALGORITHMIC bytes (what the reference's kernel moves: 20 B per point per round) / time.
             # It is an effective rate, not measured bandwidth: the kernel keeps the scene on chip, `traffic` (PMC) is what really
             # crosses HBM, and what bounds the kernel is VALU issue + barrier latency -- hence us_per_pick beside it.

@@ -37,7 +37,8 @@ __device__ __forceinline__ float act1(float v, bool act, float sc, float sh) {
     return v;
 }
 
-#define MAXCH 512       // per-channel constants are staged in LDS for layers up to this many channels
+#define MAXCH GSPN_MLP_MAX_CHANNELS      // (1024) per-channel constants are staged in LDS for layers up to this many channels (the 4-level networks of
+                        // model_rpointnet.py:109,181 feed fa_layer1 with 256 + 512 = 768 input channels)
 // fill dst[0..MAXCH) with src[0..n) (or `dflt` when src is NULL / beyond n); callers __syncthreads() afterwards
 __device__ __forceinline__ void stage_chan(float* dst, const float* __restrict__ src, int n, float dflt) {
     for (int i = threadIdx.x; i < MAXCH; i += blockDim.x) dst[i] = (src && i < n) ? src[i] : dflt;

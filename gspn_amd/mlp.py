@@ -25,6 +25,12 @@ DEFER_DW = False
 FUSE_DW = os.environ.get("GSPN_FUSE_DW", "1") != "0"
 _side_streams = {}
 
+# Optional SyncBN: batch statistics over the global batch of all ranks instead of per replica -- what the single-GPU reference
+# computes.  Off by default (standard data parallelism); when on, and torch.distributed has more than one rank, training-mode
+# batch-normalised stacks run layer by layer: the GEMM kernel of the linear layer, then parallel.sync_bn_relu (two small all-reduces per
+# layer).  Slower than the fused kernels; results equal a single-process run on the concatenated batch (tests/test_cpu_dist.py).
+SYNC_BN = False
+
 # bench.py sets this to a list to collect (kind, rows, cin, cout, start_event, end_event) around every GEMM-kernel launch of the stack
 # ("fwd", "wgrad" = pass A incl. its finalize kernels, "bwd" = pass B (+ the dW reduction riding in it)); None = no events
 PROFILE = None
@@ -279,6 +285,19 @@ def mlp_linear(x, cin, lp):
     return _Linear.apply(x, cin, lp.weights, lp.biases)
 
 
+def _mlp_stack_sync_bn(x, cin, layers, decay, pool_ns):
+    """the SYNC_BN form of mlp_stack: per layer y = x.W + b on the MFMA kernel, then BN over the global batch + ReLU"""
+    from .parallel import sync_bn_relu
+    cur = x
+    for lp in layers:
+        y = _Linear.apply(cur, cin, lp.weights, lp.biases)
+        cur = sync_bn_relu(y, lp.gamma, lp.beta, lp.moving_mean, lp.moving_variance, decay, BN_EPS) if lp.bn else torch.relu(y)
+        cin = y.shape[1]
+    if pool_ns:
+        cur = cur.view(-1, pool_ns, cur.shape[1]).max(dim=1).values
+    return cur
+
+
 def mlp_stack(x, cin, layers, is_training, bn_decay, pool_ns=None, grad_cols=None):
     """x: (rows, ld>=cin) float32 on a ROCm device.  Returns (rows/pool_ns, C_last) if pool_ns else (rows, C_last).
     grad_cols = (col0, ncols): the only columns of x whose gradient the caller will read (the rest of x.grad is left undefined)."""
@@ -289,6 +308,10 @@ def mlp_stack(x, cin, layers, is_training, bn_decay, pool_ns=None, grad_cols=Non
         raise ValueError("rows must be a multiple of pool_ns")
     if grad_cols is not None and not (0 <= grad_cols[0] and grad_cols[1] > 0 and grad_cols[0] + grad_cols[1] <= cin):
         raise ValueError("grad_cols must be a column range inside [0, cin)")
+    if SYNC_BN and is_training and any(lp.bn for lp in layers):
+        import torch.distributed as dist
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            return _mlp_stack_sync_bn(x, cin, layers, 0.9 if bn_decay is None else float(bn_decay), pool_ns)
     spec = {"layers": layers, "is_training": is_training, "decay": 0.9 if bn_decay is None else float(bn_decay), "pool_ns": pool_ns,
             "grad_cols": grad_cols}
     flat = []

@@ -29,6 +29,61 @@ def shard_range(total, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+class _SyncBNReLU(torch.autograd.Function):
+    """relu(batch_norm(y)) with the batch statistics taken over ALL ranks (the reference is single-GPU, so its tf.contrib.layers.batch_norm
+    sees the global batch: tf_util.py:529-534).  Two tiny all-reduces per layer: (rows, sum y, sum y^2) forward, (sum dyh, sum dyh*xhat)
+    backward, in double.  Same arithmetic as the fused kernels: biased variance, y*inv + (beta - mean*inv), moving = moving*decay +
+    batch*(1-decay).  Pure torch, so it runs (and is tested) on CPU tensors under gloo as well."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, moving_mean, moving_var, decay, eps, relu):
+        c = y.shape[1]
+        st = torch.empty(2 * c + 1, dtype=torch.float64, device=y.device)
+        yd = y.double()
+        st[0] = y.shape[0]
+        st[1:c + 1] = yd.sum(0)
+        st[c + 1:] = (yd * yd).sum(0)
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(st, op=dist.ReduceOp.SUM)
+        rows = st[0]
+        mean = st[1:c + 1] / rows
+        var = (st[c + 1:] / rows - mean * mean).clamp_min(0.0)
+        with torch.no_grad():
+            moving_mean.mul_(decay).add_(mean.to(moving_mean.dtype) * (1.0 - decay))
+            moving_var.mul_(decay).add_(var.to(moving_var.dtype) * (1.0 - decay))
+        rstd = torch.rsqrt(var + eps)
+        inv = (rstd * gamma.double()).to(y.dtype)
+        shift = (beta.double() - mean * rstd * gamma.double()).to(y.dtype)
+        z = y * inv + shift
+        if relu:
+            z = torch.relu(z)
+        ctx.save_for_backward(y, z, gamma, mean, rstd)
+        ctx.rows, ctx.relu = float(rows), relu
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        y, z, gamma, mean, rstd = ctx.saved_tensors
+        c = y.shape[1]
+        dyh = (dz * (z > 0)) if ctx.relu else dz
+        xhat = (y.double() - mean) * rstd
+        r = torch.empty(2 * c, dtype=torch.float64, device=y.device)
+        r[:c] = dyh.double().sum(0)
+        r[c:] = (dyh.double() * xhat).sum(0)
+        dbeta, dgamma = r[:c].to(gamma.dtype), r[c:].to(gamma.dtype)     # local sums: the bucket all-reduce adds the ranks' shares
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            r = r.clone()
+            dist.all_reduce(r, op=dist.ReduceOp.SUM)
+        r0, r1 = r[:c] / ctx.rows, r[c:] / ctx.rows
+        dy = (gamma.double() * rstd) * (dyh.double() - r0 - xhat * r1)
+        return dy.to(y.dtype), dgamma, dbeta, None, None, None, None, None
+
+
+def sync_bn_relu(y, gamma, beta, moving_mean, moving_var, decay=0.9, eps=1e-3, relu=True):
+    """training-mode BN (+ReLU) of a (rows, c) matrix with statistics over the global batch of all ranks (optional SyncBN)"""
+    return _SyncBNReLU.apply(y, gamma, beta, moving_mean, moving_var, float(decay), float(eps), bool(relu))
+
+
 class FlatGradBucket:
     """Flat fp32 bucket over a fixed parameter list.  flatten(): one `cat` gathers the fresh gradients into the persistent bucket and
     every p.grad is re-pointed at its slice (views, no copies back); all_reduce(): ONE all_reduce(SUM) + scale averages the bucket

@@ -182,7 +182,10 @@ int gspn_sa_group_concat_grad_csr(int b, int n, int c, int m, int nsample, const
  *          = relu(X*in_scale+in_shift)   otherwise (per input channel: the previous layer's BN+ReLU)
  *   stats (may be NULL; gspn_mlp_fwd_stats_bytes(rows,cout) bytes, need not be zeroed): every row-block writes its own
  *   partial column sums of Y and Y^2 (no hot-spot atomics); gspn_bn_finalize adds the partials in double.
+ * Limits of this build: cin, cout <= GSPN_MLP_MAX_CHANNELS (GSPN_ERR_UNSUPPORTED beyond; the widest layer of the reference's
+ * networks has 768 input channels, model_rpointnet.py:109,181), rows < 2^31.
  */
+#define GSPN_MLP_MAX_CHANNELS 1024
 int gspn_mlp_fwd(long rows, int cin, int cout, const float* X, int ldx, const float* in_scale, const float* in_shift,
                  const float* W, const float* bias, float* Y, int ldy, float* stats, void* stream);
 /* bytes of the `stats` workspace for a (rows, cout) layer */

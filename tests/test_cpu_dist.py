@@ -51,3 +51,70 @@ def test_gloo_world2_flat_bucket_allreduce():
     mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     assert out[0][0] and out[1][0]
     assert (out[0][1], out[0][2], out[1][1], out[1][2]) == (0, 8, 8, 16)
+
+
+def _worker4(rank, world, port, out):
+    """world 4, 10 scenes -> unequal shards (3,3,2,2): a scene-weighted mean needs the SUM form with per-scene gradient sums; and the
+    optional SyncBN (global-batch statistics) must reproduce a single-process batch norm over the concatenated batch."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from gspn_amd import parallel
+    r, local, w = parallel.init_from_env(backend="gloo")
+    total = 10
+    lo, hi = parallel.shard_range(total, r, w)
+    sizes = [parallel.shard_range(total, q, w) for q in range(w)]
+    ok = [b - a for a, b in sizes] == [3, 3, 2, 2] and sizes[0][0] == 0 and sizes[-1][1] == total
+    ok = ok and all(sizes[q][1] == sizes[q + 1][0] for q in range(w - 1))
+    # SUM all-reduce of per-scene gradient SUMS, divided by the global scene count: exact global mean with unequal shards
+    p = torch.nn.Parameter(torch.zeros(5))
+    p.grad = sum((s + 1.0) * torch.ones(5) for s in range(lo, hi))
+    bk = parallel.FlatGradBucket([p])
+    bk.flatten()
+    bk.all_reduce(average=False)
+    ok = ok and torch.allclose(p.grad / total, torch.full((5,), sum(range(1, total + 1)) / total))
+    # ---- SyncBN: rows_per_scene rows per scene, c channels; reference = one process over all scenes ----
+    g = torch.Generator().manual_seed(123)
+    rows_per_scene, cin, c = 7, 4, 6
+    x_all = torch.randn(total * rows_per_scene, cin, generator=g, dtype=torch.float64)
+    wgt = torch.randn(cin, c, generator=g, dtype=torch.float64)
+    gamma0 = torch.rand(c, generator=g, dtype=torch.float64) + 0.5
+    beta0 = torch.rand(c, generator=g, dtype=torch.float64) - 0.5
+    coef = torch.randn(total * rows_per_scene, c, generator=g, dtype=torch.float64)
+
+    def run(x, co, sync):
+        x = x.clone().requires_grad_(True)
+        W = wgt.clone().requires_grad_(True)
+        ga, be = gamma0.clone().requires_grad_(True), beta0.clone().requires_grad_(True)
+        mm, mv = torch.zeros(c, dtype=torch.float64), torch.ones(c, dtype=torch.float64)
+        y = x @ W
+        if sync:
+            z = parallel.sync_bn_relu(y, ga, be, mm, mv, 0.7, 1e-3)
+        else:
+            mean = y.mean(0)
+            var = ((y - mean) ** 2).mean(0)
+            inv = torch.rsqrt(var + 1e-3) * ga
+            z = torch.relu(y * inv + (be - mean * inv))
+            mm = mm * 0.7 + mean.detach() * 0.3
+            mv = mv * 0.7 + var.detach() * 0.3
+        (z * co).sum().backward()                      # loss = SUM over rows: the ranks' losses add up to the global loss
+        return z.detach(), x.grad, W.grad, ga.grad, be.grad, mm, mv
+
+    sl = slice(lo * rows_per_scene, hi * rows_per_scene)
+    z, dx, dW, dga, dbe, mm, mv = run(x_all[sl], coef[sl], True)
+    flat = torch.cat([dW.reshape(-1), dga, dbe])
+    dist.all_reduce(flat)                              # what the gradient bucket does
+    rz, rdx, rdW, rdga, rdbe, rmm, rmv = run(x_all, coef, False)
+    ok = ok and torch.allclose(z, rz[sl], rtol=1e-10, atol=1e-12) and torch.allclose(dx, rdx[sl], rtol=1e-9, atol=1e-11)
+    ok = ok and torch.allclose(flat, torch.cat([rdW.reshape(-1), rdga, rdbe]), rtol=1e-9, atol=1e-11)
+    ok = ok and torch.allclose(mm, rmm, rtol=1e-12) and torch.allclose(mv, rmv, rtol=1e-10)
+    out[rank] = (bool(ok), lo, hi)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world4_unequal_shards_and_sync_bn():
+    world = 4
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker4, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert all(out[r][0] for r in range(world)), dict(out)
+    assert [(out[r][1], out[r][2]) for r in range(world)] == [(0, 3), (3, 6), (6, 8), (8, 10)]

@@ -119,6 +119,8 @@ def check_stack(rows, ld, cin, chans, ns, training, ref_device="cpu"):
     (1000, 67, 67, [64, 64, 64], None),    # FP3-shaped, ragged rows
     (512, 8, 5, [20], 16),                 # padded pitch, odd channel counts
     (130, 3, 3, [7, 33], 2),
+    (1024, 768, 768, [256, 256], None),    # fa_layer1 of the 4-level networks (model_rpointnet.py:109,181): 256 + 512 input channels
+    (256, 1024, 1024, [640], None),        # the widest layer this build takes (MAXCH)
 ])
 @pytest.mark.parametrize("training", [True, False])
 def test_mlp_stack_forward_backward(rows, ld, cin, chans, ns, training):
@@ -176,3 +178,24 @@ def test_mfma_layout_is_not_transposed():
     out = mlp_stack(x.cuda(), cin, [lp], False, None, None).cpu()
     ref = torch.relu(x.double() @ w.double())
     assert rel_err(out, ref) < 1e-6
+
+
+def test_sync_bn_form_equals_the_fused_stack_on_one_rank():
+    """mlp.SYNC_BN's layer-by-layer form (MFMA linear layer + parallel.sync_bn_relu) on a single rank, where the global batch IS the
+    local batch: same outputs, gradients and moving statistics as the fused kernels"""
+    from gspn_amd import mlp as M
+    g = torch.Generator().manual_seed(17)
+    rows, cin, chans, ns = 2048, 20, [32, 48], 16
+    x64 = torch.randn(rows, cin, generator=g, dtype=torch.float64)
+    res = []
+    for sync in (False, True):
+        layers = to_layers(make_params(chans, cin, seed=4))
+        x = x64.float().cuda().requires_grad_(True)
+        out = M._mlp_stack_sync_bn(x, cin, layers, 0.7, ns) if sync else M.mlp_stack(x, cin, layers, True, 0.7, pool_ns=ns)
+        out.square().sum().backward()
+        res.append((out.detach(), x.grad, [lp.weights.grad for lp in layers], [lp.gamma.grad for lp in layers], [lp.moving_variance for lp in layers]))
+    assert rel_err(res[1][0], res[0][0]) < 1e-5
+    assert rel_err(res[1][1], res[0][1]) < 1e-4
+    for k in (2, 3, 4):
+        for a, b in zip(res[1][k], res[0][k]):
+            assert rel_err(a, b) < 1e-4
