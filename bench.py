@@ -453,6 +453,22 @@ def other_configs(xyz, col, dev):
         out["configs[3] per-GPU shard"] = {"workload": "8 x 32768 pts: multi_encoding_net(256 seeds, r .5/1/1.5, ns 256/256/512, mlp [64,128,256] x3, use_xyz) + "
                                                       "Chamfer nn_distance on 2048 x (512,512) clouds, fwd+bwd, eager, geometry inline",
                                            "ms_per_step": t * 1e3, "scenes_per_s": b / t, "grouped_rows": rows, "mlp_TFLOPs_fwd_bwd_over_whole_step": gf / t / 1e12}
+        # configs[4], one GPU's shard of the SA/FP part (8 of the 64 scenes): 65536-pt scenes through pn2_fea_extractor, fwd+bwd
+        from gspn_amd.fea_extractor import pn2_fea_extractor
+        tf_util.set_variable_store(tf_util.VariableStore(device=dev, seed=4))
+        n5 = 65536
+        xyz5 = torch.from_numpy(np.stack([np.random.default_rng(5000 + i).random((n5, 3), dtype=np.float32) for i in range(b)])).to(dev)
+        col5 = torch.rand(b, n5, 3, device=dev, generator=gen)
+        st5 = {}
+
+        def c4():
+            for p_ in tf_util.get_variable_store().parameters():
+                p_.grad = None
+            o = pn2_fea_extractor(xyz5, col5, 'c4', True, 0.5)
+            o.square().mean().backward()
+        t = _time_steps(c4, 2, 5)
+        out["configs[4] per-GPU shard (SA/FP part)"] = {"workload": "8 x 65536 pts: pn2_fea_extractor 3 x SA + 3 x FP fwd+bwd, eager, geometry inline (FPS on the multi-CU kernel, "
+                                                                    "4 CUs per scene)", "ms_per_step": t * 1e3, "scenes_per_s": b / t}
     finally:
         tf_util.set_variable_store(keep)
         torch.cuda.empty_cache()

@@ -24,6 +24,11 @@ class DyArgs(_c.Structure):
                 ("scale", _P), ("shift", _P), ("cA", _P), ("cB", _P), ("cC", _P)]
 
 
+class GatherArgs(_c.Structure):
+    """mirror of struct gspn_gather_args (include/gspn_hip.h)"""
+    _fields_ = [("feat", _P), ("ldf", _I), ("c", _I), ("gidx", _P), ("rel", _P), ("xyz_first", _I)]
+
+
 # symbol -> argtypes; every entry point of include/gspn_hip.h (tests check the list against the header)
 SIGNATURES = {
     "gspn_dist_policy": [],
@@ -59,6 +64,12 @@ SIGNATURES = {
     "gspn_sa_group_concat_grad": [_I, _I, _I, _I, _I, _P, _I, _I, _P, _P, _P],
     "gspn_sa_group_concat_grad_csr": [_I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P, _P],
     "gspn_mlp_fwd": [_L, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P],
+    "gspn_mlp_fwd_pool32": [_L, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P],
+    "gspn_pool32_select": [_L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "gspn_sa_rel": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
+    "gspn_mlp_gather_cin": [_c.POINTER(GatherArgs)],
+    "gspn_mlp_fwd_gather": [_L, _c.POINTER(GatherArgs), _I, _P, _P, _P, _I, _P, _P],
+    "gspn_mlp_bwd_wgrad_gather": [_L, _c.POINTER(GatherArgs), _I, _c.POINTER(DyArgs), _P, _P, _P, _F, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "gspn_bn_finalize": [_L, _I, _P, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P],
     "gspn_bnrelu_maxpool": [_L, _I, _I, _P, _I, _P, _P, _P, _P, _P],
     "gspn_bnrelu_apply": [_L, _I, _P, _I, _P, _P, _P, _I, _P],

@@ -138,6 +138,59 @@ __device__ __forceinline__ float4 dz4_resolve(const gspn_dy_args& a, const DzRaw
     return v;
 }
 
+// ---- max-pool over groups of 32 rows folded into the forward epilogue (pointnet_util.py:123-124 with nsample = 32) -------------
+// A pool group of 32 consecutive rows is exactly one wave's 32-row MFMA tile, so the group extrema of the raw output y are taken
+// from the accumulators, before y ever leaves the registers.  BN+ReLU is monotone per channel (increasing for scale >= 0, decreasing
+// for scale < 0), hence max_k relu(scale*y_k + shift) = relu(scale*ymax + shift) resp. relu(scale*ymin + shift): once the batch
+// statistics are known a (groups x c) kernel (pool_select_kernel) finishes the pool, and the (rows x c) tensor is not read again
+// (134 MB for SA level 1 of the benchmark).  First extremum wins ties (lowest row), like the stand-alone kernel.
+struct PoolOut { float* vmax; float* vmin; int* amax; int* amin; };
+
+// acc: this lane's 16 accumulator values (+ bias applied by the caller through `bv`) of one 32x32 tile; lane l and l^32 hold the same
+// column.  Writes the column's extrema over the tile's 32 rows (lanes < 32).
+__device__ __forceinline__ void pool32_tile(const f32x16& acc, float bv, int lane, const PoolOut& po, size_t at) {
+    float mx = acc[0] + bv, mn = mx;
+    int imx = c_row(0, lane), imn = imx;
+#pragma unroll
+    for (int r = 1; r < 16; ++r) {                       // c_row(r, lane) ascends with r inside a lane: strict compares keep the first
+        const float v = acc[r] + bv;
+        const int row = c_row(r, lane);
+        if (v > mx) { mx = v; imx = row; }
+        if (v < mn) { mn = v; imn = row; }
+    }
+    const float omx = __shfl_xor(mx, 32, 64), omn = __shfl_xor(mn, 32, 64);
+    const int oimx = __shfl_xor(imx, 32, 64), oimn = __shfl_xor(imn, 32, 64);
+    if (omx > mx || (omx == mx && oimx < imx)) { mx = omx; imx = oimx; }
+    if (omn < mn || (omn == mn && oimn < imn)) { mn = omn; imn = oimn; }
+    if (lane < 32) {
+        po.vmax[at] = mx; po.vmin[at] = mn;
+        po.amax[at] = imx; po.amin[at] = imn;
+    }
+}
+
+__global__ void pool_select_kernel(long total, int c, PoolOut po, const float* __restrict__ scale, const float* __restrict__ shift,
+                                   float* __restrict__ out, int* __restrict__ arg) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int col = (int)(i % c);
+        const float sc = scale[col], sh = shift[col];
+        const bool up = sc >= 0.f;
+        float z = (up ? po.vmax[i] : po.vmin[i]) * sc + sh;          // two roundings, as every other BN application here
+        z = z > 0.f ? z : 0.f;
+        out[i] = z;
+        if (arg) arg[i] = up ? po.amax[i] : po.amin[i];
+    }
+}
+// finishes a pool the forward launch started (gspn_mlp_fwd_pool32): out (groups, c), arg (groups, c) row offset of the maximum
+extern "C" int gspn_pool32_select(long groups, int c, const float* vmax, const float* vmin, const int* amax, const int* amin,
+                                  const float* scale, const float* shift, float* out, int* arg, void* stream) {
+    if (groups < 0 || c <= 0 || !scale || !shift || !out) return GSPN_ERR_ARG;
+    const long total = groups * c;
+    if (total == 0) return 0;
+    PoolOut po{const_cast<float*>(vmax), const_cast<float*>(vmin), const_cast<int*>(amax), const_cast<int*>(amin)};
+    hipLaunchKernelGGL(pool_select_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, total, c, po, scale, shift, out, arg);
+    return gspn_launch_status();
+}
+
 // ============================================================================================
 // Forward:  Y = act(X).W + bias  (+ column sum / sumsq)
 // grid (persistent row tiles, cout tiles of BN); block 256 = 4 waves, wave w owns rows w*32..+31.
@@ -148,7 +201,7 @@ template <int BN, bool VEC>
 __global__ __launch_bounds__(256) void mlp_fwd_kernel(long rows, int cin, int cout, const float* __restrict__ X, int ldx,
                                                       const float* __restrict__ in_scale, const float* __restrict__ in_shift,
                                                       const float* __restrict__ W, const float* __restrict__ bias,
-                                                      float* __restrict__ Y, int ldy, float* __restrict__ stats) {
+                                                      float* __restrict__ Y, int ldy, float* __restrict__ stats, PoolOut po) {
     constexpr int NT = BN / 32;
     constexpr int LDB = BN + 4;
     constexpr int BQ = BN / 4;                   // float4 per B row
@@ -253,6 +306,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(long rows, int cin, int co
                 for (int nt = 0; nt < NT; ++nt) {
                     const int col = n0 + nt * 32 + (lane & 31);
                     if (col < cout) {
+                        if (po.vmax && m0 + wave * 32 < rows) pool32_tile(acc[nt], bv[nt], lane, po, (size_t)((m0 >> 5) + wave) * cout + col);   // rows % 32 == 0 (launcher)
                         float* yp = Y + (m0 + wave * 32 + 4 * (lane >> 5)) * ldy + col;
                         if (full) {
 #pragma unroll
@@ -323,11 +377,22 @@ __device__ __forceinline__ int fwd_swz_key(int row, int qx) {            // qx a
     if (qx & (qx - 1)) return 0;
     return qx >= 16 ? (row & (qx - 1)) : ((row * qx) >> 4) & (qx - 1);
 }
-template <int BN, int TRG>
+// GATHER (the first layer of a set-abstraction stack, pointnet_util.py:36-52 + :109-113 without the grouped tensor): input row r is
+// VIRTUAL -- [ feat[gidx[r]][0 .. 4*cq) | rel[r][0..4) ], the grouped point's features followed by its centred coordinates -- and every
+// LDS-DMA lane simply takes its quad from where it lives: the gather costs nothing on top of the load.  The kernel's k order is that
+// internal one; W's rows are picked accordingly while W is staged (gspn_gather_args::xyz_first says where the 3 xyz rows of W sit).
+struct GatherSrc { const float* feat; const int* gidx; const float* rel; int cq, c_real, xyz_first; };
+__device__ __forceinline__ int gather_w_row(const GatherSrc& g, int k) {           // row of the caller's W for internal k, or -1 (zero)
+    if (k < 4 * g.cq) return k < g.c_real ? (g.xyz_first ? 3 + k : k) : -1;
+    const int a = k - 4 * g.cq;
+    return a < 3 ? (g.xyz_first ? a : g.c_real + a) : -1;
+}
+template <int BN, int TRG, bool GATHER>
 __global__ __launch_bounds__(256) void mlp_fwd_stream_kernel(int rows, int cin, int cout, const float* __restrict__ X, int ldx,
                                                              const float* __restrict__ in_scale, const float* __restrict__ in_shift,
                                                              const float* __restrict__ W, const float* __restrict__ bias,
-                                                             float* __restrict__ Y, int ldy, float* __restrict__ stats, int nparts) {
+                                                             float* __restrict__ Y, int ldy, float* __restrict__ stats, int nparts, PoolOut po,
+                                                             GatherSrc gs) {
     constexpr int NT = BN / 32, CG = 4 / TRG, NTW = NT / CG, TR = 32 * TRG;
     static_assert(NT % CG == 0 && NTW >= 1, "column groups tile the block");
     constexpr int JPMAX = 8;                              // 1-KiB pieces per wave per row tile (TR * QX / 64 / 4 <= 8 by the launcher's LDS check)
@@ -348,7 +413,8 @@ __global__ __launch_bounds__(256) void mlp_fwd_stream_kernel(int rows, int cin, 
     }
     for (int f = t; f < KP * BN; f += 256) {
         const int k = f / BN, n = f - k * BN;
-        const float w = (k < cin && n0 + n < cout) ? W[(size_t)k * cout + n0 + n] : 0.f;
+        const int kw = GATHER ? gather_w_row(gs, k) : (k < cin ? k : -1);
+        const float w = (kw >= 0 && n0 + n < cout) ? W[(size_t)kw * cout + n0 + n] : 0.f;
         const int j = k >> 2, h = (k >> 1) & 1, e = k & 1;
         sW[(((j * 2 + h) * BN) + n) * 2 + e] = w;
     }
@@ -360,15 +426,32 @@ __global__ __launch_bounds__(256) void mlp_fwd_stream_kernel(int rows, int cin, 
         const int f = (wave + 4 * j) * 64 + lane;
         const int row = f / QX, slot = f - row * QX;
         p_row[j] = row;
-        p_col[j] = min((slot ^ fwd_swz_key(row, QX)) * 4, ldx - 4);
+        p_col[j] = GATHER ? (slot ^ fwd_swz_key(row, QX)) : min((slot ^ fwd_swz_key(row, QX)) * 4, ldx - 4);      // GATHER: the source QUAD
     }
+    // GATHER: source rows of the lane's pieces, fetched one tile ahead of the tile whose DMA they address (g_nxt is consumed right
+    // after the vmcnt(0) that opens an iteration, so the look-up never adds a wait of its own)
+    int g_nxt[GATHER ? JPMAX : 1];
+    auto gfetch = [&](int tile) {
+        if constexpr (GATHER) {
+            const int r0 = tile * TR;
+#pragma unroll
+            for (int j = 0; j < JPMAX; ++j) g_nxt[j] = gs.gidx[min(r0 + p_row[j], rows - 1)];
+        }
+    };
     auto issue = [&](int tile, int buf) {
         float* dst = sXb + buf * (TR * KP);
         const int r0 = tile * TR;
 #pragma unroll
         for (int j = 0; j < JPMAX; ++j)
-            if (wave + 4 * j < npiece)
-                glds16(X + ((size_t)min(r0 + p_row[j], rows - 1) * ldx + p_col[j]), dst + (wave + 4 * j) * 256);
+            if (wave + 4 * j < npiece) {
+                if constexpr (GATHER) {
+                    const float* src = p_col[j] < gs.cq ? gs.feat + ((size_t)g_nxt[j] * gs.cq + p_col[j]) * 4
+                                                        : gs.rel + (size_t)min(r0 + p_row[j], rows - 1) * 4;
+                    glds16(src, dst + (wave + 4 * j) * 256);
+                } else {
+                    glds16(X + ((size_t)min(r0 + p_row[j], rows - 1) * ldx + p_col[j]), dst + (wave + 4 * j) * 256);
+                }
+            }
     };
     float bv[NTW], csum[NTW], csq[NTW];
 #pragma unroll
@@ -387,6 +470,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_stream_kernel(int rows, int cin, 
         for (int y = 0; y < NTW; ++y) {
             const int col = n0 + (cg * NTW + y) * 32 + l31;
             if (col < cout) {
+                if (po.vmax && m0 < rows) pool32_tile(acc[y], bv[y], lane, po, (size_t)(m0 >> 5) * cout + col);      // rows % 32 == 0 (launcher)
                 float* yp = Y + (size_t)(m0 + 4 * kh) * ldy + col;
                 if (full) {
 #pragma unroll
@@ -413,11 +497,18 @@ __global__ __launch_bounds__(256) void mlp_fwd_stream_kernel(int rows, int cin, 
     };
     f32x16 acc[NTW], pacc[NTW];
     int it = 0, ptile = -1;
-    if ((int)blockIdx.x < ntiles) issue(blockIdx.x, 0);
+    if ((int)blockIdx.x < ntiles) {
+        gfetch(blockIdx.x);
+        issue(blockIdx.x, 0);
+        if ((int)(blockIdx.x + gridDim.x) < ntiles) gfetch(blockIdx.x + gridDim.x);
+    }
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                    // tile `it` has landed (and W / constants are visible the first time)
-        if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x, (it + 1) & 1);
+        if (tile + (int)gridDim.x < ntiles) {
+            issue(tile + gridDim.x, (it + 1) & 1);
+            if (tile + 2 * (int)gridDim.x < ntiles) gfetch(tile + 2 * gridDim.x);
+        }
         // the previous tile's stores go out here, a whole compute phase before the next vmcnt(0): their latency is never waited on
         if (ptile >= 0) epilogue(ptile, pacc);
         const float* sx = sXb + (it & 1) * (TR * KP) + arow * KP;
@@ -513,9 +604,11 @@ extern "C" long gspn_mlp_fwd_stats_bytes(long rows, int cout) {
 }
 static inline bool vec_ok(const void* p, int ld) { return (ld % 4 == 0) && (((uintptr_t)p) % 16 == 0); }
 
-extern "C" int gspn_mlp_fwd(long rows, int cin, int cout, const float* X, int ldx, const float* in_scale, const float* in_shift,
-                            const float* W, const float* bias, float* Y, int ldy, float* stats, void* stream) {
-    if (rows < 0 || cin <= 0 || cout <= 0 || ldx < cin || ldy < cout) return GSPN_ERR_ARG;
+static int mlp_fwd_impl(long rows, int cin, int cout, const float* X, int ldx, const float* in_scale, const float* in_shift,
+                        const float* W, const float* bias, float* Y, int ldy, float* stats, PoolOut po, void* stream,
+                        const GatherSrc* gsrc = nullptr) {
+    // gsrc: the input rows are virtual (GatherSrc); cin is then the INTERNAL width 4*cq + 4, X is unused, only the streaming kernel applies
+    if (rows < 0 || cin <= 0 || cout <= 0 || (!gsrc && ldx < cin) || ldy < cout) return GSPN_ERR_ARG;
     if ((in_scale == nullptr) != (in_shift == nullptr)) return GSPN_ERR_ARG;
     if (cin > MAXCH || cout > MAXCH) return GSPN_ERR_UNSUPPORTED;
     if (rows == 0) return 0;
@@ -531,8 +624,9 @@ extern "C" int gspn_mlp_fwd(long rows, int cin, int cout, const float* X, int ld
         else if (BNs >= 64 && lds2 + 32L * QX <= 80 * 1024) trg = 2;
         if (trg && (32 * trg * QX) % 64 != 0) trg = 0;
         if (trg && 32 * trg * QX / 64 > 32) trg = 0;                                      // <= 8 pieces per wave
-        if (trg && vec_ok(X, ldx) && ldx >= 4 && rows < (1L << 31) && rows * (long)ldx < (1L << 31) && rows * (long)ldy < (1L << 31) &&
-            getenv("GSPN_FWD_NO_STREAM") == nullptr) {
+        const bool src_ok = gsrc ? true : (vec_ok(X, ldx) && ldx >= 4 && rows * (long)ldx < (1L << 31));
+        if (gsrc && !trg) return GSPN_ERR_UNSUPPORTED;
+        if (trg && src_ok && rows < (1L << 31) && rows * (long)ldy < (1L << 31) && (gsrc || getenv("GSPN_FWD_NO_STREAM") == nullptr)) {
             const size_t dyn = (size_t)(trg == 4 ? lds4 : lds2) + 32u * QX;
             const long ntiles = (rows + 32 * trg - 1) / (32 * trg);
             long bpc = (160L * 1024) / (long)(dyn + 2 * trg * BNs * 4 + 512);
@@ -545,18 +639,23 @@ extern "C" int gspn_mlp_fwd(long rows, int cin, int cout, const float* X, int ld
             if (gx > ntiles) gx = ntiles;
             if (gx > (long)nparts) gx = nparts;
             if (gx < 1) gx = 1;
-#define FWDS_GO(BN_, TRG_)                                                                                                             \
+#define FWDS_GO1(BN_, TRG_, G_, GS_)                                                                                                  \
             do {                                                                                                                       \
                 static bool attr_done = false;                                                                                         \
                 if (!attr_done) {                                                                                                      \
-                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_stream_kernel<BN_, TRG_>),               \
+                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_stream_kernel<BN_, TRG_, G_>),           \
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                         \
                     if (e != hipSuccess) return (int)e;                                                                                \
                     attr_done = true;                                                                                                  \
                 }                                                                                                                      \
-                hipLaunchKernelGGL((mlp_fwd_stream_kernel<BN_, TRG_>), dim3((unsigned)gx, yt), dim3(256), dyn, st, (int)rows, cin, cout, X, ldx, \
-                                   in_scale, in_shift, W, bias, Y, ldy, stats, (int)nparts);                                           \
+                hipLaunchKernelGGL((mlp_fwd_stream_kernel<BN_, TRG_, G_>), dim3((unsigned)gx, yt), dim3(256), dyn, st, (int)rows, cin, cout, X, ldx, \
+                                   in_scale, in_shift, W, bias, Y, ldy, stats, (int)nparts, po, GS_);                                  \
                 return gspn_launch_status();                                                                                           \
+            } while (0)
+#define FWDS_GO(BN_, TRG_)                                                                                                             \
+            do {                                                                                                                       \
+                if (gsrc) FWDS_GO1(BN_, TRG_, true, *gsrc);                                                                            \
+                else FWDS_GO1(BN_, TRG_, false, GatherSrc{});                                                                          \
             } while (0)
             if (BNs == 32 && trg == 4) FWDS_GO(32, 4);
             if (BNs == 64 && trg == 4) FWDS_GO(64, 4);
@@ -564,12 +663,14 @@ extern "C" int gspn_mlp_fwd(long rows, int cin, int cout, const float* X, int ld
             if (BNs == 128 && trg == 4) FWDS_GO(128, 4);
             if (BNs == 128 && trg == 2) FWDS_GO(128, 2);
 #undef FWDS_GO
+#undef FWDS_GO1
         }
     }
+    if (gsrc) return GSPN_ERR_UNSUPPORTED;
     const bool v = vec_ok(X, ldx) && vec_ok(W, cout);
 #define FWD_LAUNCH(BN_, V_, YT_)                                                                                                   \
     hipLaunchKernelGGL((mlp_fwd_kernel<BN_, V_>), dim3(fwd_blocks(rows, cout), YT_), dim3(256), 0, st, rows, cin, cout, X, ldx, \
-                       in_scale, in_shift, W, bias, Y, ldy, stats)
+                       in_scale, in_shift, W, bias, Y, ldy, stats, po)
     const int bn = pick_bn(rows, cout, "GSPN_FWD_FORCE_BN");
     const int yt = (cout + bn - 1) / bn;
     if (bn == 32) { if (v) FWD_LAUNCH(32, true, yt); else FWD_LAUNCH(32, false, yt); }
@@ -577,6 +678,19 @@ extern "C" int gspn_mlp_fwd(long rows, int cin, int cout, const float* X, int ld
     else { if (v) FWD_LAUNCH(128, true, yt); else FWD_LAUNCH(128, false, yt); }
 #undef FWD_LAUNCH
     return gspn_launch_status();
+}
+extern "C" int gspn_mlp_fwd(long rows, int cin, int cout, const float* X, int ldx, const float* in_scale, const float* in_shift,
+                            const float* W, const float* bias, float* Y, int ldy, float* stats, void* stream) {
+    return mlp_fwd_impl(rows, cin, cout, X, ldx, in_scale, in_shift, W, bias, Y, ldy, stats, PoolOut{nullptr, nullptr, nullptr, nullptr}, stream);
+}
+// gspn_mlp_fwd that also leaves, per group of 32 consecutive rows and channel, the largest and the smallest raw output and their row
+// offsets (each (rows/32, cout)): the first half of the max-pool of pointnet_util.py:123-124 for nsample = 32; gspn_pool32_select is
+// the second, once the batch statistics of this layer are known.  rows must be a multiple of 32.
+extern "C" int gspn_mlp_fwd_pool32(long rows, int cin, int cout, const float* X, int ldx, const float* in_scale, const float* in_shift,
+                                   const float* W, const float* bias, float* Y, int ldy, float* stats,
+                                   float* vmax, float* vmin, int* amax, int* amin, void* stream) {
+    if (!vmax || !vmin || !amax || !amin || (rows & 31)) return GSPN_ERR_ARG;
+    return mlp_fwd_impl(rows, cin, cout, X, ldx, in_scale, in_shift, W, bias, Y, ldy, stats, PoolOut{vmax, vmin, amax, amin}, stream);
 }
 
 // ============================================================================================
@@ -911,12 +1025,15 @@ template <int MT, int NTT> struct WgradSplit {
     static constexpr int AM = MT / GM, BNW = NTT / GN;
     static_assert(MT % GM == 0 && NTT % GN == 0, "wave groups tile the block");
 };
-template <int MT, int NTT, int TKW, bool WANT_GX, bool POOLED>
+// GATHER: the A operand's rows are virtual (GatherSrc, see mlp_fwd_stream_kernel); cin is the internal width 4*cq + 4 and the partial
+// tiles / column sums come out in that internal row order (the dW reduction maps them back: DwJob::gq).
+template <int MT, int NTT, int TKW, bool WANT_GX, bool POOLED, bool GATHER = false>
 __global__ __launch_bounds__(256, ((WgradSplit<MT, NTT>::AM * WgradSplit<MT, NTT>::BNW * (WANT_GX ? 2 : 1) >= 4 || (POOLED && TKW >= 32)) ? 2 : 3)) void wgrad_stream_kernel(int rows, int cin, int cout, gspn_dy_args a, const float* __restrict__ X, int ldx,
                                                            const float* __restrict__ in_scale, const float* __restrict__ in_shift,
                                                            const float* __restrict__ mean, const float* __restrict__ var, float eps,
                                                            float* __restrict__ RP, float* __restrict__ GP, float* __restrict__ PP,
-                                                           int rows_per_chunk, int nslots, int shared, int nch, int nrow, int ncol) {
+                                                           int rows_per_chunk, int nslots, int shared, int nch, int nrow, int ncol, GatherSrc gsrc) {
+    static_assert(!(GATHER && POOLED), "the gathered layer is the first of a stack: its upstream gradient is dense");
     using SP = WgradSplit<MT, NTT>;
     constexpr int BM = 32 * MT, BN = 32 * NTT;
     constexpr int WK = SP::WK, GM = SP::GM, GN = SP::GN, AM = SP::AM, BNW = SP::BNW;
@@ -962,7 +1079,7 @@ __global__ __launch_bounds__(256, ((WgradSplit<MT, NTT>::AM * WgradSplit<MT, NTT
     for (int j = 0; j < JA; ++j) {
         const int f = (wave + 4 * j) * 64 + lane;
         a_kk[j] = f / AQ;
-        a_col[j] = min(m0 + (f - a_kk[j] * AQ) * 4, ldx - 4);
+        a_col[j] = min(m0 + (f - a_kk[j] * AQ) * 4, (GATHER ? cin : ldx) - 4);
     }
 #pragma unroll
     for (int j = 0; j < JB; ++j) {
@@ -970,16 +1087,32 @@ __global__ __launch_bounds__(256, ((WgradSplit<MT, NTT>::AM * WgradSplit<MT, NTT
         b_kk[j] = f / BQ;
         b_col[j] = min(n0 + (f - b_kk[j] * BQ) * 4, cout - 4);
     }
-    const float* Xc = X + (size_t)r_begin * ldx;
+    const float* Xc = GATHER ? nullptr : X + (size_t)r_begin * ldx;
     const float* Yc = a.Y + (size_t)r_begin * a.ldy;
     const float* Zc = POOLED ? nullptr : a.dZ + (size_t)r_begin * a.ldz;
+    // GATHER: source rows of the lane's A pieces for the NEXT stage to issue (fetched a stage ahead, consumed after the opening vmcnt(0))
+    int ga_nxt[GATHER ? JA : 1];
+    auto gfetch = [&](int s) {
+        if constexpr (GATHER) {
+            const int k0 = s * TKW;
+#pragma unroll
+            for (int j = 0; j < JA; ++j) ga_nxt[j] = gsrc.gidx[r_begin + min(k0 + a_kk[j], lrmax)];
+        }
+    };
     auto issue = [&](int s) {
         float* dst = sbuf + (s % NBUF) * SF;
         const int k0 = s * TKW;
 #pragma unroll
         for (int j = 0; j < JA; ++j) {
-            if (PA % 4 == 0 || wave + 4 * j < PA)
-                glds16(Xc + (size_t)(min(k0 + a_kk[j], lrmax) * ldx + a_col[j]), dst + (wave + 4 * j) * 256);
+            if (PA % 4 == 0 || wave + 4 * j < PA) {
+                if constexpr (GATHER) {
+                    const float* src = a_col[j] < 4 * gsrc.cq ? gsrc.feat + (size_t)ga_nxt[j] * (4 * gsrc.cq) + a_col[j]
+                                                            : gsrc.rel + (size_t)(r_begin + min(k0 + a_kk[j], lrmax)) * 4;
+                    glds16(src, dst + (wave + 4 * j) * 256);
+                } else {
+                    glds16(Xc + (size_t)(min(k0 + a_kk[j], lrmax) * ldx + a_col[j]), dst + (wave + 4 * j) * 256);
+                }
+            }
         }
 #pragma unroll
         for (int j = 0; j < JB; ++j) {
@@ -1057,8 +1190,11 @@ __global__ __launch_bounds__(256, ((WgradSplit<MT, NTT>::AM * WgradSplit<MT, NTT
 #pragma unroll
     for (int y = 0; y < BNW; ++y) r0a[y] = r1a[y] = 0.f;
 
+    static_assert(!(GATHER && NBUF == 3), "the gather look-ahead is written for two stage buffers");
     pool_fetch();
+    gfetch(0);
     issue(0);
+    if (nit > 1) gfetch(1);
     if (NBUF == 3 && nit > 1) issue(1);
     for (int s = 0; s < nit; ++s) {
         // this wave's pieces of stage s have landed (with three buffers the PPW pieces of stage s+1 may still be in flight) ...
@@ -1074,7 +1210,7 @@ __global__ __launch_bounds__(256, ((WgradSplit<MT, NTT>::AM * WgradSplit<MT, NTT
             off_cur = off_nxt;
         }
         if (NBUF == 3) { if (s + 2 < nit) issue(s + 2); }
-        else if (s + 1 < nit) { pool_fetch(); issue(s + 1); }
+        else if (s + 1 < nit) { pool_fetch(); issue(s + 1); if (s + 2 < nit) gfetch(s + 2); }
         const float* sA = buf;
         const float* sY = buf + TKW * BM;
         const float* sZ = buf + TKW * (BM + BN);
@@ -1420,6 +1556,7 @@ struct DwJob {
     float eps;
     int use_bn, is_training;
     float* dW;
+    int gq, gc_real, gxyz_first;          // gq > 0: rows of the partial tiles are in the gathered layer's internal order (GatherSrc)
 };
 // One workgroup of NTH threads = DW_OX consecutive outputs x NTH/DW_OX interleaved slot slices; sh = 2 * (NTH/64) * DW_OX doubles.
 template <int NTH>
@@ -1467,6 +1604,12 @@ __device__ __forceinline__ void wgrad_dw_block(const DwJob& j, unsigned blk, dou
     double A = 1.0;
     if (j.use_bn) A = (j.gamma ? (double)j.gamma[n] : 1.0) / sqrt((double)j.var[n] + (double)j.eps);
     if (tr) w1 -= (j.red[n] / R) * (double)j.g3[m] + (j.red[j.cout + n] / R) * wx;
+    if (j.gq > 0) {                                               // internal row m -> row of the caller's dW (padding rows have none)
+        GatherSrc g{nullptr, nullptr, nullptr, j.gq, j.gc_real, j.gxyz_first};
+        const int mo = gather_w_row(g, m);
+        if (mo >= 0) j.dW[(size_t)mo * j.cout + n] = (float)(A * w1);
+        return;
+    }
     j.dW[i] = (float)(A * w1);
 }
 __global__ __launch_bounds__(1024) void wgrad_dw_kernel(DwJob j) {
@@ -1478,6 +1621,7 @@ static DwJob dw_job(long rows, int cin, int cout, long nslots, const float* PP, 
     DwJob j;
     j.rows = rows; j.cin = cin; j.cout = cout; j.nslots = (int)nslots; j.nblk = (int)(((long)cin * cout + DW_OX - 1) / DW_OX);
     j.PP = PP; j.red = red; j.g3 = g3; j.var = var; j.gamma = gamma; j.eps = eps; j.use_bn = use_bn; j.is_training = is_training; j.dW = dW;
+    j.gq = 0; j.gc_real = 0; j.gxyz_first = 0;
     return j;
 }
 
@@ -1497,11 +1641,12 @@ static WgradPlan wgrad_choose(long rows, int cin, int cout, const gspn_dy_args* 
     return p;
 }
 
-extern "C" int gspn_mlp_bwd_wgrad(long rows, int cin, int cout, const gspn_dy_args* a, const float* X, int ldx,
-                                  const float* in_scale, const float* in_shift, const float* mean, const float* var, const float* gamma,
-                                  float eps, int use_bn, int is_training, float* work, float* cA, float* cB, float* cC,
-                                  float* dgamma, float* dbeta, float* dbias, float* dW, void* stream) {
-    if (rows <= 0 || cin <= 0 || cout <= 0 || ldx < cin || !a || !a->Y || !a->scale || !a->shift || !work) return GSPN_ERR_ARG;
+static int wgrad_impl(long rows, int cin, int cout, const gspn_dy_args* a, const float* X, int ldx,
+                      const float* in_scale, const float* in_shift, const float* mean, const float* var, const float* gamma,
+                      float eps, int use_bn, int is_training, float* work, float* cA, float* cB, float* cC,
+                      float* dgamma, float* dbeta, float* dbias, float* dW, void* stream, const GatherSrc* gsrc) {
+    // gsrc: virtual input rows (GatherSrc); cin is then the internal width 4*cq + 4 and X / ldx are unused
+    if (rows <= 0 || cin <= 0 || cout <= 0 || (!gsrc && ldx < cin) || !a || !a->Y || !a->scale || !a->shift || !work) return GSPN_ERR_ARG;
     if (!a->dZ && !(a->dPool && a->pool_arg && a->ns > 0)) return GSPN_ERR_ARG;
     if ((in_scale == nullptr) != (in_shift == nullptr)) return GSPN_ERR_ARG;
     if (use_bn && (!mean || !var)) return GSPN_ERR_ARG;
@@ -1511,7 +1656,16 @@ extern "C" int gspn_mlp_bwd_wgrad(long rows, int cin, int cout, const gspn_dy_ar
     const bool pooled = a->dZ == nullptr;
     const bool tr = use_bn && is_training;
     bool use_stream;
-    const WgradPlan p = wgrad_choose(rows, cin, cout, a, X, ldx, &use_stream);
+    WgradPlan p;
+    if (gsrc) {
+        if (pooled || !vec_ok(a->Y, a->ldy) || !vec_ok(a->dZ, a->ldz) || cout < 4) return GSPN_ERR_UNSUPPORTED;
+        p = wgrad_plan(rows, cin, cout, false, false);
+        const long ldmax = a->ldy > a->ldz ? a->ldy : a->ldz;
+        if (p.rpc * ldmax >= (1L << 31) || p.MTs != 1 || !(p.NTs == 1 || p.NTs == 2)) return GSPN_ERR_UNSUPPORTED;
+        use_stream = true;
+    } else {
+        p = wgrad_choose(rows, cin, cout, a, X, ldx, &use_stream);
+    }
     char* wb = reinterpret_cast<char*>(work);
     if (reinterpret_cast<uintptr_t>(wb) % 16) return GSPN_ERR_ARG;
     double* red = reinterpret_cast<double*>(wb);
@@ -1529,7 +1683,16 @@ extern "C" int gspn_mlp_bwd_wgrad(long rows, int cin, int cout, const gspn_dy_ar
         int launched = 0;
         const dim3 grid((unsigned)((p.nch + 7) / 8 * 8 * p.nrow * p.ncol));
 #define WS_ARGS (int)rows, cin, cout, *a, X, ldx, in_scale, in_shift, mu, vr, eps, RP, GP, PP, (int)p.rpc, (int)p.nslots, p.shared, (int)p.nch, p.nrow, p.ncol
-#define WS_GO(MT_, NT_, TKW_, G_, P_) hipLaunchKernelGGL((wgrad_stream_kernel<MT_, NT_, TKW_, G_, P_>), grid, dim3(256), 0, st, WS_ARGS)
+#define WS_GO(MT_, NT_, TKW_, G_, P_) hipLaunchKernelGGL((wgrad_stream_kernel<MT_, NT_, TKW_, G_, P_>), grid, dim3(256), 0, st, WS_ARGS, GatherSrc{})
+#define WS_GATHER(MT_, NT_, TKW_)                                                                \
+        if (!launched && gsrc && p.MTs == MT_ && p.NTs == NT_ && p.TKW == TKW_) {               \
+            if (tr) hipLaunchKernelGGL((wgrad_stream_kernel<MT_, NT_, TKW_, true, false, true>), grid, dim3(256), 0, st, WS_ARGS, *gsrc);    \
+            else hipLaunchKernelGGL((wgrad_stream_kernel<MT_, NT_, TKW_, false, false, true>), grid, dim3(256), 0, st, WS_ARGS, *gsrc);      \
+            launched = 1;                                                                       \
+        }
+        WS_GATHER(1, 1, 64) WS_GATHER(1, 2, 32)
+        if (gsrc && !launched) return GSPN_ERR_UNSUPPORTED;
+#undef WS_GATHER
 #define WS_TRY(MT_, NT_, TKW_)                                                                   \
         if (!launched && p.MTs == MT_ && p.NTs == NT_ && p.TKW == TKW_) {                       \
             if (tr) { if (pooled) WS_GO(MT_, NT_, TKW_, true, true); else WS_GO(MT_, NT_, TKW_, true, false); }     \
@@ -1558,10 +1721,71 @@ extern "C" int gspn_mlp_bwd_wgrad(long rows, int cin, int cout, const gspn_dy_ar
     hipLaunchKernelGGL(wgrad_small_reduce_kernel, dim3(cmax), dim3(256), 0, st, rows, cin, cout, (int)p.nch, RP, GP, red, g3, mean, var, gamma, eps,
                        use_bn, is_training, cA, cB, cC, dgamma, dbeta, dbias);
     if (dW) {
-        const DwJob j = dw_job(rows, cin, cout, p.nslots, PP, red, g3, var, gamma, eps, use_bn, is_training, dW);
+        DwJob j = dw_job(rows, cin, cout, p.nslots, PP, red, g3, var, gamma, eps, use_bn, is_training, dW);
+        if (gsrc) { j.gq = gsrc->cq; j.gc_real = gsrc->c_real; j.gxyz_first = gsrc->xyz_first; }
         hipLaunchKernelGGL(wgrad_dw_kernel, dim3((unsigned)j.nblk), dim3(1024), 0, st, j);
     }
     return gspn_launch_status();
+}
+extern "C" int gspn_mlp_bwd_wgrad(long rows, int cin, int cout, const gspn_dy_args* a, const float* X, int ldx,
+                                  const float* in_scale, const float* in_shift, const float* mean, const float* var, const float* gamma,
+                                  float eps, int use_bn, int is_training, float* work, float* cA, float* cB, float* cC,
+                                  float* dgamma, float* dbeta, float* dbias, float* dW, void* stream) {
+    return wgrad_impl(rows, cin, cout, a, X, ldx, in_scale, in_shift, mean, var, gamma, eps, use_bn, is_training, work, cA, cB, cC,
+                      dgamma, dbeta, dbias, dW, stream, nullptr);
+}
+
+// ============================================================================================
+// Fused set-abstraction front end (pointnet_util.py:36-52 + the first conv2d of :109-113): the grouped tensor
+// (b, npoint, nsample, 3+c) is never written.  gspn_sa_rel leaves, per grouped row, its source row and its centred coordinates
+// (20 bytes instead of 4*(3+c)); the first layer's forward GEMM and its weight-gradient pass then take every input row straight
+// from the (b, n, c) feature tensor through the LDS-DMA's per-lane addresses (GatherSrc).
+// ============================================================================================
+__global__ void sa_rel_kernel(long total, int n, int m, int ns, const float* __restrict__ xyz, const float* __restrict__ new_xyz,
+                              const int* __restrict__ idx, float* __restrict__ rel, int* __restrict__ gidx) {
+    for (long r = blockIdx.x * (long)blockDim.x + threadIdx.x; r < total; r += (long)gridDim.x * blockDim.x) {
+        const long q = r / ns;                       // (scene, query)
+        const int scene = (int)(q / m);
+        const int src = scene * n + idx[r];
+        const float* p = xyz + (size_t)src * 3;
+        const float* c = new_xyz + (size_t)q * 3;
+        *reinterpret_cast<float4*>(rel + r * 4) = make_float4(p[0] - c[0], p[1] - c[1], p[2] - c[2], 0.f);     // :41-42
+        gidx[r] = src;
+    }
+}
+extern "C" int gspn_sa_rel(int b, int n, int m, int ns, const float* xyz, const float* new_xyz, const int* idx, float* rel, int* gidx, void* stream) {
+    if (b < 0 || n <= 0 || m < 0 || ns <= 0) return GSPN_ERR_ARG;
+    const long total = (long)b * m * ns;
+    if (total == 0) return 0;
+    if (!xyz || !new_xyz || !idx || !rel || !gidx || ((uintptr_t)rel % 16)) return GSPN_ERR_ARG;
+    if ((long)b * n >= (1L << 31)) return GSPN_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(sa_rel_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, total, n, m, ns, xyz, new_xyz, idx, rel, gidx);
+    return gspn_launch_status();
+}
+static int gather_src(const gspn_gather_args* g, GatherSrc* out) {
+    if (!g || !g->feat || !g->gidx || !g->rel || g->c <= 0 || g->ldf < g->c || (g->ldf & 3)) return GSPN_ERR_ARG;
+    if (((uintptr_t)g->feat % 16) || ((uintptr_t)g->rel % 16)) return GSPN_ERR_ARG;
+    out->feat = g->feat; out->gidx = g->gidx; out->rel = g->rel;
+    out->cq = g->ldf / 4; out->c_real = g->c; out->xyz_first = g->xyz_first ? 1 : 0;
+    return 0;
+}
+extern "C" int gspn_mlp_gather_cin(const gspn_gather_args* g) { return (g && g->ldf > 0) ? g->ldf + 4 : GSPN_ERR_ARG; }
+extern "C" int gspn_mlp_fwd_gather(long rows, const gspn_gather_args* g, int cout, const float* W, const float* bias, float* Y, int ldy,
+                                   float* stats, void* stream) {
+    GatherSrc gs;
+    const int rc = gather_src(g, &gs);
+    if (rc) return rc;
+    return mlp_fwd_impl(rows, 4 * gs.cq + 4, cout, nullptr, 0, nullptr, nullptr, W, bias, Y, ldy, stats, PoolOut{nullptr, nullptr, nullptr, nullptr}, stream, &gs);
+}
+extern "C" int gspn_mlp_bwd_wgrad_gather(long rows, const gspn_gather_args* g, int cout, const gspn_dy_args* a, const float* mean, const float* var,
+                                         const float* gamma, float eps, int use_bn, int is_training, float* work, float* cA, float* cB, float* cC,
+                                         float* dgamma, float* dbeta, float* dbias, float* dW, void* stream) {
+    GatherSrc gs;
+    const int rc = gather_src(g, &gs);
+    if (rc) return rc;
+    if (!dW) return GSPN_ERR_ARG;                    // the row mapping back to the caller's dW happens in this call's reduction
+    return wgrad_impl(rows, 4 * gs.cq + 4, cout, a, nullptr, 0, nullptr, nullptr, mean, var, gamma, eps, use_bn, is_training, work, cA, cB, cC,
+                      dgamma, dbeta, dbias, dW, stream, &gs);
 }
 
 // The deferred last kernel of pass A: dW from the partial tiles / sums that gspn_mlp_bwd_wgrad(..., dW = NULL, ...) left in `work`.

@@ -26,14 +26,16 @@ from .tf_sampling import farthest_point_sample, gather_point
 class SAGeometry:
     """new_xyz (b,npoint,3), idx (b,npoint,nsample) int32, pts_cnt (b,npoint) int32 or None (knn), plus the inverse lists the gradient
     of the grouping gathers through: order (b, npoint*nsample) int32 = grouped positions sorted by data-point index, offsets (b, n+1)."""
-    __slots__ = ("new_xyz", "idx", "pts_cnt", "npoint", "nsample", "order", "offsets")
+    __slots__ = ("new_xyz", "idx", "pts_cnt", "npoint", "nsample", "order", "offsets", "rel", "gidx")
 
-    def __init__(self, new_xyz, idx, pts_cnt, npoint, nsample, order=None, offsets=None):
+    def __init__(self, new_xyz, idx, pts_cnt, npoint, nsample, order=None, offsets=None, rel=None, gidx=None):
         self.new_xyz, self.idx, self.pts_cnt, self.npoint, self.nsample = new_xyz, idx, pts_cnt, npoint, nsample
         self.order, self.offsets = order, offsets
+        # fused SA front end (gspn_sa_rel): per grouped row its centred coordinates (b*npoint*nsample, 4) and its source row (int32)
+        self.rel, self.gidx = rel, gidx
 
     def tensors(self):
-        return [t for t in (self.new_xyz, self.idx, self.pts_cnt, self.order, self.offsets) if t is not None]
+        return [t for t in (self.new_xyz, self.idx, self.pts_cnt, self.order, self.offsets, self.rel, self.gidx) if t is not None]
 
 
 def inverse_lists(idx2d, n):
@@ -61,8 +63,20 @@ class FPGeometry:
         return [t for t in (self.idx, self.weight, self.order, self.offsets) if t is not None]
 
 
-def sa_geometry(xyz, npoint, radius, nsample, knn=False, inverse=True):
-    """pointnet_util.py:38-40: centres by FPS, neighbours by ball query (or kNN)."""
+def sa_front(xyz, new_xyz, idx):
+    """pointnet_util.py:41-42 reduced to what depends on coordinates only: rel[r] = (xyz[idx[r]] - centre, 0) and the source row
+    gidx[r] of every grouped row r -- the inputs of the fused front end (gspn_mlp_fwd_gather), 20 bytes per grouped row."""
+    b, n, _ = xyz.shape
+    _, m, ns = idx.shape
+    rel = torch.empty((b * m * ns, 4), dtype=torch.float32, device=xyz.device)
+    gidx = torch.empty((b * m * ns,), dtype=torch.int32, device=xyz.device)
+    with torch.cuda.device(xyz.device):
+        L.check(L.lib().gspn_sa_rel(b, n, m, ns, L.ptr(xyz), L.ptr(new_xyz), L.ptr(idx), L.ptr(rel), L.ptr(gidx), L.stream()), "sa_rel")
+    return rel, gidx
+
+
+def sa_geometry(xyz, npoint, radius, nsample, knn=False, inverse=True, front=True):
+    """pointnet_util.py:38-40: centres by FPS, neighbours by ball query (or kNN); front: also the coordinate half of the grouping."""
     xyz = xyz.detach()
     new_xyz = gather_point(xyz, farthest_point_sample(npoint, xyz))
     if knn:
@@ -71,7 +85,8 @@ def sa_geometry(xyz, npoint, radius, nsample, knn=False, inverse=True):
     else:
         idx, cnt = query_ball_point(radius, nsample, xyz, new_xyz)
     order, offsets = inverse_lists(idx.reshape(idx.shape[0], -1), xyz.shape[1]) if inverse else (None, None)
-    return SAGeometry(new_xyz, idx, cnt, npoint, nsample, order, offsets)
+    rel, gidx = sa_front(xyz, new_xyz, idx) if front else (None, None)
+    return SAGeometry(new_xyz, idx, cnt, npoint, nsample, order, offsets, rel, gidx)
 
 
 def fp_geometry(xyz1, xyz2):

@@ -21,6 +21,9 @@ BN_EPS = 1e-3      # tf.contrib.layers.batch_norm default epsilon (tf_util.py:52
 # kernels.  Off by default: inside a captured step the fork becomes a multi-branch hipGraph, and ROCm 7.2 replays those far slower
 # than a linear graph (measured on MI355X: 3.9 -> 6.6 ms per step), which costs more than the ~0.2 ms of overlap gains.
 DEFER_DW = False
+# max-pool over nsample = 32 rows taken from the last layer's accumulators (gspn_mlp_fwd_pool32 + gspn_pool32_select) instead of a pass
+# over the (rows, c) output
+FUSE_POOL32 = os.environ.get("GSPN_FUSE_POOL32", "1") != "0"
 # one launch for pass B + the dW reduction of the same layer (gspn_mlp_bwd_data_dw) instead of two
 FUSE_DW = os.environ.get("GSPN_FUSE_DW", "1") != "0"
 _side_streams = {}
@@ -85,7 +88,14 @@ class _MlpStack(torch.autograd.Function):
         params: flat list of the differentiable tensors (w, b[, beta, gamma]) per layer, for autograd."""
         lib = L.lib()
         dev = x.device
-        rows, ld = x.shape
+        gather = spec.get("gather")              # fused SA front end: x is the (b*n, ldf) feature matrix, the GEMM rows are virtual
+        if gather is not None:
+            rows, ld = gather["rows"], 0
+            ga = L.GatherArgs(x.data_ptr(), x.shape[1], gather["c"], gather["gidx"].data_ptr(), gather["rel"].data_ptr(), int(gather["xyz_first"]))
+            ctx.gargs = ga
+            ctx.gather_x = x                     # the backward pass gathers from it again: keep the storage alive
+        else:
+            rows, ld = x.shape
         layers = spec["layers"]
         is_training = bool(spec["is_training"])
         decay = float(spec["decay"])
@@ -93,16 +103,28 @@ class _MlpStack(torch.autograd.Function):
         saved = []
         cur, cur_ld, cin = x, ld, cin0
         in_scale = in_shift = None
+        pool = None                              # (vmax, vmin, amax, amin) of the last layer when the pool rides in its forward epilogue
         with torch.cuda.device(dev):
             st = L.stream()                      # the current stream of x's device (not of whatever device was current outside)
-            for lp in layers:
+            for li, lp in enumerate(layers):
                 cout = lp.weights.shape[1]
                 y = torch.empty((rows, cout), dtype=torch.float32, device=dev)
                 use_stats = lp.bn and is_training
                 stats = torch.empty(int(lib.gspn_mlp_fwd_stats_bytes(rows, cout)) // 4, dtype=torch.float32, device=dev) if use_stats else None
                 ev = _tic()
-                L.check(lib.gspn_mlp_fwd(rows, cin, cout, L.ptr(cur), cur_ld, L.ptr(in_scale), L.ptr(in_shift),
-                                         L.ptr(lp.weights), L.ptr(lp.biases), L.ptr(y), cout, L.ptr(stats), st), "mlp_fwd")
+                if FUSE_POOL32 and pool_ns == 32 and li == len(layers) - 1 and rows % 32 == 0:
+                    g32 = rows // 32
+                    pool = (torch.empty((g32, cout), dtype=torch.float32, device=dev), torch.empty((g32, cout), dtype=torch.float32, device=dev),
+                            torch.empty((g32, cout), dtype=torch.int32, device=dev), torch.empty((g32, cout), dtype=torch.int32, device=dev))
+                    L.check(lib.gspn_mlp_fwd_pool32(rows, cin, cout, L.ptr(cur), cur_ld, L.ptr(in_scale), L.ptr(in_shift), L.ptr(lp.weights),
+                                                    L.ptr(lp.biases), L.ptr(y), cout, L.ptr(stats), L.ptr(pool[0]), L.ptr(pool[1]), L.ptr(pool[2]),
+                                                    L.ptr(pool[3]), st), "mlp_fwd_pool32")
+                elif li == 0 and gather is not None:
+                    L.check(lib.gspn_mlp_fwd_gather(rows, ctypes.byref(ga), cout, L.ptr(lp.weights), L.ptr(lp.biases), L.ptr(y), cout, L.ptr(stats), st),
+                            "mlp_fwd_gather")
+                else:
+                    L.check(lib.gspn_mlp_fwd(rows, cin, cout, L.ptr(cur), cur_ld, L.ptr(in_scale), L.ptr(in_shift),
+                                             L.ptr(lp.weights), L.ptr(lp.biases), L.ptr(y), cout, L.ptr(stats), st), "mlp_fwd")
                 _toc(ev, "fwd", rows, cin, cout)
                 mean = torch.empty(cout, dtype=torch.float32, device=dev)
                 var = torch.empty(cout, dtype=torch.float32, device=dev)
@@ -117,7 +139,7 @@ class _MlpStack(torch.autograd.Function):
                     shift.zero_()
                     mean.zero_()
                     var.fill_(1.0)
-                saved.append((cur, cur_ld, cin, in_scale, in_shift, y, mean, var, scale, shift))
+                saved.append((None if (li == 0 and gather is not None) else cur, cur_ld, cin, in_scale, in_shift, y, mean, var, scale, shift))
                 cur, cur_ld, cin, in_scale, in_shift = y, cout, cout, scale, shift
             cl = cin
             arg = None
@@ -125,11 +147,16 @@ class _MlpStack(torch.autograd.Function):
                 groups = rows // pool_ns
                 out = torch.empty((groups, cl), dtype=torch.float32, device=dev)
                 arg = torch.empty((groups, cl), dtype=torch.int32, device=dev)
-                L.check(lib.gspn_bnrelu_maxpool(groups, pool_ns, cl, L.ptr(cur), cur_ld, L.ptr(in_scale), L.ptr(in_shift),
-                                                L.ptr(out), L.ptr(arg), st), "bnrelu_maxpool")
+                if pool is not None:             # the group extrema came out of the last forward launch: finish on (groups, c) elements
+                    L.check(lib.gspn_pool32_select(groups, cl, L.ptr(pool[0]), L.ptr(pool[1]), L.ptr(pool[2]), L.ptr(pool[3]),
+                                                   L.ptr(in_scale), L.ptr(in_shift), L.ptr(out), L.ptr(arg), st), "pool32_select")
+                else:
+                    L.check(lib.gspn_bnrelu_maxpool(groups, pool_ns, cl, L.ptr(cur), cur_ld, L.ptr(in_scale), L.ptr(in_shift),
+                                                    L.ptr(out), L.ptr(arg), st), "bnrelu_maxpool")
             else:
                 out = torch.empty((rows, cl), dtype=torch.float32, device=dev)
                 L.check(lib.gspn_bnrelu_apply(rows, cl, L.ptr(cur), cur_ld, L.ptr(in_scale), L.ptr(in_shift), L.ptr(out), cl, st), "bnrelu_apply")
+        ctx.gather = gather
         ctx.saved = saved
         # backward re-reads the weights and gamma: an in-place update between forward and backward would silently change the result
         # (autograd's own check only covers save_for_backward tensors; these are kept as attributes so the layer list stays one object)
@@ -151,6 +178,7 @@ class _MlpStack(torch.autograd.Function):
         is_training = bool(spec["is_training"])
         pool_ns = spec["pool_ns"]
         rows = ctx.rows
+        gather = ctx.gather
         d_out = d_out.contiguous()
         dev = d_out.device
         grads = []
@@ -180,16 +208,24 @@ class _MlpStack(torch.autograd.Function):
                 dbeta = torch.empty(cout, dtype=torch.float32, device=dev) if lp.bn else None
                 dbias = torch.empty(cout, dtype=torch.float32, device=dev)
                 dW = torch.empty_like(lp.weights)
-                work = torch.empty(int(lib.gspn_mlp_bwd_work_bytes(rows, cin, cout)) // 4 + 4, dtype=torch.float32, device=dev)
+                gather0 = gather if li == 0 else None
+                wcin = int(lib.gspn_mlp_gather_cin(ctypes.byref(ctx.gargs))) if gather0 is not None else cin
+                work = torch.empty(int(lib.gspn_mlp_bwd_work_bytes(rows, wcin, cout)) // 4 + 4, dtype=torch.float32, device=dev)
                 has_dx = li > 0 or ctx.x_needs_grad
-                fuse_dw = FUSE_DW and has_dx and not DEFER_DW      # the dW reduction rides in spare workgroups of this layer's pass B
+                fuse_dw = FUSE_DW and has_dx and not DEFER_DW and gather0 is None     # the dW reduction rides in spare workgroups of this layer's pass B
                 ev = _tic()
-                L.check(lib.gspn_mlp_bwd_wgrad(rows, cin, cout, ctypes.byref(a), L.ptr(xin), xld, L.ptr(in_scale), L.ptr(in_shift),
-                                               L.ptr(mean), L.ptr(var), L.ptr(lp.gamma if lp.bn else None), BN_EPS, int(lp.bn), int(is_training),
-                                               L.ptr(work), L.ptr(cA), L.ptr(cB), L.ptr(cC), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dbias),
-                                               None if (DEFER_DW or fuse_dw) else L.ptr(dW), st), "mlp_bwd_wgrad")
+                if gather0 is not None:
+                    L.check(lib.gspn_mlp_bwd_wgrad_gather(rows, ctypes.byref(ctx.gargs), cout, ctypes.byref(a), L.ptr(mean), L.ptr(var),
+                                                          L.ptr(lp.gamma if lp.bn else None), BN_EPS, int(lp.bn), int(is_training), L.ptr(work),
+                                                          L.ptr(cA), L.ptr(cB), L.ptr(cC), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dbias), L.ptr(dW), st),
+                            "mlp_bwd_wgrad_gather")
+                else:
+                    L.check(lib.gspn_mlp_bwd_wgrad(rows, cin, cout, ctypes.byref(a), L.ptr(xin), xld, L.ptr(in_scale), L.ptr(in_shift),
+                                                   L.ptr(mean), L.ptr(var), L.ptr(lp.gamma if lp.bn else None), BN_EPS, int(lp.bn), int(is_training),
+                                                   L.ptr(work), L.ptr(cA), L.ptr(cB), L.ptr(cC), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dbias),
+                                                   None if (DEFER_DW or fuse_dw) else L.ptr(dW), st), "mlp_bwd_wgrad")
                 _toc(ev, "wgrad", rows, cin, cout)
-                if DEFER_DW:
+                if DEFER_DW and gather0 is None:
                     if side is None:
                         side = _side_stream(dev)
                         main = torch.cuda.current_stream()
@@ -202,7 +238,29 @@ class _MlpStack(torch.autograd.Function):
                 if lp.bn:
                     g += [dbeta, dgamma]
                 grads = g + grads
-                if has_dx:
+                if has_dx and gather0 is not None:
+                    # the gathered layer: dX of the feature columns in grouped-row layout, then the gather-form gradient of the grouping
+                    # (inverse lists; atomics without them) straight into d(features)
+                    gb, gn, gm, gns = gather0["dims"]
+                    gc, xf = gather0["c"], int(gather0["xyz_first"])
+                    ldp = (3 + gc + 3) // 4 * 4
+                    dxg = torch.empty((rows, ldp), dtype=torch.float32, device=dev)
+                    ev = _tic()
+                    L.check(lib.gspn_mlp_bwd_data_cols(rows, cin, cout, ctypes.byref(a), L.ptr(lp.weights), 3 if xf else 0, gc, L.ptr(dxg), ldp, st),
+                            "mlp_bwd_data_cols")
+                    _toc(ev, "bwd", rows, cin, cout)
+                    gp = torch.empty((gb, gn, gc), dtype=torch.float32, device=dev)
+                    if gather0.get("order") is not None:
+                        L.check(lib.gspn_sa_group_concat_grad_csr(gb, gn, gc, gm, gns, L.ptr(gather0["order"]), L.ptr(gather0["offsets"]), xf, ldp,
+                                                                  L.ptr(dxg), L.ptr(gp), st), "sa_group_concat_grad_csr")
+                    else:
+                        L.check(lib.gspn_sa_group_concat_grad(gb, gn, gc, gm, gns, L.ptr(gather0["idx"]), xf, ldp, L.ptr(dxg), L.ptr(gp), st),
+                                "sa_group_concat_grad")
+                    ldf = ctx.gargs.ldf
+                    dx0 = gp.view(gb * gn, gc)
+                    if ldf != gc:
+                        dx0 = torch.nn.functional.pad(dx0, (0, ldf - gc))
+                elif has_dx:
                     dx = torch.empty((rows, xld), dtype=torch.float32, device=dev) if li == 0 else torch.empty((rows, cin), dtype=torch.float32, device=dev)
                     if li == 0 and xld > cin and spec.get("grad_cols") is None:
                         dx.zero_()
@@ -298,13 +356,21 @@ def _mlp_stack_sync_bn(x, cin, layers, decay, pool_ns):
     return cur
 
 
-def mlp_stack(x, cin, layers, is_training, bn_decay, pool_ns=None, grad_cols=None):
+def mlp_stack(x, cin, layers, is_training, bn_decay, pool_ns=None, grad_cols=None, gather=None):
     """x: (rows, ld>=cin) float32 on a ROCm device.  Returns (rows/pool_ns, C_last) if pool_ns else (rows, C_last).
-    grad_cols = (col0, ncols): the only columns of x whose gradient the caller will read (the rest of x.grad is left undefined)."""
+    grad_cols = (col0, ncols): the only columns of x whose gradient the caller will read (the rest of x.grad is left undefined).
+    gather (fused SA front end): x is then the (b*n, ldf) FEATURE matrix and the stack's input rows are virtual --
+    dict(rows, c, xyz_first, gidx, rel, dims=(b, n, m, ns), idx, order, offsets), see pointnet_util.pointnet_sa_module; cin = 3 + c.
+    Raises NotImplementedError (before anything has run) when the first layer's shape is outside what the gathering kernels take."""
     if not layers:
         raise ValueError("mlp_stack needs at least one layer")
     x = L.need(x, torch.float32, 2, "x")
-    if pool_ns and x.shape[0] % pool_ns:
+    if gather is not None:
+        if x.shape[1] % 4 or gather["c"] > x.shape[1] or cin != 3 + gather["c"] or len(layers) < 2 or layers[0].weights.shape[1] % 4:
+            raise NotImplementedError("mlp_stack(gather=): needs 16-byte feature rows, >= 2 layers and a first layer of 4k output channels")
+        if SYNC_BN:
+            raise NotImplementedError("mlp_stack(gather=) with SYNC_BN")
+    if pool_ns and (gather["rows"] if gather is not None else x.shape[0]) % pool_ns:
         raise ValueError("rows must be a multiple of pool_ns")
     if grad_cols is not None and not (0 <= grad_cols[0] and grad_cols[1] > 0 and grad_cols[0] + grad_cols[1] <= cin):
         raise ValueError("grad_cols must be a column range inside [0, cin)")
@@ -313,7 +379,7 @@ def mlp_stack(x, cin, layers, is_training, bn_decay, pool_ns=None, grad_cols=Non
         if dist.is_initialized() and dist.get_world_size() > 1:
             return _mlp_stack_sync_bn(x, cin, layers, 0.9 if bn_decay is None else float(bn_decay), pool_ns)
     spec = {"layers": layers, "is_training": is_training, "decay": 0.9 if bn_decay is None else float(bn_decay), "pool_ns": pool_ns,
-            "grad_cols": grad_cols}
+            "grad_cols": grad_cols, "gather": gather}
     flat = []
     for lp in layers:
         flat += lp.tensors()

@@ -6,6 +6,8 @@ pointnet_sa_module / pointnet_fp_module run the fused device path: FPS -> gather
 one grouping kernel that writes concat([xyz[idx]-new_xyz, points[idx]]) straight into the MLP's
 input matrix -> MFMA MLP stack with the max-pool folded into its last layer.
 """
+import os
+
 import torch
 
 from . import _lib as L
@@ -125,6 +127,25 @@ def group_concat(xyz, new_xyz, points, idx, xyz_first=True, order=None, offsets=
     return _GroupConcat.apply(xyz, new_xyz, points, idx, xyz_first, order, offsets)
 
 
+# fused SA front end: first conv2d straight from (b, n, c) features + 20 bytes per grouped row, no (b,m,ns,3+c) tensor
+FUSE_SA_FRONT = os.environ.get("GSPN_FUSE_SA_FRONT", "1") != "0"
+
+
+def _sa_stack_gathered(points, geometry, xyz_first, cin, layers, is_training, bn_decay, nsample):
+    """the SA module's conv stack + max-pool with the first layer gathering its input rows (mlp_stack(gather=)); None when the shape is
+    outside what the gathering kernels take (the caller then materialises the grouped rows as before)"""
+    b, n, c = points.shape
+    m, ns = geometry.idx.shape[1], geometry.idx.shape[2]
+    feat = points if c % 4 == 0 else torch.nn.functional.pad(points, (0, 4 - c % 4))     # 16-byte feature rows (the pad columns are ignored)
+    feat = feat.reshape(b * n, feat.shape[2])
+    g = {"rows": b * m * ns, "c": c, "xyz_first": xyz_first, "gidx": geometry.gidx, "rel": geometry.rel, "dims": (b, n, m, ns),
+         "idx": geometry.idx, "order": geometry.order, "offsets": geometry.offsets}
+    try:
+        return mlp_stack(feat, cin, layers, bool(is_training), bn_decay, pool_ns=nsample, gather=g)
+    except NotImplementedError:
+        return None
+
+
 def sample_and_group(npoint, radius, nsample, xyz, points, tnet_spec=None, knn=False, use_xyz=True):
     """pointnet_util.py:17-54.  Returns new_xyz (b,npoint,3), new_points (b,npoint,nsample,3+c),
     idx (b,npoint,nsample), grouped_xyz (b,npoint,nsample,3)."""
@@ -184,12 +205,17 @@ def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_al
             if geometry is None:
                 geometry = sa_geometry(xyz, npoint, radius, nsample, inverse=points is not None and points.requires_grad)
             new_xyz, idx = geometry.new_xyz, geometry.idx
-            rows = group_concat(xyz, new_xyz, points, idx, True, geometry.order, geometry.offsets)      # (b*npoint*nsample, pitch >= 3+c)
             cin = 3 + (0 if points is None else points.shape[2])
             layers = _mlp_layers(mlp, cin, 'conv', bn)
-            # group_concat's gradient reads the feature columns only (xyz carries no gradient): backward skips the 3 xyz columns of dX
-            gcols = (3, cin - 3) if cin > 3 else None
-            pooled = mlp_stack(rows, cin, layers, bool(is_training), bn_decay, pool_ns=nsample, grad_cols=gcols)     # (b*npoint, mlp[-1])
+            pooled = None
+            if FUSE_SA_FRONT and points is not None and geometry.rel is not None and len(mlp) >= 2:
+                # fused front end: the grouped tensor is never written -- the first layer gathers its rows from `points` (mlp.py, gather=)
+                pooled = _sa_stack_gathered(points, geometry, True, cin, layers, is_training, bn_decay, nsample)
+            if pooled is None:
+                rows = group_concat(xyz, new_xyz, points, idx, True, geometry.order, geometry.offsets)      # (b*npoint*nsample, pitch >= 3+c)
+                # group_concat's gradient reads the feature columns only (xyz carries no gradient): backward skips the 3 xyz columns of dX
+                gcols = (3, cin - 3) if cin > 3 else None
+                pooled = mlp_stack(rows, cin, layers, bool(is_training), bn_decay, pool_ns=nsample, grad_cols=gcols)     # (b*npoint, mlp[-1])
             new_points = pooled.view(b, npoint, 1, mlp[-1])
         else:
             if group_all:

@@ -188,6 +188,15 @@ int gspn_sa_group_concat_grad_csr(int b, int n, int c, int m, int nsample, const
 #define GSPN_MLP_MAX_CHANNELS 1024
 int gspn_mlp_fwd(long rows, int cin, int cout, const float* X, int ldx, const float* in_scale, const float* in_shift,
                  const float* W, const float* bias, float* Y, int ldy, float* stats, void* stream);
+/* gspn_mlp_fwd + the first half of a max-pool over groups of 32 consecutive rows (pointnet_util.py:123-124, nsample = 32): per group
+ * and channel the largest / smallest raw output and their row offsets, taken from the accumulators (vmax, vmin, amax, amin: each
+ * (rows/32, cout)).  BN+ReLU is monotone per channel, so gspn_pool32_select finishes the pool from these once scale/shift exist:
+ * out = relu(scale*(scale >= 0 ? vmax : vmin) + shift), arg = the matching row offset -- the (rows, cout) tensor is not read again. */
+int gspn_mlp_fwd_pool32(long rows, int cin, int cout, const float* X, int ldx, const float* in_scale, const float* in_shift,
+                        const float* W, const float* bias, float* Y, int ldy, float* stats,
+                        float* vmax, float* vmin, int* amax, int* amin, void* stream);
+int gspn_pool32_select(long groups, int c, const float* vmax, const float* vmin, const int* amax, const int* amin,
+                       const float* scale, const float* shift, float* out, int* arg, void* stream);
 /* bytes of the `stats` workspace for a (rows, cout) layer */
 long gspn_mlp_fwd_stats_bytes(long rows, int cout);
 
@@ -260,6 +269,33 @@ int gspn_mlp_bwd_data_cols(long rows, int cin, int cout, const gspn_dy_args* a, 
 int gspn_mlp_bwd_data_dw(long rows, int cin, int cout, const gspn_dy_args* a, const float* W, int col0, int ncols, float* dX, int ldx,
                          const float* X, int ldx_in, const float* var, const float* gamma, float eps, int use_bn, int is_training,
                          const float* work, float* dW, void* stream);
+
+/* ---- fused set-abstraction front end: sample_and_group's concat (pointnet_util.py:36-52) + the first conv2d (:109-113)
+ * without the grouped (b, npoint, nsample, 3+c) tensor.  gspn_sa_rel writes, per grouped row r = ((i*m + j)*ns + k), its centred
+ * coordinates rel[r] = (xyz[i, idx[r]] - new_xyz[i, j], 0) and its source row gidx[r] = i*n + idx[r] (20 bytes per row).  The first
+ * layer then reads VIRTUAL input rows [ feat[gidx[r]][0..ldf) | rel[r][0..4) ] -- the LDS-DMA of the streaming kernels takes each quad
+ * from where it lives -- and W's rows are picked to match: xyz_first = 1 for W = [xyz(3); features(c)] (sample_and_group, :48),
+ * 0 for W = [features(c); xyz(3)] (multi_encoding_net, model_rpointnet.py:61).
+ *   feat: (b*n, ldf) rows, ldf % 4 == 0, ldf >= c (columns >= c are ignored), 16-byte aligned.
+ * gspn_mlp_fwd_gather / gspn_mlp_bwd_wgrad_gather are gspn_mlp_fwd / gspn_mlp_bwd_wgrad for such a first layer (no input activation);
+ * they return GSPN_ERR_UNSUPPORTED for shapes the streaming kernels do not take (the caller then materialises the rows with
+ * gspn_sa_group_concat).  Workspace of the backward call: gspn_mlp_bwd_work_bytes(rows, gspn_mlp_gather_cin(g), cout).
+ * Pass B of that layer is the ordinary gspn_mlp_bwd_data_cols (it does not read the layer's input). */
+typedef struct gspn_gather_args {
+    const float* feat;
+    int ldf;
+    int c;
+    const int* gidx;
+    const float* rel;
+    int xyz_first;
+} gspn_gather_args;
+int gspn_sa_rel(int b, int n, int m, int ns, const float* xyz, const float* new_xyz, const int* idx, float* rel, int* gidx, void* stream);
+int gspn_mlp_gather_cin(const gspn_gather_args* g);
+int gspn_mlp_fwd_gather(long rows, const gspn_gather_args* g, int cout, const float* W, const float* bias, float* Y, int ldy,
+                        float* stats, void* stream);
+int gspn_mlp_bwd_wgrad_gather(long rows, const gspn_gather_args* g, int cout, const gspn_dy_args* a, const float* mean, const float* var,
+                              const float* gamma, float eps, int use_bn, int is_training, float* work, float* cA, float* cB, float* cC,
+                              float* dgamma, float* dbeta, float* dbias, float* dW, void* stream);
 
 /* Inverse lists (CSR) of an index tensor -- what the gather-form gradients walk.  idx (b,L) int32 with values in [0,n):
  * order (b,L) = positions 0..L-1 grouped by value, ascending inside a group; offsets (b,n+1) = start of every group (offsets[n] = L).

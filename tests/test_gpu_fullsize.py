@@ -230,3 +230,36 @@ def test_fea_extractor_full_size_forward_backward(scenes):
         up = _ref_layers(store, 'fea/fa_layer%d' % (k + 1), names, torch.cat([interp, feats[dl]], -1), dev)
     err = float((got[0].double() - up).abs().max() / up.abs().max())
     assert err < 1e-5, err
+
+
+def test_config5_scene_size_through_the_extractor():
+    """BASELINE configs[4]'s per-GPU shard: 8 scenes x 65536 points through pn2_fea_extractor, forward + backward.  FPS takes the
+    multi-CU kernel (one scene no longer fits a CU); every index equals the oracle's; the step is finite and bit-reproducible."""
+    from gspn_amd import tf_util
+    from gspn_amd.fea_extractor import PN2_SA_SPEC, pn2_fea_extractor, pn2_geometry
+    b, n = 8, 65536
+    xyz = D.batch("U", b, n, 300)
+    t = torch.from_numpy(xyz).cuda()
+    col = torch.rand(b, n, 3, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
+    geo = pn2_geometry(t)
+    cur, levels = xyz, [xyz]
+    for lvl, (npoint, radius, ns) in enumerate(PN2_SA_SPEC):
+        new = O.gather_point(cur, O.farthest_point_sample(npoint, cur, mt=True))
+        ridx, _ = O.query_ball_point(radius, ns, cur, new, mt=True)
+        np.testing.assert_array_equal(geo["sa"][lvl].new_xyz.cpu().numpy(), new)
+        np.testing.assert_array_equal(geo["sa"][lvl].idx.cpu().numpy(), ridx)
+        cur = new
+        levels.append(new)
+    rd, ri = O.three_nn(levels[0][:1], levels[1][:1])               # the 65536 <- 2048 level, one scene (single-threaded oracle)
+    np.testing.assert_array_equal(geo["fp"][2].idx[:1].cpu().numpy(), ri)
+    runs = []
+    for _ in range(2):
+        store = tf_util.set_variable_store(tf_util.VariableStore(seed=8))
+        out = pn2_fea_extractor(t, col, 'fea', True, 0.5, geometry=geo)
+        assert out.shape == (b, n, 64)
+        out.square().mean().backward()
+        torch.cuda.synchronize()
+        runs.append((out.detach().clone(), {nm: p.grad.detach().clone() for nm, p in store.named_parameters()}))
+    assert torch.isfinite(runs[0][0]).all() and torch.equal(runs[0][0], runs[1][0])
+    for nm, g in runs[0][1].items():
+        assert torch.isfinite(g).all() and torch.equal(g, runs[1][1][nm]), nm

@@ -199,3 +199,29 @@ def test_sync_bn_form_equals_the_fused_stack_on_one_rank():
     for k in (2, 3, 4):
         for a, b in zip(res[1][k], res[0][k]):
             assert rel_err(a, b) < 1e-4
+
+
+@pytest.mark.parametrize("rows,cin,chans", [(4096, 32, [64]), (2048 + 32, 67, [64, 128]), (1024, 131, [128, 256]), (96, 6, [32, 32, 64])])
+def test_pool_in_the_forward_epilogue_equals_the_pool_kernel(rows, cin, chans, monkeypatch):
+    """nsample = 32: the max-pool taken from the accumulators (+ gspn_pool32_select) returns the same pooled values, bit for bit, as
+    the stand-alone bnrelu_maxpool pass over the (rows, c) tensor, and an arg-max that selects the same value; negative BN scales take
+    the group MINIMUM of the raw output (BN+ReLU decreasing in y)"""
+    from gspn_amd import mlp as M
+    g = torch.Generator().manual_seed(rows)
+    ld = (cin + 3) // 4 * 4
+    x = torch.randn(rows, ld, generator=g)
+    x[:, cin:] = 0
+    outs = []
+    for fuse in (False, True):
+        monkeypatch.setattr(M, "FUSE_POOL32", fuse)
+        ps = make_params(chans, cin, seed=3)
+        ps[-1]["gamma"][::3] *= -1.0                      # every third channel of the pooled layer: negative scale
+        layers = to_layers(ps)
+        xx = x.cuda().requires_grad_(True)
+        out = M.mlp_stack(xx, cin, layers, True, 0.7, pool_ns=32)
+        out.square().sum().backward()
+        outs.append((out.detach().clone(), xx.grad.clone(), [lp.weights.grad.clone() for lp in layers]))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert rel_err(outs[1][1], outs[0][1]) < 1e-6          # equal unless two rows of a group tie exactly (then either is a valid arg-max)
+    for a, b in zip(outs[1][2], outs[0][2]):
+        assert rel_err(a, b) < 1e-6

@@ -208,3 +208,42 @@ def test_three_nn_metre_scale_rooms(n, m, offset):
     rd, ri = O.three_nn(xyz1, xyz2)
     np.testing.assert_array_equal(i.cpu().numpy(), ri)
     np.testing.assert_array_equal(d.cpu().numpy(), rd)
+
+
+@pytest.mark.parametrize("kind,b,n,c,npoint,radius,ns,mlp,expect_gather", [
+    ("U", 2, 4096, 3, 512, 0.2, 32, [32, 32, 64], True),         # SA1-shaped: 3 colour channels, padded to a 16-byte feature row
+    ("D", 2, 2048, 64, 256, 0.4, 32, [64, 64, 128], True),       # SA2-shaped
+    ("U", 3, 1500, 8, 100, 0.3, 16, [32, 48], True),
+    ("U", 2, 1024, 20, 64, 0.3, 32, [64, 32], True),
+    ("U", 2, 512, 128, 64, 0.8, 32, [128, 128, 256], False),     # SA3-shaped: 132 input columns do not fit the streaming forward -> materialised rows
+])
+def test_fused_sa_front_end_equals_the_materialised_path(kind, b, n, c, npoint, radius, ns, mlp, expect_gather, monkeypatch):
+    """the first conv2d gathers its rows from (b,n,c) features + 20 bytes per grouped row (gspn_sa_rel) instead of reading
+    a (b,npoint,nsample,3+c) tensor.  Same module output and gradients as the materialised path to fp32 rounding (the k order of the
+    first GEMM differs: features first), and both against the float64 composition on oracle geometry."""
+    from gspn_amd import pointnet_util as PU
+    from gspn_amd.geometry import sa_geometry
+    xyz = D.batch(kind, b, n, 6)
+    pts = np.random.default_rng(12).standard_normal((b, n, c)).astype(np.float32)
+    tx = dev(xyz)
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(PU, "FUSE_SA_FRONT", fused)
+        store = fresh_store(55)
+        tp = dev(pts).requires_grad_(True)
+        if fused:       # the gathering kernels must really take this shape (or really decline it)
+            geo = sa_geometry(tx, npoint, radius, ns)
+            layers = PU._mlp_layers(mlp, 3 + c, 'probe', True)
+            got = PU._sa_stack_gathered(tp.detach(), geo, True, 3 + c, layers, True, 0.5, ns)
+            assert (got is not None) == expect_gather
+            store = fresh_store(55)
+        new_xyz, new_points, idx = PU.pointnet_sa_module(tx, tp, npoint, radius, ns, mlp, None, False, True, 0.5, 'sa')
+        g = torch.from_numpy(np.random.default_rng(5).standard_normal(tuple(new_points.shape)).astype(np.float32)).cuda()
+        new_points.backward(g)
+        res[fused] = (new_points.detach(), tp.grad.clone(), {k: v.grad.clone() for k, v in store.named_parameters()}, store)
+    assert rel_err(res[True][0], res[False][0]) < 2e-6
+    assert rel_err(res[True][1], res[False][1]) < 1e-5
+    for k in res[True][2]:
+        assert rel_err(res[True][2][k], res[False][2][k]) < 1e-5, k
+    rnew, ref, ridx, leaves = ref_sa(res[True][3], 'sa', xyz, pts, npoint, radius, ns, mlp, None, False, 'max', False, True, 0.5)
+    assert rel_err(res[True][0], ref) < 1e-5
