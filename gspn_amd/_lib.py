@@ -64,8 +64,8 @@ SIGNATURES = {
     "gspn_sa_group_concat_grad": [_I, _I, _I, _I, _I, _P, _I, _I, _P, _P, _P],
     "gspn_sa_group_concat_grad_csr": [_I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P, _P],
     "gspn_mlp_fwd": [_L, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P],
-    "gspn_mlp_fwd_pool32": [_L, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P],
-    "gspn_pool32_select": [_L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "gspn_mlp_fwd_pool32": [_L, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P],
+    "gspn_pool32_select": [_L, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P],
     "gspn_sa_rel": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "gspn_mlp_gather_cin": [_c.POINTER(GatherArgs)],
     "gspn_mlp_fwd_gather": [_L, _c.POINTER(GatherArgs), _I, _P, _P, _P, _I, _P, _P],

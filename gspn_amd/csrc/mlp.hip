@@ -143,51 +143,62 @@ __device__ __forceinline__ float4 dz4_resolve(const gspn_dy_args& a, const DzRaw
 // from the accumulators, before y ever leaves the registers.  BN+ReLU is monotone per channel (increasing for scale >= 0, decreasing
 // for scale < 0), hence max_k relu(scale*y_k + shift) = relu(scale*ymax + shift) resp. relu(scale*ymin + shift): once the batch
 // statistics are known a (groups x c) kernel (pool_select_kernel) finishes the pool, and the (rows x c) tensor is not read again
-// (134 MB for SA level 1 of the benchmark).  First extremum wins ties (lowest row), like the stand-alone kernel.
-struct PoolOut { float* vmax; float* vmin; int* amax; int* amin; };
+// (134 MB for SA level 1 of the benchmark).  The first maximum wins ties (lowest row), like the stand-alone kernel.  Only the maximum
+// is kept: channels with a negative scale are finished from Y itself (pool_select_kernel).
+struct PoolOut { float* vmax; int* amax; };
 
-// acc: this lane's 16 accumulator values (+ bias applied by the caller through `bv`) of one 32x32 tile; lane l and l^32 hold the same
-// column.  Writes the column's extrema over the tile's 32 rows (lanes < 32).
+// acc: this lane's 16 accumulator values of one 32x32 tile (bias `bv` still to be added); lane l and l^32 hold the same column.
+// Writes the column's maximum over the tile's 32 rows and the row it is first reached in (lanes < 32).  VALU work is not hidden under
+// the MFMAs on this chip, so: one max3 tree for the value, then the first register that equals it (c_row ascends with the register
+// index inside a lane), then one exchange with the other half-wave.
 __device__ __forceinline__ void pool32_tile(const f32x16& acc, float bv, int lane, const PoolOut& po, size_t at) {
-    float mx = acc[0] + bv, mn = mx;
-    int imx = c_row(0, lane), imn = imx;
+    float v[16];
 #pragma unroll
-    for (int r = 1; r < 16; ++r) {                       // c_row(r, lane) ascends with r inside a lane: strict compares keep the first
-        const float v = acc[r] + bv;
-        const int row = c_row(r, lane);
-        if (v > mx) { mx = v; imx = row; }
-        if (v < mn) { mn = v; imn = row; }
-    }
-    const float omx = __shfl_xor(mx, 32, 64), omn = __shfl_xor(mn, 32, 64);
-    const int oimx = __shfl_xor(imx, 32, 64), oimn = __shfl_xor(imn, 32, 64);
+    for (int r = 0; r < 16; ++r) v[r] = acc[r] + bv;
+    float mx = __builtin_fmaxf(__builtin_fmaxf(v[0], v[1]), v[2]);
+#pragma unroll
+    for (int r = 3; r < 15; r += 2) mx = __builtin_fmaxf(__builtin_fmaxf(mx, v[r]), v[r + 1]);
+    mx = __builtin_fmaxf(mx, v[15]);
+    int ir = 15;
+#pragma unroll
+    for (int r = 14; r >= 0; --r) ir = v[r] == mx ? r : ir;
+    int imx = c_row(ir, lane);
+    const float omx = __shfl_xor(mx, 32, 64);
+    const int oimx = __shfl_xor(imx, 32, 64);
     if (omx > mx || (omx == mx && oimx < imx)) { mx = omx; imx = oimx; }
-    if (omn < mn || (omn == mn && oimn < imn)) { mn = omn; imn = oimn; }
-    if (lane < 32) {
-        po.vmax[at] = mx; po.vmin[at] = mn;
-        po.amax[at] = imx; po.amin[at] = imn;
-    }
+    if (lane < 32) { po.vmax[at] = mx; po.amax[at] = imx; }
 }
 
-__global__ void pool_select_kernel(long total, int c, PoolOut po, const float* __restrict__ scale, const float* __restrict__ shift,
-                                   float* __restrict__ out, int* __restrict__ arg) {
+// out = relu(scale * max_k y_k + shift) for scale >= 0 (BN+ReLU increasing in y).  A channel with a NEGATIVE scale (gamma < 0: legal,
+// rare) needs the group's minimum instead, which the forward epilogue does not keep: those (group, channel) pairs re-read their 32
+// values of Y here.
+__global__ void pool_select_kernel(long total, int c, PoolOut po, const float* __restrict__ Y, int ldy, const float* __restrict__ scale,
+                                   const float* __restrict__ shift, float* __restrict__ out, int* __restrict__ arg) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int col = (int)(i % c);
+        const long g = i / c;
+        const int col = (int)(i - g * c);
         const float sc = scale[col], sh = shift[col];
-        const bool up = sc >= 0.f;
-        float z = (up ? po.vmax[i] : po.vmin[i]) * sc + sh;          // two roundings, as every other BN application here
+        float y = po.vmax[i];
+        int a = po.amax[i];
+        if (sc < 0.f) {
+            const float* p = Y + g * 32 * ldy + col;
+            y = p[0]; a = 0;
+            for (int k = 1; k < 32; ++k) { const float t = p[(size_t)k * ldy]; if (t < y) { y = t; a = k; } }
+        }
+        float z = y * sc + sh;                                       // two roundings, as every other BN application here
         z = z > 0.f ? z : 0.f;
         out[i] = z;
-        if (arg) arg[i] = up ? po.amax[i] : po.amin[i];
+        if (arg) arg[i] = a;
     }
 }
 // finishes a pool the forward launch started (gspn_mlp_fwd_pool32): out (groups, c), arg (groups, c) row offset of the maximum
-extern "C" int gspn_pool32_select(long groups, int c, const float* vmax, const float* vmin, const int* amax, const int* amin,
+extern "C" int gspn_pool32_select(long groups, int c, const float* vmax, const int* amax, const float* Y, int ldy,
                                   const float* scale, const float* shift, float* out, int* arg, void* stream) {
-    if (groups < 0 || c <= 0 || !scale || !shift || !out) return GSPN_ERR_ARG;
+    if (groups < 0 || c <= 0 || !scale || !shift || !out || !Y || ldy < c) return GSPN_ERR_ARG;
     const long total = groups * c;
     if (total == 0) return 0;
-    PoolOut po{const_cast<float*>(vmax), const_cast<float*>(vmin), const_cast<int*>(amax), const_cast<int*>(amin)};
-    hipLaunchKernelGGL(pool_select_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, total, c, po, scale, shift, out, arg);
+    PoolOut po{const_cast<float*>(vmax), const_cast<int*>(amax)};
+    hipLaunchKernelGGL(pool_select_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, total, c, po, Y, ldy, scale, shift, out, arg);
     return gspn_launch_status();
 }
 
@@ -497,17 +508,27 @@ __global__ __launch_bounds__(256) void mlp_fwd_stream_kernel(int rows, int cin, 
     };
     f32x16 acc[NTW], pacc[NTW];
     int it = 0, ptile = -1;
-    if ((int)blockIdx.x < ntiles) {
-        gfetch(blockIdx.x);
-        issue(blockIdx.x, 0);
-        if ((int)(blockIdx.x + gridDim.x) < ntiles) gfetch(blockIdx.x + gridDim.x);
+    // tiles of this workgroup: strided over the grid, or (GATHER) a contiguous run placed so that the workgroups of one XCD (block % 8)
+    // cover one contiguous eighth of the rows -- the feature rows they gather then belong to one or two scenes and stay in that XCD's L2
+    int tile0 = blockIdx.x, tstep = gridDim.x, tend = ntiles;
+    if (GATHER && (gridDim.x & 7) == 0) {
+        const int per = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+        const int cid = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+        tile0 = cid * per;
+        tstep = 1;
+        tend = min(ntiles, tile0 + per);
     }
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
+    if (tile0 < tend) {
+        gfetch(tile0);
+        issue(tile0, 0);
+        if (tile0 + tstep < tend) gfetch(tile0 + tstep);
+    }
+    for (int tile = tile0; tile < tend; tile += tstep, ++it) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                    // tile `it` has landed (and W / constants are visible the first time)
-        if (tile + (int)gridDim.x < ntiles) {
-            issue(tile + gridDim.x, (it + 1) & 1);
-            if (tile + 2 * (int)gridDim.x < ntiles) gfetch(tile + 2 * gridDim.x);
+        if (tile + tstep < tend) {
+            issue(tile + tstep, (it + 1) & 1);
+            if (tile + 2 * tstep < tend) gfetch(tile + 2 * tstep);
         }
         // the previous tile's stores go out here, a whole compute phase before the next vmcnt(0): their latency is never waited on
         if (ptile >= 0) epilogue(ptile, pacc);
@@ -681,16 +702,15 @@ static int mlp_fwd_impl(long rows, int cin, int cout, const float* X, int ldx, c
 }
 extern "C" int gspn_mlp_fwd(long rows, int cin, int cout, const float* X, int ldx, const float* in_scale, const float* in_shift,
                             const float* W, const float* bias, float* Y, int ldy, float* stats, void* stream) {
-    return mlp_fwd_impl(rows, cin, cout, X, ldx, in_scale, in_shift, W, bias, Y, ldy, stats, PoolOut{nullptr, nullptr, nullptr, nullptr}, stream);
+    return mlp_fwd_impl(rows, cin, cout, X, ldx, in_scale, in_shift, W, bias, Y, ldy, stats, PoolOut{nullptr, nullptr}, stream);
 }
-// gspn_mlp_fwd that also leaves, per group of 32 consecutive rows and channel, the largest and the smallest raw output and their row
-// offsets (each (rows/32, cout)): the first half of the max-pool of pointnet_util.py:123-124 for nsample = 32; gspn_pool32_select is
-// the second, once the batch statistics of this layer are known.  rows must be a multiple of 32.
+// gspn_mlp_fwd that also leaves, per group of 32 consecutive rows and channel, the largest raw output and its row offset (each
+// (rows/32, cout)): the first half of the max-pool of pointnet_util.py:123-124 for nsample = 32; gspn_pool32_select is the second, once
+// the batch statistics of this layer are known.  rows must be a multiple of 32.
 extern "C" int gspn_mlp_fwd_pool32(long rows, int cin, int cout, const float* X, int ldx, const float* in_scale, const float* in_shift,
-                                   const float* W, const float* bias, float* Y, int ldy, float* stats,
-                                   float* vmax, float* vmin, int* amax, int* amin, void* stream) {
-    if (!vmax || !vmin || !amax || !amin || (rows & 31)) return GSPN_ERR_ARG;
-    return mlp_fwd_impl(rows, cin, cout, X, ldx, in_scale, in_shift, W, bias, Y, ldy, stats, PoolOut{vmax, vmin, amax, amin}, stream);
+                                   const float* W, const float* bias, float* Y, int ldy, float* stats, float* vmax, int* amax, void* stream) {
+    if (!vmax || !amax || (rows & 31)) return GSPN_ERR_ARG;
+    return mlp_fwd_impl(rows, cin, cout, X, ldx, in_scale, in_shift, W, bias, Y, ldy, stats, PoolOut{vmax, amax}, stream);
 }
 
 // ============================================================================================
@@ -769,13 +789,54 @@ __global__ void bnrelu_maxpool_kernel(long total, int ns, int c, const float* __
         if (arg) arg[i] = bi;
     }
 }
+// same, four channels per thread (c, ldy multiples of 4, 16-byte rows) and eight row loads in flight: the scalar kernel above is
+// latency-bound (1.6 TB/s on the 134 MB of SA level 1)
+__global__ void bnrelu_maxpool4_kernel(long total4, int ns, int c4, const float* __restrict__ Y, int ldy, const float* __restrict__ scale,
+                                       const float* __restrict__ shift, float* __restrict__ out, int* __restrict__ arg) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+        const long g = i / c4;
+        const int col = (int)(i - g * c4) * 4;
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (scale) { sc = *reinterpret_cast<const float4*>(scale + col); sh = *reinterpret_cast<const float4*>(shift + col); }
+        const float* p = Y + g * ns * ldy + col;
+        float4 best = make_float4(0.f, 0.f, 0.f, 0.f);
+        int4 bi = make_int4(0, 0, 0, 0);
+        for (int k0 = 0; k0 < ns; k0 += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(p + (size_t)min(k0 + u, ns - 1) * ldy);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + u;
+                if (k < ns) {
+                    float4 z = v[u];
+                    if (scale) {
+                        z.x = z.x * sc.x + sh.x; z.x = z.x > 0.f ? z.x : 0.f;
+                        z.y = z.y * sc.y + sh.y; z.y = z.y > 0.f ? z.y : 0.f;
+                        z.z = z.z * sc.z + sh.z; z.z = z.z > 0.f ? z.z : 0.f;
+                        z.w = z.w * sc.w + sh.w; z.w = z.w > 0.f ? z.w : 0.f;
+                    }
+                    if (k == 0 || z.x > best.x) { best.x = z.x; bi.x = k; }
+                    if (k == 0 || z.y > best.y) { best.y = z.y; bi.y = k; }
+                    if (k == 0 || z.z > best.z) { best.z = z.z; bi.z = k; }
+                    if (k == 0 || z.w > best.w) { best.w = z.w; bi.w = k; }
+                }
+            }
+        }
+        *reinterpret_cast<float4*>(out + g * (4L * c4) + col) = best;
+        if (arg) *reinterpret_cast<int4*>(arg + g * (4L * c4) + col) = bi;
+    }
+}
 extern "C" int gspn_bnrelu_maxpool(long groups, int ns, int c, const float* Y, int ldy, const float* scale, const float* shift,
                                    float* out, int* arg, void* stream) {
     if (groups < 0 || ns <= 0 || c <= 0 || ldy < c) return GSPN_ERR_ARG;
     if ((scale == nullptr) != (shift == nullptr)) return GSPN_ERR_ARG;
     const long total = groups * c;
     if (total == 0) return 0;
-    hipLaunchKernelGGL(bnrelu_maxpool_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, total, ns, c, Y, ldy, scale, shift, out, arg);
+    const bool v4 = (c % 4 == 0) && (ldy % 4 == 0) && ((uintptr_t)Y % 16 == 0) && ((uintptr_t)out % 16 == 0) && (!arg || (uintptr_t)arg % 16 == 0) &&
+                    (!scale || ((uintptr_t)scale % 16 == 0 && (uintptr_t)shift % 16 == 0));
+    if (v4) hipLaunchKernelGGL(bnrelu_maxpool4_kernel, dim3(grid_for(total / 4, 256)), dim3(256), 0, (hipStream_t)stream, total / 4, ns, c / 4, Y, ldy, scale, shift, out, arg);
+    else hipLaunchKernelGGL(bnrelu_maxpool_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, total, ns, c, Y, ldy, scale, shift, out, arg);
     return gspn_launch_status();
 }
 __global__ void bnrelu_apply_kernel(long total, int c, const float* __restrict__ Y, int ldy, const float* __restrict__ scale,
@@ -1775,7 +1836,7 @@ extern "C" int gspn_mlp_fwd_gather(long rows, const gspn_gather_args* g, int cou
     GatherSrc gs;
     const int rc = gather_src(g, &gs);
     if (rc) return rc;
-    return mlp_fwd_impl(rows, 4 * gs.cq + 4, cout, nullptr, 0, nullptr, nullptr, W, bias, Y, ldy, stats, PoolOut{nullptr, nullptr, nullptr, nullptr}, stream, &gs);
+    return mlp_fwd_impl(rows, 4 * gs.cq + 4, cout, nullptr, 0, nullptr, nullptr, W, bias, Y, ldy, stats, PoolOut{nullptr, nullptr}, stream, &gs);
 }
 extern "C" int gspn_mlp_bwd_wgrad_gather(long rows, const gspn_gather_args* g, int cout, const gspn_dy_args* a, const float* mean, const float* var,
                                          const float* gamma, float eps, int use_bn, int is_training, float* work, float* cA, float* cB, float* cC,

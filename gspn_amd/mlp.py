@@ -103,7 +103,7 @@ class _MlpStack(torch.autograd.Function):
         saved = []
         cur, cur_ld, cin = x, ld, cin0
         in_scale = in_shift = None
-        pool = None                              # (vmax, vmin, amax, amin) of the last layer when the pool rides in its forward epilogue
+        pool = None                              # (vmax, amax) of the last layer when the pool rides in its forward epilogue
         with torch.cuda.device(dev):
             st = L.stream()                      # the current stream of x's device (not of whatever device was current outside)
             for li, lp in enumerate(layers):
@@ -114,11 +114,10 @@ class _MlpStack(torch.autograd.Function):
                 ev = _tic()
                 if FUSE_POOL32 and pool_ns == 32 and li == len(layers) - 1 and rows % 32 == 0:
                     g32 = rows // 32
-                    pool = (torch.empty((g32, cout), dtype=torch.float32, device=dev), torch.empty((g32, cout), dtype=torch.float32, device=dev),
-                            torch.empty((g32, cout), dtype=torch.int32, device=dev), torch.empty((g32, cout), dtype=torch.int32, device=dev))
+                    pool = (torch.empty((g32, cout), dtype=torch.float32, device=dev), torch.empty((g32, cout), dtype=torch.int32, device=dev))
                     L.check(lib.gspn_mlp_fwd_pool32(rows, cin, cout, L.ptr(cur), cur_ld, L.ptr(in_scale), L.ptr(in_shift), L.ptr(lp.weights),
-                                                    L.ptr(lp.biases), L.ptr(y), cout, L.ptr(stats), L.ptr(pool[0]), L.ptr(pool[1]), L.ptr(pool[2]),
-                                                    L.ptr(pool[3]), st), "mlp_fwd_pool32")
+                                                    L.ptr(lp.biases), L.ptr(y), cout, L.ptr(stats), L.ptr(pool[0]), L.ptr(pool[1]), st),
+                            "mlp_fwd_pool32")
                 elif li == 0 and gather is not None:
                     L.check(lib.gspn_mlp_fwd_gather(rows, ctypes.byref(ga), cout, L.ptr(lp.weights), L.ptr(lp.biases), L.ptr(y), cout, L.ptr(stats), st),
                             "mlp_fwd_gather")
@@ -148,7 +147,7 @@ class _MlpStack(torch.autograd.Function):
                 out = torch.empty((groups, cl), dtype=torch.float32, device=dev)
                 arg = torch.empty((groups, cl), dtype=torch.int32, device=dev)
                 if pool is not None:             # the group extrema came out of the last forward launch: finish on (groups, c) elements
-                    L.check(lib.gspn_pool32_select(groups, cl, L.ptr(pool[0]), L.ptr(pool[1]), L.ptr(pool[2]), L.ptr(pool[3]),
+                    L.check(lib.gspn_pool32_select(groups, cl, L.ptr(pool[0]), L.ptr(pool[1]), L.ptr(cur), cur_ld,
                                                    L.ptr(in_scale), L.ptr(in_shift), L.ptr(out), L.ptr(arg), st), "pool32_select")
                 else:
                     L.check(lib.gspn_bnrelu_maxpool(groups, pool_ns, cl, L.ptr(cur), cur_ld, L.ptr(in_scale), L.ptr(in_shift),

@@ -189,13 +189,13 @@ int gspn_sa_group_concat_grad_csr(int b, int n, int c, int m, int nsample, const
 int gspn_mlp_fwd(long rows, int cin, int cout, const float* X, int ldx, const float* in_scale, const float* in_shift,
                  const float* W, const float* bias, float* Y, int ldy, float* stats, void* stream);
 /* gspn_mlp_fwd + the first half of a max-pool over groups of 32 consecutive rows (pointnet_util.py:123-124, nsample = 32): per group
- * and channel the largest / smallest raw output and their row offsets, taken from the accumulators (vmax, vmin, amax, amin: each
- * (rows/32, cout)).  BN+ReLU is monotone per channel, so gspn_pool32_select finishes the pool from these once scale/shift exist:
- * out = relu(scale*(scale >= 0 ? vmax : vmin) + shift), arg = the matching row offset -- the (rows, cout) tensor is not read again. */
+ * and channel the largest raw output and its row offset, taken from the accumulators (vmax, amax: each (rows/32, cout)).  BN+ReLU is
+ * increasing in y for scale >= 0, so gspn_pool32_select finishes the pool from these once scale/shift exist:
+ * out = relu(scale*vmax + shift), arg = amax -- the (rows, cout) tensor is not read again, except for channels with a negative scale
+ * (their group minimum is taken from Y by the select kernel). */
 int gspn_mlp_fwd_pool32(long rows, int cin, int cout, const float* X, int ldx, const float* in_scale, const float* in_shift,
-                        const float* W, const float* bias, float* Y, int ldy, float* stats,
-                        float* vmax, float* vmin, int* amax, int* amin, void* stream);
-int gspn_pool32_select(long groups, int c, const float* vmax, const float* vmin, const int* amax, const int* amin,
+                        const float* W, const float* bias, float* Y, int ldy, float* stats, float* vmax, int* amax, void* stream);
+int gspn_pool32_select(long groups, int c, const float* vmax, const int* amax, const float* Y, int ldy,
                        const float* scale, const float* shift, float* out, int* arg, void* stream);
 /* bytes of the `stats` workspace for a (rows, cout) layer */
 long gspn_mlp_fwd_stats_bytes(long rows, int cout);
