@@ -70,6 +70,11 @@ SIGNATURES = {
     "gspn_mlp_gather_cin": [_c.POINTER(GatherArgs)],
     "gspn_mlp_fwd_gather": [_L, _c.POINTER(GatherArgs), _I, _P, _P, _P, _I, _P, _P],
     "gspn_mlp_bwd_wgrad_gather": [_L, _c.POINTER(GatherArgs), _I, _c.POINTER(DyArgs), _P, _P, _P, _F, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "gspn_pool_rsum": [_L, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _F, _P, _c.POINTER(_I), _P],
+    "gspn_mlp_bwd_coef": [_L, _I, _I, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P],
+    "gspn_mlp_bwd_wgrad_known": [_L, _I, _I, _c.POINTER(DyArgs), _P, _I, _P, _P, _c.POINTER(GatherArgs), _P, _P, _P],
+    "gspn_mlp_bwd_data_ex": [_L, _I, _I, _c.POINTER(DyArgs), _P, _I, _I, _P, _I, _P, _I, _P, _P, _F, _I, _I, _P, _P,
+                             _P, _I, _P, _P, _P, _P, _F, _P, _c.POINTER(_I), _P],
     "gspn_bn_finalize": [_L, _I, _P, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P],
     "gspn_bnrelu_maxpool": [_L, _I, _I, _P, _I, _P, _P, _P, _P, _P],
     "gspn_bnrelu_apply": [_L, _I, _P, _I, _P, _P, _P, _I, _P],
@@ -92,6 +97,7 @@ SPECIAL = {
     "gspn_mlp_fwd_stats_bytes": ([_L, _I], _L),
     "gspn_fps_cells_ws_bytes": ([_I, _I], _L),
     "gspn_fps_multi_ws_bytes": ([_I, _I], _L),
+    "gspn_rsum_part_floats": ([_L, _I], _L),
     "gspn_inverse_lists_work_ints": ([_I, _I, _I], _L),
 }
 

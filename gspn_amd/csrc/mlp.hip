@@ -1088,13 +1088,17 @@ template <int MT, int NTT> struct WgradSplit {
 };
 // GATHER: the A operand's rows are virtual (GatherSrc, see mlp_fwd_stream_kernel); cin is the internal width 4*cq + 4 and the partial
 // tiles / column sums come out in that internal row order (the dW reduction maps them back: DwJob::gq).
-template <int MT, int NTT, int TKW, bool WANT_GX, bool POOLED, bool GATHER = false>
+// KNOWN (early coefficients): the BN reductions r0, r1 of this layer were taken BEFORE this pass (by the epilogue of the next layer's
+// pass B, or from the pool arg-max: gspn_mlp_bwd_coef), so a.cA/cB/cC are final and the B operand is dY = cA*dyh + cB*y + cC itself:
+// ONE GEMM dW = A^T.dY instead of G1 and Gx, no x-hat, no column sums.  Implies !WANT_GX; PP holds dW's partial tiles directly.
+template <int MT, int NTT, int TKW, bool WANT_GX, bool POOLED, bool GATHER = false, bool KNOWN = false>
 __global__ __launch_bounds__(256, ((WgradSplit<MT, NTT>::AM * WgradSplit<MT, NTT>::BNW * (WANT_GX ? 2 : 1) >= 4 || (POOLED && TKW >= 32)) ? 2 : 3)) void wgrad_stream_kernel(int rows, int cin, int cout, gspn_dy_args a, const float* __restrict__ X, int ldx,
                                                            const float* __restrict__ in_scale, const float* __restrict__ in_shift,
                                                            const float* __restrict__ mean, const float* __restrict__ var, float eps,
                                                            float* __restrict__ RP, float* __restrict__ GP, float* __restrict__ PP,
                                                            int rows_per_chunk, int nslots, int shared, int nch, int nrow, int ncol, GatherSrc gsrc) {
     static_assert(!(GATHER && POOLED), "the gathered layer is the first of a stack: its upstream gradient is dense");
+    static_assert(!(KNOWN && WANT_GX), "known coefficients need no second product");
     using SP = WgradSplit<MT, NTT>;
     constexpr int BM = 32 * MT, BN = 32 * NTT;
     constexpr int WK = SP::WK, GM = SP::GM, GN = SP::GN, AM = SP::AM, BNW = SP::BNW;
@@ -1204,6 +1208,12 @@ __global__ __launch_bounds__(256, ((WgradSplit<MT, NTT>::AM * WgradSplit<MT, NTT
         bsh[y] = a.shift[n];
         brs[y] = var ? (float)(1.0 / sqrt((double)var[n] + (double)eps)) : 1.f;
         bmr[y] = -(mean ? mean[n] : 0.f) * brs[y];
+        if constexpr (KNOWN) { brs[y] = a.cB[n]; bmr[y] = a.cC[n]; }      // reused: dY = cA*dyh + (cB*y + cC)
+    }
+    float kca[KNOWN ? BNW : 1];
+    if constexpr (KNOWN) {
+#pragma unroll
+        for (int y = 0; y < BNW; ++y) kca[y] = a.cA[min(n0 + bo[y], cout - 1)];
     }
     // ---- pooled gradient: per (column tile, group-in-stage) arg-max offset and pooled gradient of the lane's column ----
     const int ns = POOLED ? a.ns : TKW;
@@ -1304,16 +1314,19 @@ __global__ __launch_bounds__(256, ((WgradSplit<MT, NTT>::AM * WgradSplit<MT, NTT
                     }
                     if (TAIL) dz = r < live ? dz : 0.f;
                     dyh[y] = __builtin_fmaf(yv, bsc[y], bsh[y]) > 0.f ? dz : 0.f;
-                    xh[y] = __builtin_fmaf(yv, brs[y], bmr[y]);              // (y - mean) * rstd
+                    xh[y] = __builtin_fmaf(yv, brs[y], bmr[y]);              // (y - mean) * rstd   [KNOWN: cB*y + cC]
+                    if constexpr (KNOWN) {
+                        dyh[y] = __builtin_fmaf(kca[y], dyh[y], xh[y]);      // dY (rows past the end are killed through av = 0)
+                    }
                 }
-                if (gm == 0) {
+                if (!KNOWN && gm == 0) {
 #pragma unroll
                     for (int y = 0; y < BNW; ++y) {
                         r0a[y] += dyh[y];
                         r1a[y] = __builtin_fmaf(dyh[y], xh[y], r1a[y]);
                     }
                 }
-                if (gn == 0) {
+                if (!KNOWN && gn == 0) {
 #pragma unroll
                     for (int x = 0; x < AM; ++x) g3a[x] += av[x];
                 }
@@ -1409,6 +1422,7 @@ __global__ __launch_bounds__(256, ((WgradSplit<MT, NTT>::AM * WgradSplit<MT, NTT
     }
     // column sums: one LDS cell per (k-part, lane half, column), summed in a fixed order.  Every column tile is seen by GM wave
     // groups (only gm == 0 reports it), every row tile by GN (only gn == 0 reports it).
+    if constexpr (KNOWN) return;
     __syncthreads();
     float* sR = sbuf;                                   // [WK*2][2][BN]
     float* sG = sbuf + WK * 2 * 2 * BN;                 // [WK*2][BM]
@@ -1617,6 +1631,7 @@ struct DwJob {
     float eps;
     int use_bn, is_training;
     float* dW;
+    int plain;                            // the partial tiles ARE dW's (pass A ran with known coefficients): dW = their sum
     int gq, gc_real, gxyz_first;          // gq > 0: rows of the partial tiles are in the gathered layer's internal order (GatherSrc)
 };
 // One workgroup of NTH threads = DW_OX consecutive outputs x NTH/DW_OX interleaved slot slices; sh = 2 * (NTH/64) * DW_OX doubles.
@@ -1627,7 +1642,7 @@ __device__ __forceinline__ void wgrad_dw_block(const DwJob& j, unsigned blk, dou
     double* sx = sh + NW * DW_OX;
     const long total = (long)j.cin * j.cout;
     const double R = (double)j.rows;
-    const bool tr = j.use_bn && j.is_training;
+    const bool tr = j.use_bn && j.is_training && !j.plain;
     const int ox = threadIdx.x % DW_OX, sl = threadIdx.x / DW_OX, wave = threadIdx.x >> 6;
     const long i = blk * (long)DW_OX + ox;
     const long ic = i < total ? i : total - 1;                   // clamped: every lane takes part in the shuffles
@@ -1663,7 +1678,7 @@ __device__ __forceinline__ void wgrad_dw_block(const DwJob& j, unsigned blk, dou
     for (int q = 0; q < NW; ++q) { w1 += s1[q * DW_OX + ox]; wx += sx[q * DW_OX + ox]; }
     const int n = (int)(i % j.cout), m = (int)(i / j.cout);
     double A = 1.0;
-    if (j.use_bn) A = (j.gamma ? (double)j.gamma[n] : 1.0) / sqrt((double)j.var[n] + (double)j.eps);
+    if (j.use_bn && !j.plain) A = (j.gamma ? (double)j.gamma[n] : 1.0) / sqrt((double)j.var[n] + (double)j.eps);
     if (tr) w1 -= (j.red[n] / R) * (double)j.g3[m] + (j.red[j.cout + n] / R) * wx;
     if (j.gq > 0) {                                               // internal row m -> row of the caller's dW (padding rows have none)
         GatherSrc g{nullptr, nullptr, nullptr, j.gq, j.gc_real, j.gxyz_first};
@@ -1682,7 +1697,7 @@ static DwJob dw_job(long rows, int cin, int cout, long nslots, const float* PP, 
     DwJob j;
     j.rows = rows; j.cin = cin; j.cout = cout; j.nslots = (int)nslots; j.nblk = (int)(((long)cin * cout + DW_OX - 1) / DW_OX);
     j.PP = PP; j.red = red; j.g3 = g3; j.var = var; j.gamma = gamma; j.eps = eps; j.use_bn = use_bn; j.is_training = is_training; j.dW = dW;
-    j.gq = 0; j.gc_real = 0; j.gxyz_first = 0;
+    j.gq = 0; j.gc_real = 0; j.gxyz_first = 0; j.plain = 0;
     return j;
 }
 
@@ -1705,8 +1720,9 @@ static WgradPlan wgrad_choose(long rows, int cin, int cout, const gspn_dy_args* 
 static int wgrad_impl(long rows, int cin, int cout, const gspn_dy_args* a, const float* X, int ldx,
                       const float* in_scale, const float* in_shift, const float* mean, const float* var, const float* gamma,
                       float eps, int use_bn, int is_training, float* work, float* cA, float* cB, float* cC,
-                      float* dgamma, float* dbeta, float* dbias, float* dW, void* stream, const GatherSrc* gsrc) {
+                      float* dgamma, float* dbeta, float* dbias, float* dW, void* stream, const GatherSrc* gsrc, bool known = false) {
     // gsrc: virtual input rows (GatherSrc); cin is then the internal width 4*cq + 4 and X / ldx are unused
+    // known: a->cA/cB/cC are already final (gspn_mlp_bwd_coef): one GEMM with dY as the operand, no reductions, no coefficient kernel
     if (rows <= 0 || cin <= 0 || cout <= 0 || (!gsrc && ldx < cin) || !a || !a->Y || !a->scale || !a->shift || !work) return GSPN_ERR_ARG;
     if (!a->dZ && !(a->dPool && a->pool_arg && a->ns > 0)) return GSPN_ERR_ARG;
     if ((in_scale == nullptr) != (in_shift == nullptr)) return GSPN_ERR_ARG;
@@ -1727,6 +1743,7 @@ static int wgrad_impl(long rows, int cin, int cout, const gspn_dy_args* a, const
     } else {
         p = wgrad_choose(rows, cin, cout, a, X, ldx, &use_stream);
     }
+    if (known && (!use_stream || p.MTs != 1 || !a->cA || !a->cB || !a->cC)) return GSPN_ERR_UNSUPPORTED;
     char* wb = reinterpret_cast<char*>(work);
     if (reinterpret_cast<uintptr_t>(wb) % 16) return GSPN_ERR_ARG;
     double* red = reinterpret_cast<double*>(wb);
@@ -1751,6 +1768,21 @@ static int wgrad_impl(long rows, int cin, int cout, const gspn_dy_args* a, const
             else hipLaunchKernelGGL((wgrad_stream_kernel<MT_, NT_, TKW_, false, false, true>), grid, dim3(256), 0, st, WS_ARGS, *gsrc);      \
             launched = 1;                                                                       \
         }
+#define WS_KNOWN(MT_, NT_, TKW_)                                                                 \
+        if (!launched && known && p.MTs == MT_ && p.NTs == NT_ && p.TKW == TKW_) {              \
+            if (gsrc) hipLaunchKernelGGL((wgrad_stream_kernel<MT_, NT_, TKW_, false, false, true, true>), grid, dim3(256), 0, st, WS_ARGS, *gsrc);          \
+            else if (pooled) hipLaunchKernelGGL((wgrad_stream_kernel<MT_, NT_, TKW_, false, true, false, true>), grid, dim3(256), 0, st, WS_ARGS, GatherSrc{}); \
+            else hipLaunchKernelGGL((wgrad_stream_kernel<MT_, NT_, TKW_, false, false, false, true>), grid, dim3(256), 0, st, WS_ARGS, GatherSrc{});        \
+            launched = 1;                                                                       \
+        }
+        WS_KNOWN(1, 1, 64) WS_KNOWN(1, 2, 32)
+        if (!launched && known && !gsrc && p.MTs == 1 && p.NTs == 4 && p.TKW == 16) {
+            if (pooled) hipLaunchKernelGGL((wgrad_stream_kernel<1, 4, 16, false, true, false, true>), grid, dim3(256), 0, st, WS_ARGS, GatherSrc{});
+            else hipLaunchKernelGGL((wgrad_stream_kernel<1, 4, 16, false, false, false, true>), grid, dim3(256), 0, st, WS_ARGS, GatherSrc{});
+            launched = 1;
+        }
+        if (known && !launched) return GSPN_ERR_UNSUPPORTED;
+#undef WS_KNOWN
         WS_GATHER(1, 1, 64) WS_GATHER(1, 2, 32)
         if (gsrc && !launched) return GSPN_ERR_UNSUPPORTED;
 #undef WS_GATHER
@@ -1779,10 +1811,12 @@ static int wgrad_impl(long rows, int cin, int cout, const gspn_dy_args* a, const
 #undef WG_ARGS
     }
     const int cmax = cin > cout ? cin : cout;
-    hipLaunchKernelGGL(wgrad_small_reduce_kernel, dim3(cmax), dim3(256), 0, st, rows, cin, cout, (int)p.nch, RP, GP, red, g3, mean, var, gamma, eps,
-                       use_bn, is_training, cA, cB, cC, dgamma, dbeta, dbias);
+    if (!known)
+        hipLaunchKernelGGL(wgrad_small_reduce_kernel, dim3(cmax), dim3(256), 0, st, rows, cin, cout, (int)p.nch, RP, GP, red, g3, mean, var, gamma, eps,
+                           use_bn, is_training, cA, cB, cC, dgamma, dbeta, dbias);
     if (dW) {
         DwJob j = dw_job(rows, cin, cout, p.nslots, PP, red, g3, var, gamma, eps, use_bn, is_training, dW);
+        j.plain = known ? 1 : 0;
         if (gsrc) { j.gq = gsrc->cq; j.gc_real = gsrc->c_real; j.gxyz_first = gsrc->xyz_first; }
         hipLaunchKernelGGL(wgrad_dw_kernel, dim3((unsigned)j.nblk), dim3(1024), 0, st, j);
     }
@@ -1794,6 +1828,105 @@ extern "C" int gspn_mlp_bwd_wgrad(long rows, int cin, int cout, const gspn_dy_ar
                                   float* dgamma, float* dbeta, float* dbias, float* dW, void* stream) {
     return wgrad_impl(rows, cin, cout, a, X, ldx, in_scale, in_shift, mean, var, gamma, eps, use_bn, is_training, work, cA, cB, cC,
                       dgamma, dbeta, dbias, dW, stream, nullptr);
+}
+
+// ============================================================================================
+// Early coefficients.  Training-mode BN's backward needs r0 = sum(dyh), r1 = sum(dyh*xhat) over ALL rows before any dY can be formed;
+// pass A above avoids waiting for them by carrying a second product (Gx) through the GEMM -- twice the MFMA work.  When the two sums
+// are available BEFORE pass A, the coefficients are final and pass A is one GEMM on dY (wgrad_stream_kernel<..., KNOWN>):
+//   * top layer of a pooled stack: the upstream gradient is (groups, c) with one live row per group -> pool_rsum_kernel;
+//   * every other layer l: its dz is the dX that pass B of layer l+1 writes -> that kernel's epilogue takes the sums (RsumArgs);
+//   * gspn_mlp_bwd_coef turns the per-workgroup partials into cA/cB/cC, dgamma, dbeta, dbias (what wgrad_small_reduce_kernel does
+//     for the two-product form).
+// ============================================================================================
+__global__ __launch_bounds__(256) void pool_rsum_kernel(long groups, int ns, int c, const float* __restrict__ dPool, const int* __restrict__ arg,
+                                                        const float* __restrict__ Y, int ldy, const float* __restrict__ scale,
+                                                        const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ var,
+                                                        float eps, float* __restrict__ part, long gpb) {
+    const long g0 = blockIdx.x * gpb, g1 = min(groups, g0 + gpb);
+    for (int col = threadIdx.x; col < c; col += 256) {
+        const float sc = scale[col], sh = shift[col];
+        const float rs = (float)(1.0 / sqrt((double)var[col] + (double)eps)), mr = -mean[col] * rs;
+        float r0 = 0.f, r1 = 0.f;
+        for (long g = g0; g < g1; ++g) {
+            const float dp = dPool[g * c + col];
+            const float yv = Y[(g * ns + arg[g * c + col]) * ldy + col];
+            const float dyh = __builtin_fmaf(yv, sc, sh) > 0.f ? dp : 0.f;
+            r0 += dyh;
+            r1 = __builtin_fmaf(dyh, __builtin_fmaf(yv, rs, mr), r1);
+        }
+        part[(size_t)blockIdx.x * 2 * c + col] = r0;
+        part[(size_t)blockIdx.x * 2 * c + c + col] = r1;
+    }
+}
+#define RSUM_POOL_BLOCKS 256
+// partial sums [nparts][2][c] of (dyh, dyh*xhat) for the top layer of a pooled stack; returns nparts through *nparts_out.
+// part: at least gspn_rsum_part_floats(c) floats.
+extern "C" long gspn_rsum_part_floats(long rows, int c) {
+    if (c <= 0) return GSPN_ERR_ARG;
+    long n = row_grid(rows > 0 ? rows : 1, 1, 4);            // what pass B's epilogue needs at most (one row of partials per workgroup)
+    if (n < RSUM_POOL_BLOCKS) n = RSUM_POOL_BLOCKS;
+    return n * 2 * c;
+}
+extern "C" int gspn_pool_rsum(long groups, int ns, int c, const float* dPool, const int* arg, const float* Y, int ldy, const float* scale,
+                              const float* shift, const float* mean, const float* var, float eps, float* part, int* nparts_out, void* stream) {
+    if (groups <= 0 || ns <= 0 || c <= 0 || !dPool || !arg || !Y || !scale || !shift || !mean || !var || !part || !nparts_out) return GSPN_ERR_ARG;
+    long nblk = groups < RSUM_POOL_BLOCKS ? groups : RSUM_POOL_BLOCKS;
+    const long gpb = (groups + nblk - 1) / nblk;
+    nblk = (groups + gpb - 1) / gpb;
+    hipLaunchKernelGGL(pool_rsum_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, groups, ns, c, dPool, arg, Y, ldy, scale, shift, mean, var,
+                       eps, part, gpb);
+    *nparts_out = (int)nblk;
+    return gspn_launch_status();
+}
+__global__ __launch_bounds__(256) void bwd_coef_kernel(long rows, int c, int nparts, const float* __restrict__ part, const float* __restrict__ mean,
+                                                       const float* __restrict__ var, const float* __restrict__ gamma, float eps,
+                                                       float* __restrict__ cA, float* __restrict__ cB, float* __restrict__ cC,
+                                                       float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dbias) {
+    __shared__ double sh[2][4];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int n = blockIdx.x;
+    double a0 = 0.0, a1 = 0.0;
+    for (int p = t; p < nparts; p += 256) { a0 += (double)part[(size_t)p * 2 * c + n]; a1 += (double)part[(size_t)p * 2 * c + c + n]; }
+    a0 = wave_sum_f64(a0); a1 = wave_sum_f64(a1);
+    if (lane == 0) { sh[0][wave] = a0; sh[1][wave] = a1; }
+    __syncthreads();
+    if (t != 0) return;
+    const double r0 = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
+    const double r1 = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
+    const double R = (double)rows;
+    const double g = gamma ? (double)gamma[n] : 1.0;
+    const double rstd = 1.0 / sqrt((double)var[n] + (double)eps);
+    const double mu = (double)mean[n];
+    cA[n] = (float)(g * rstd);                                         // same formulas as wgrad_small_reduce_kernel (training-mode BN)
+    cB[n] = (float)(-g * rstd * rstd * (r1 / R));
+    cC[n] = (float)(-g * rstd * (r0 / R - mu * rstd * (r1 / R)));
+    if (dgamma) dgamma[n] = (float)r1;
+    if (dbeta) dbeta[n] = (float)r0;
+    if (dbias) dbias[n] = 0.f;                                        // sum(dY) is exactly 0 under batch statistics
+}
+// coefficients of a training-mode BN layer from partial sums [nparts][2][c] (gspn_pool_rsum, or pass B's epilogue: gspn_mlp_bwd_data_rsum)
+extern "C" int gspn_mlp_bwd_coef(long rows, int c, int nparts, const float* part, const float* mean, const float* var, const float* gamma, float eps,
+                                 float* cA, float* cB, float* cC, float* dgamma, float* dbeta, float* dbias, void* stream) {
+    if (rows <= 0 || c <= 0 || nparts <= 0 || !part || !mean || !var || !cA || !cB || !cC) return GSPN_ERR_ARG;
+    hipLaunchKernelGGL(bwd_coef_kernel, dim3(c), dim3(256), 0, (hipStream_t)stream, rows, c, nparts, part, mean, var, gamma, eps, cA, cB, cC, dgamma, dbeta, dbias);
+    return gspn_launch_status();
+}
+static int gather_src(const gspn_gather_args* g, GatherSrc* out);
+// pass A with final coefficients in a->cA/cB/cC (one GEMM).  g: gather descriptor of a fused-front-end first layer, or NULL (then X/ldx/
+// in_scale/in_shift as in gspn_mlp_bwd_wgrad).  dW may be NULL (sum of the partial tiles left to gspn_mlp_bwd_data_dw with use_bn = 0).
+extern "C" int gspn_mlp_bwd_wgrad_known(long rows, int cin, int cout, const gspn_dy_args* a, const float* X, int ldx, const float* in_scale,
+                                        const float* in_shift, const gspn_gather_args* g, float* work, float* dW, void* stream) {
+    if (g) {
+        GatherSrc gs;
+        const int rc = gather_src(g, &gs);
+        if (rc) return rc;
+        if (!dW) return GSPN_ERR_ARG;
+        return wgrad_impl(rows, 4 * gs.cq + 4, cout, a, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0, 0, work, nullptr, nullptr, nullptr,
+                          nullptr, nullptr, nullptr, dW, stream, &gs, true);
+    }
+    return wgrad_impl(rows, cin, cout, a, X, ldx, in_scale, in_shift, nullptr, nullptr, nullptr, 0.f, 0, 0, work, nullptr, nullptr, nullptr,
+                      nullptr, nullptr, nullptr, dW, stream, nullptr, true);
 }
 
 // ============================================================================================
@@ -1875,9 +2008,13 @@ extern "C" int gspn_mlp_bwd_dw(long rows, int cin, int cout, const gspn_dy_args*
 // DW: the first dwj.nblk workgroups (of row blockIdx.y == 0) are not part of the GEMM: they reduce the layer's partial dW tiles (the
 // last kernel of pass A, which nothing in pass B depends on) while the rest of the grid computes dX -- one launch, no tail, instead of
 // a 15 us kernel of its own per layer.
+// RsumArgs (Yp != NULL): this launch's dX is the dz of the PREVIOUS layer (pre-BN output Yp, batch statistics mean/var, forward
+// scale/shift); the epilogue also takes that layer's BN reductions sum(dyh), sum(dyh*xhat) from the finished tiles -- per-workgroup
+// partials part[workgroup][2][cin], summed by gspn_mlp_bwd_coef -- so its pass A can run with final coefficients (one GEMM).
+struct RsumArgs { const float* Yp; int ldyp; const float* scale; const float* shift; const float* mean; const float* var; float eps; float* part; };
 template <int BN, bool VEC, bool POOLED, bool DW>
 __global__ __launch_bounds__(256) void mlp_bwd_data_kernel(long rows, int cin, int cout, gspn_dy_args a, const float* __restrict__ W,
-                                                           float* __restrict__ dX, int ldx, int col0, DwJob dwj) {
+                                                           float* __restrict__ dX, int ldx, int col0, DwJob dwj, RsumArgs rs) {
     // `cin` is the END of the column range [col0, cin) of dX this launch produces (gspn_mlp_bwd_data_cols)
     constexpr int NT = BN / 32;
     constexpr int LDBT = BN + 1;                 // B written transposed: odd pitch
@@ -1959,6 +2096,21 @@ __global__ __launch_bounds__(256) void mlp_bwd_data_kernel(long rows, int cin, i
         }
     };
     f32x16 acc[NT];
+    // previous layer's reductions (RsumArgs): per-lane constants of this lane's columns and running sums over the workgroup's tiles
+    const bool rsum = rs.Yp != nullptr;
+    float p_sc[NT], p_sh[NT], p_rs[NT], p_mr[NT], r0s[NT], r1s[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        r0s[nt] = r1s[nt] = 0.f;
+        p_sc[nt] = p_sh[nt] = p_rs[nt] = p_mr[nt] = 0.f;
+        if (rsum) {
+            const int col = min(n0 + nt * 32 + (lane & 31), cin - 1);
+            p_sc[nt] = rs.scale[col];
+            p_sh[nt] = rs.shift[col];
+            p_rs[nt] = (float)(1.0 / sqrt((double)rs.var[col] + (double)rs.eps));
+            p_mr[nt] = -rs.mean[col] * p_rs[nt];
+        }
+    }
     const long my_tiles = bx < ntiles ? (ntiles - bx + gx - 1) / gx : 0;
     const long nsteps = my_tiles * nchunks;
     for (long sidx = 0; sidx <= nsteps; ++sidx) {
@@ -1985,6 +2137,29 @@ __global__ __launch_bounds__(256) void mlp_bwd_data_kernel(long rows, int cin, i
             if (c == nchunks - 1) {
                 const long m0 = tile * TM;
                 const bool full = m0 + TM <= rows;
+                if (rsum) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const int col = n0 + nt * 32 + (lane & 31);
+                        if (col < cin) {
+                            const float* yp = rs.Yp + (m0 + wave * 32 + 4 * (lane >> 5)) * rs.ldyp + col;
+                            float yv[16];
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {         // clamped, unconditional loads: all sixteen in flight
+                                const long rr = (r & 3) + 8 * (r >> 2);
+                                const long rowc = min(m0 + wave * 32 + 4 * (lane >> 5) + rr, rows - 1) - (m0 + wave * 32 + 4 * (lane >> 5));
+                                yv[r] = yp[rowc * rs.ldyp];
+                            }
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const bool live = full || (m0 + wave * 32 + c_row(r, lane)) < rows;
+                                const float dyh = (live && __builtin_fmaf(yv[r], p_sc[nt], p_sh[nt]) > 0.f) ? acc[nt][r] : 0.f;
+                                r0s[nt] += dyh;
+                                r1s[nt] = __builtin_fmaf(dyh, __builtin_fmaf(yv[r], p_rs[nt], p_mr[nt]), r1s[nt]);
+                            }
+                        }
+                    }
+                }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     const int col = n0 + nt * 32 + (lane & 31);
@@ -2008,9 +2183,34 @@ __global__ __launch_bounds__(256) void mlp_bwd_data_kernel(long rows, int cin, i
         if (sidx < nsteps) commit();
         __syncthreads();
     }
+    if (rsum) {
+        // lanes l and l+32 hold the same column; then the four waves through LDS (sA is free now); one partial row per workgroup
+        float* sR = sA;                                  // [4 waves][2][BN]
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            r0s[nt] += __shfl_xor(r0s[nt], 32, 64);
+            r1s[nt] += __shfl_xor(r1s[nt], 32, 64);
+            if (lane < 32) {
+                sR[(wave * 2 + 0) * BN + nt * 32 + lane] = r0s[nt];
+                sR[(wave * 2 + 1) * BN + nt * 32 + lane] = r1s[nt];
+            }
+        }
+        __syncthreads();
+        float* pr = rs.part + (size_t)bx * 2 * cin;
+        for (int j = t; j < BN; j += 256) {
+            const int col = n0 + j;
+            if (col < cin) {
+                float v0 = 0.f, v1 = 0.f;
+                for (int w = 0; w < 4; ++w) { v0 += sR[(w * 2 + 0) * BN + j]; v1 += sR[(w * 2 + 1) * BN + j]; }
+                pr[col] = v0;
+                pr[cin + col] = v1;
+            }
+        }
+    }
 }
 static int bwd_data_launch(long rows, int cin, int cout, const gspn_dy_args* a, const float* W, int col0, int ncols, float* dX, int ldx, const DwJob* dwj,
-                           hipStream_t st) {
+                           hipStream_t st, const RsumArgs* rsp = nullptr, int* nparts_out = nullptr) {
+    const RsumArgs rs = rsp ? *rsp : RsumArgs{nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr};
     const bool pooled = a->dZ == nullptr;
     const bool v = vec_ok(a->Y, a->ldy) && vec_ok(W, cout) &&
                    (pooled ? (((uintptr_t)a->dPool) % 16 == 0 && ((uintptr_t)a->pool_arg) % 16 == 0) : vec_ok(a->dZ, a->ldz));
@@ -2020,8 +2220,9 @@ static int bwd_data_launch(long rows, int cin, int cout, const gspn_dy_args* a, 
 #define BD_GO(BN_, V_, P_, YT_)                                                                                                       \
     do {                                                                                                                               \
         const dim3 g(row_grid(rows, YT_, BN_ >= 128 ? 3 : 4) + extra, YT_);                                                            \
-        if (dwj) hipLaunchKernelGGL((mlp_bwd_data_kernel<BN_, V_, P_, true>), g, dim3(256), 0, st, rows, cend, cout, *a, W, dX, ldx, col0, *dwj);   \
-        else     hipLaunchKernelGGL((mlp_bwd_data_kernel<BN_, V_, P_, false>), g, dim3(256), 0, st, rows, cend, cout, *a, W, dX, ldx, col0, none);  \
+        if (nparts_out) *nparts_out = (int)(g.x - extra);                                                                              \
+        if (dwj) hipLaunchKernelGGL((mlp_bwd_data_kernel<BN_, V_, P_, true>), g, dim3(256), 0, st, rows, cend, cout, *a, W, dX, ldx, col0, *dwj, rs);   \
+        else     hipLaunchKernelGGL((mlp_bwd_data_kernel<BN_, V_, P_, false>), g, dim3(256), 0, st, rows, cend, cout, *a, W, dX, ldx, col0, none, rs);  \
     } while (0)
 #define BD_LAUNCH(BN_, V_, YT_) do { if (pooled) BD_GO(BN_, V_, true, YT_); else BD_GO(BN_, V_, false, YT_); } while (0)
     const int bn = pick_bn(rows, ncols, "GSPN_BWD_FORCE_BN");
@@ -2065,6 +2266,36 @@ extern "C" int gspn_mlp_bwd_data_dw(long rows, int cin, int cout, const gspn_dy_
     const DwJob j = dw_job(rows, cin, cout, p.nslots, reinterpret_cast<const float*>(wb + ws_off_pp(p.nch, cin, cout)), reinterpret_cast<const double*>(wb),
                            reinterpret_cast<const float*>(wb + ws_off_g3(cout)), var, gamma, eps, use_bn, is_training, dW);
     return bwd_data_launch(rows, cin, cout, a, W, col0, ncols, dX, ldx, &j, (hipStream_t)stream);
+}
+// Pass B with both options: the fused dW reduction of gspn_mlp_bwd_data_dw (work != NULL) and the previous layer's BN reductions in the
+// epilogue (part != NULL: Yp (rows, ldyp) = that layer's pre-BN output = this layer's input before activation; scale_p/shift_p its
+// forward scale/shift; mean_p/var_p its batch statistics; part = gspn_rsum_part_floats(rows, cin) floats; *nparts_out = rows of partials
+// written, for gspn_mlp_bwd_coef).  The reductions need the whole row: col0 = 0, ncols = cin.
+extern "C" int gspn_mlp_bwd_data_ex(long rows, int cin, int cout, const gspn_dy_args* a, const float* W, int col0, int ncols, float* dX, int ldx,
+                                    const float* X, int ldx_in, const float* var, const float* gamma, float eps, int use_bn, int is_training,
+                                    const float* work, float* dW,
+                                    const float* Yp, int ldyp, const float* scale_p, const float* shift_p, const float* mean_p, const float* var_p,
+                                    float eps_p, float* part, int* nparts_out, void* stream) {
+    const int rc = bwd_data_check(rows, cin, cout, a, col0, ncols, ldx);
+    if (rc) return rc;
+    if (rows <= 0) return GSPN_ERR_ARG;
+    DwJob j;
+    const DwJob* jp = nullptr;
+    if (work) {
+        if (!dW || (X && ldx_in < cin) || (use_bn && !var)) return GSPN_ERR_ARG;
+        bool use_stream;
+        const WgradPlan p = wgrad_choose(rows, cin, cout, a, X, ldx_in, &use_stream);
+        const char* wb = reinterpret_cast<const char*>(work);
+        j = dw_job(rows, cin, cout, p.nslots, reinterpret_cast<const float*>(wb + ws_off_pp(p.nch, cin, cout)), reinterpret_cast<const double*>(wb),
+                   reinterpret_cast<const float*>(wb + ws_off_g3(cout)), var, gamma, eps, use_bn, is_training, dW);
+        jp = &j;
+    }
+    RsumArgs rs{nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr};
+    if (part) {
+        if (!Yp || ldyp < cin || !scale_p || !shift_p || !mean_p || !var_p || !nparts_out || col0 != 0 || ncols != cin) return GSPN_ERR_ARG;
+        rs = RsumArgs{Yp, ldyp, scale_p, shift_p, mean_p, var_p, eps_p, part};
+    }
+    return bwd_data_launch(rows, cin, cout, a, W, col0, ncols, dX, ldx, jp, (hipStream_t)stream, part ? &rs : nullptr, nparts_out);
 }
 extern "C" int gspn_mlp_bwd_data(long rows, int cin, int cout, const gspn_dy_args* a, const float* W, float* dX, int ldx, void* stream) {
     return gspn_mlp_bwd_data_cols(rows, cin, cout, a, W, 0, cin, dX, ldx, stream);

@@ -24,6 +24,9 @@ DEFER_DW = False
 # max-pool over nsample = 32 rows taken from the last layer's accumulators (gspn_mlp_fwd_pool32 + gspn_pool32_select) instead of a pass
 # over the (rows, c) output
 FUSE_POOL32 = os.environ.get("GSPN_FUSE_POOL32", "1") != "0"
+# early coefficients (mlp.hip, "Early coefficients"): the BN reductions of a layer are taken before its pass A -- by the epilogue of the
+# next layer's pass B, or from the pool arg-max for the top layer of a pooled stack -- so that pass A is one GEMM instead of two
+EARLY_R = os.environ.get("GSPN_EARLY_R", "1") != "0"
 # one launch for pass B + the dW reduction of the same layer (gspn_mlp_bwd_data_dw) instead of two
 FUSE_DW = os.environ.get("GSPN_FUSE_DW", "1") != "0"
 _side_streams = {}
@@ -188,13 +191,12 @@ class _MlpStack(torch.autograd.Function):
         keep = []
         with torch.cuda.device(dev):
             st = L.stream()
+            tr_all = is_training and EARLY_R and not DEFER_DW
+            coef = {}                            # layer index -> (cA, cB, cC, dgamma, dbeta, dbias) taken BEFORE that layer's pass A
             for li in range(len(layers) - 1, -1, -1):
                 lp = layers[li]
                 (xin, xld, cin, in_scale, in_shift, y, mean, var, scale, shift) = ctx.saved[li]
                 cout = lp.weights.shape[1]
-                cA = torch.empty(cout, dtype=torch.float32, device=dev)
-                cB = torch.empty(cout, dtype=torch.float32, device=dev)
-                cC = torch.empty(cout, dtype=torch.float32, device=dev)
                 a = L.DyArgs()
                 a.Y, a.ldy = y.data_ptr(), cout
                 if dz is None:
@@ -202,27 +204,52 @@ class _MlpStack(torch.autograd.Function):
                 else:
                     a.dZ, a.ldz, a.dPool, a.pool_arg, a.ns = dz.data_ptr(), ldz, None, None, 0
                 a.scale, a.shift = scale.data_ptr(), shift.data_ptr()
-                a.cA, a.cB, a.cC = cA.data_ptr(), cB.data_ptr(), cC.data_ptr()
-                dgamma = torch.empty(cout, dtype=torch.float32, device=dev) if lp.bn else None
-                dbeta = torch.empty(cout, dtype=torch.float32, device=dev) if lp.bn else None
-                dbias = torch.empty(cout, dtype=torch.float32, device=dev)
-                dW = torch.empty_like(lp.weights)
                 gather0 = gather if li == 0 else None
+                # ---- early coefficients of the top layer of a pooled stack: (groups x c) work on (dPool, arg, Y) ----
+                if tr_all and lp.bn and dz is None and li not in coef:
+                    part = torch.empty(int(lib.gspn_rsum_part_floats(rows, cout)), dtype=torch.float32, device=dev)
+                    npart = ctypes.c_int(0)
+                    L.check(lib.gspn_pool_rsum(rows // pool_ns, pool_ns, cout, L.ptr(d_out), L.ptr(ctx.arg), L.ptr(y), cout, L.ptr(scale), L.ptr(shift),
+                                               L.ptr(mean), L.ptr(var), BN_EPS, L.ptr(part), ctypes.byref(npart), st), "pool_rsum")
+                    coef[li] = _coef_from_parts(lib, rows, cout, npart.value, part, mean, var, lp, dev, st)
+                known = coef.get(li)
+                if known is not None:
+                    cA, cB, cC, dgamma, dbeta, dbias = known
+                else:
+                    cA = torch.empty(cout, dtype=torch.float32, device=dev)
+                    cB = torch.empty(cout, dtype=torch.float32, device=dev)
+                    cC = torch.empty(cout, dtype=torch.float32, device=dev)
+                    dgamma = torch.empty(cout, dtype=torch.float32, device=dev) if lp.bn else None
+                    dbeta = torch.empty(cout, dtype=torch.float32, device=dev) if lp.bn else None
+                    dbias = torch.empty(cout, dtype=torch.float32, device=dev)
+                a.cA, a.cB, a.cC = cA.data_ptr(), cB.data_ptr(), cC.data_ptr()
+                dW = torch.empty_like(lp.weights)
                 wcin = int(lib.gspn_mlp_gather_cin(ctypes.byref(ctx.gargs))) if gather0 is not None else cin
                 work = torch.empty(int(lib.gspn_mlp_bwd_work_bytes(rows, wcin, cout)) // 4 + 4, dtype=torch.float32, device=dev)
                 has_dx = li > 0 or ctx.x_needs_grad
                 fuse_dw = FUSE_DW and has_dx and not DEFER_DW and gather0 is None     # the dW reduction rides in spare workgroups of this layer's pass B
+                # ---- pass A ----
                 ev = _tic()
-                if gather0 is not None:
-                    L.check(lib.gspn_mlp_bwd_wgrad_gather(rows, ctypes.byref(ctx.gargs), cout, ctypes.byref(a), L.ptr(mean), L.ptr(var),
-                                                          L.ptr(lp.gamma if lp.bn else None), BN_EPS, int(lp.bn), int(is_training), L.ptr(work),
-                                                          L.ptr(cA), L.ptr(cB), L.ptr(cC), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dbias), L.ptr(dW), st),
-                            "mlp_bwd_wgrad_gather")
-                else:
-                    L.check(lib.gspn_mlp_bwd_wgrad(rows, cin, cout, ctypes.byref(a), L.ptr(xin), xld, L.ptr(in_scale), L.ptr(in_shift),
-                                                   L.ptr(mean), L.ptr(var), L.ptr(lp.gamma if lp.bn else None), BN_EPS, int(lp.bn), int(is_training),
-                                                   L.ptr(work), L.ptr(cA), L.ptr(cB), L.ptr(cC), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dbias),
-                                                   None if (DEFER_DW or fuse_dw) else L.ptr(dW), st), "mlp_bwd_wgrad")
+                ran_known = False
+                if known is not None:
+                    try:
+                        L.check(lib.gspn_mlp_bwd_wgrad_known(rows, cin, cout, ctypes.byref(a), L.ptr(xin), xld, L.ptr(in_scale), L.ptr(in_shift),
+                                                             ctypes.byref(ctx.gargs) if gather0 is not None else None, L.ptr(work),
+                                                             None if fuse_dw else L.ptr(dW), st), "mlp_bwd_wgrad_known")
+                        ran_known = True
+                    except NotImplementedError:
+                        ran_known = False            # a shape the one-GEMM kernels do not take: the two-product pass recomputes the same coefficients
+                if not ran_known:
+                    if gather0 is not None:
+                        L.check(lib.gspn_mlp_bwd_wgrad_gather(rows, ctypes.byref(ctx.gargs), cout, ctypes.byref(a), L.ptr(mean), L.ptr(var),
+                                                              L.ptr(lp.gamma if lp.bn else None), BN_EPS, int(lp.bn), int(is_training), L.ptr(work),
+                                                              L.ptr(cA), L.ptr(cB), L.ptr(cC), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dbias), L.ptr(dW), st),
+                                "mlp_bwd_wgrad_gather")
+                    else:
+                        L.check(lib.gspn_mlp_bwd_wgrad(rows, cin, cout, ctypes.byref(a), L.ptr(xin), xld, L.ptr(in_scale), L.ptr(in_shift),
+                                                       L.ptr(mean), L.ptr(var), L.ptr(lp.gamma if lp.bn else None), BN_EPS, int(lp.bn), int(is_training),
+                                                       L.ptr(work), L.ptr(cA), L.ptr(cB), L.ptr(cC), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dbias),
+                                                       None if (DEFER_DW or fuse_dw) else L.ptr(dW), st), "mlp_bwd_wgrad")
                 _toc(ev, "wgrad", rows, cin, cout)
                 if DEFER_DW and gather0 is None:
                     if side is None:
@@ -237,6 +264,7 @@ class _MlpStack(torch.autograd.Function):
                 if lp.bn:
                     g += [dbeta, dgamma]
                 grads = g + grads
+                # ---- pass B ----
                 if has_dx and gather0 is not None:
                     # the gathered layer: dX of the feature columns in grouped-row layout, then the gather-form gradient of the grouping
                     # (inverse lists; atomics without them) straight into d(features)
@@ -265,11 +293,25 @@ class _MlpStack(torch.autograd.Function):
                         dx.zero_()
                     # only grad_cols of the input feed a gradient upstream (e.g. not the xyz columns of an SA input)
                     gc = (spec.get("grad_cols") if li == 0 else None) or (0, cin)
+                    # this dX is the dz of layer li-1: its epilogue can take that layer's BN reductions (early coefficients for its pass A)
+                    prev = layers[li - 1] if li > 0 else None
+                    want_rsum = tr_all and prev is not None and prev.bn
                     ev = _tic()
-                    if fuse_dw:
-                        L.check(lib.gspn_mlp_bwd_data_dw(rows, cin, cout, ctypes.byref(a), L.ptr(lp.weights), int(gc[0]), int(gc[1]), L.ptr(dx), dx.shape[1],
-                                                         L.ptr(xin), xld, L.ptr(var), L.ptr(lp.gamma if lp.bn else None), BN_EPS, int(lp.bn),
-                                                         int(is_training), L.ptr(work), L.ptr(dW), st), "mlp_bwd_data_dw")
+                    if want_rsum or fuse_dw:
+                        part = npart = None
+                        pY = pmean = pvar = pscale = pshift = None
+                        if want_rsum:
+                            (_, _, _, _, _, pY, pmean, pvar, pscale, pshift) = ctx.saved[li - 1]
+                            part = torch.empty(int(lib.gspn_rsum_part_floats(rows, cin)), dtype=torch.float32, device=dev)
+                            npart = ctypes.c_int(0)
+                        bn_dw = 0 if ran_known else int(lp.bn)           # known coefficients: the partial tiles are dW's own (plain sum)
+                        L.check(lib.gspn_mlp_bwd_data_ex(rows, cin, cout, ctypes.byref(a), L.ptr(lp.weights), int(gc[0]), int(gc[1]), L.ptr(dx), dx.shape[1],
+                                                         L.ptr(xin), xld, L.ptr(var), L.ptr(lp.gamma if lp.bn else None), BN_EPS, bn_dw,
+                                                         int(is_training), L.ptr(work) if fuse_dw else None, L.ptr(dW) if fuse_dw else None,
+                                                         L.ptr(pY), cin, L.ptr(pscale), L.ptr(pshift), L.ptr(pmean), L.ptr(pvar), BN_EPS, L.ptr(part),
+                                                         ctypes.byref(npart) if want_rsum else None, st), "mlp_bwd_data_ex")
+                        if want_rsum:
+                            coef[li - 1] = _coef_from_parts(lib, rows, cin, npart.value, part, pmean, pvar, prev, dev, st)
                     else:
                         L.check(lib.gspn_mlp_bwd_data_cols(rows, cin, cout, ctypes.byref(a), L.ptr(lp.weights), int(gc[0]), int(gc[1]), L.ptr(dx),
                                                            dx.shape[1], st), "mlp_bwd_data_cols")
@@ -283,6 +325,20 @@ class _MlpStack(torch.autograd.Function):
                 main.wait_event(side.record_event())                # join: the gradients (and the workspaces) are complete past here
         del keep
         return (dx0, None, None) + tuple(grads)
+
+
+def _coef_from_parts(lib, rows, c, nparts, part, mean, var, lp, dev, st):
+    """gspn_mlp_bwd_coef: partial sums [nparts][2][c] of (dyh, dyh*xhat) -> the layer's final BN-backward coefficients and its
+    dgamma / dbeta / dbias, before its pass A runs"""
+    cA = torch.empty(c, dtype=torch.float32, device=dev)
+    cB = torch.empty(c, dtype=torch.float32, device=dev)
+    cC = torch.empty(c, dtype=torch.float32, device=dev)
+    dgamma = torch.empty(c, dtype=torch.float32, device=dev)
+    dbeta = torch.empty(c, dtype=torch.float32, device=dev)
+    dbias = torch.empty(c, dtype=torch.float32, device=dev)
+    L.check(lib.gspn_mlp_bwd_coef(rows, c, int(nparts), L.ptr(part), L.ptr(mean), L.ptr(var), L.ptr(lp.gamma), BN_EPS,
+                                  L.ptr(cA), L.ptr(cB), L.ptr(cC), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dbias), st), "mlp_bwd_coef")
+    return cA, cB, cC, dgamma, dbeta, dbias
 
 
 class _Linear(torch.autograd.Function):

@@ -270,6 +270,29 @@ int gspn_mlp_bwd_data_dw(long rows, int cin, int cout, const gspn_dy_args* a, co
                          const float* X, int ldx_in, const float* var, const float* gamma, float eps, int use_bn, int is_training,
                          const float* work, float* dW, void* stream);
 
+/* ---- early coefficients: pass A as ONE GEMM ------------------------------------------------------------------------------------
+ * Training-mode BN's backward needs r0 = sum(dyh) and r1 = sum(dyh*xhat) over all rows before dY exists; gspn_mlp_bwd_wgrad side-steps
+ * that with a second product (Gx) inside the GEMM -- twice the matrix work.  When the two sums are taken BEFORE pass A, the coefficients
+ * cA/cB/cC are final and gspn_mlp_bwd_wgrad_known runs one GEMM dW = act(X)^T . dY (g: optional gspn_gather_args of a fused first layer,
+ * defined below; dW may be NULL, the sum over partial tiles then rides in gspn_mlp_bwd_data_ex / _dw called with use_bn = 0):
+ *   - top layer of a pooled stack: gspn_pool_rsum takes the sums from (dPool, pool_arg, Y) -- (groups x c) work;
+ *   - any other layer l: its dz is the dX of layer l+1's pass B, whose epilogue takes them (gspn_mlp_bwd_data_ex, Yp = Y of layer l);
+ *   - gspn_mlp_bwd_coef(rows, c, nparts, part, ...) sums the partial rows [nparts][2][c] in double and writes cA, cB, cC, dgamma, dbeta,
+ *     dbias (the same formulas as gspn_mlp_bwd_wgrad's).  part: gspn_rsum_part_floats(rows, c) floats. */
+struct gspn_gather_args;
+long gspn_rsum_part_floats(long rows, int c);
+int gspn_pool_rsum(long groups, int ns, int c, const float* dPool, const int* arg, const float* Y, int ldy, const float* scale,
+                   const float* shift, const float* mean, const float* var, float eps, float* part, int* nparts_out, void* stream);
+int gspn_mlp_bwd_coef(long rows, int c, int nparts, const float* part, const float* mean, const float* var, const float* gamma, float eps,
+                      float* cA, float* cB, float* cC, float* dgamma, float* dbeta, float* dbias, void* stream);
+int gspn_mlp_bwd_wgrad_known(long rows, int cin, int cout, const gspn_dy_args* a, const float* X, int ldx, const float* in_scale,
+                             const float* in_shift, const struct gspn_gather_args* g, float* work, float* dW, void* stream);
+int gspn_mlp_bwd_data_ex(long rows, int cin, int cout, const gspn_dy_args* a, const float* W, int col0, int ncols, float* dX, int ldx,
+                         const float* X, int ldx_in, const float* var, const float* gamma, float eps, int use_bn, int is_training,
+                         const float* work, float* dW,
+                         const float* Yp, int ldyp, const float* scale_p, const float* shift_p, const float* mean_p, const float* var_p,
+                         float eps_p, float* part, int* nparts_out, void* stream);
+
 /* ---- fused set-abstraction front end: sample_and_group's concat (pointnet_util.py:36-52) + the first conv2d (:109-113)
  * without the grouped (b, npoint, nsample, 3+c) tensor.  gspn_sa_rel writes, per grouped row r = ((i*m + j)*ns + k), its centred
  * coordinates rel[r] = (xyz[i, idx[r]] - new_xyz[i, j], 0) and its source row gidx[r] = i*n + idx[r] (20 bytes per row).  The first

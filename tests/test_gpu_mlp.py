@@ -225,3 +225,26 @@ def test_pool_in_the_forward_epilogue_equals_the_pool_kernel(rows, cin, chans, m
     assert rel_err(outs[1][1], outs[0][1]) < 1e-6          # equal unless two rows of a group tie exactly (then either is a valid arg-max)
     for a, b in zip(outs[1][2], outs[0][2]):
         assert rel_err(a, b) < 1e-6
+
+
+@pytest.mark.parametrize("rows,cin,chans,ns", [(4096, 32, [32, 64, 48], 32), (2048, 67, [64, 64, 128], 32), (3000, 20, [24, 40, 16], None), (1024, 131, [128, 256], 32)])
+def test_early_coefficients_equal_the_two_product_pass(rows, cin, chans, ns, monkeypatch):
+    """mlp.EARLY_R: BN reductions taken by the previous pass-B epilogue / the pool arg-max, pass A as ONE GEMM on dY -- same gradients
+    as the two-product pass A (G1, Gx, g3 combined afterwards) to fp32 rounding, for every tensor of the stack"""
+    from gspn_amd import mlp as M
+    g = torch.Generator().manual_seed(rows + cin)
+    ld = (cin + 3) // 4 * 4
+    x0 = torch.randn(rows, ld, generator=g)
+    x0[:, cin:] = 0
+    go = torch.randn(rows // ns if ns else rows, chans[-1], generator=g).cuda()
+    res = []
+    for early in (True, False):
+        monkeypatch.setattr(M, "EARLY_R", early)
+        layers = to_layers(make_params(chans, cin, seed=2))
+        x = x0.cuda().requires_grad_(True)
+        out = M.mlp_stack(x, cin, layers, True, 0.7, pool_ns=ns)
+        out.backward(go)
+        res.append([x.grad[:, :cin].clone()] + [t.grad.clone() for lp in layers for t in lp.tensors()])
+    for a_, b_ in zip(res[0], res[1]):
+        scale = float(b_.abs().max())
+        assert float((a_ - b_).abs().max()) <= 2e-5 * max(scale, 1e-3)

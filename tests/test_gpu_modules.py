@@ -243,7 +243,8 @@ def test_fp_concat_matches_interpolate_plus_concat(b, n1, n2, c1, c2):
 
 def test_dw_reduction_placements_agree():
     """the dW reduction as its own kernel, on a side stream (mlp.DEFER_DW), or inside pass B's launch (mlp.FUSE_DW, the default):
-    identical dX; identical dW for the two stand-alone placements, and the same sum with fewer slot slices for the fused one"""
+    identical dX and dW for the two placements that share an algorithm, the same sum with fewer slot slices for the fused one; the
+    side-stream placement runs the two-product pass A (no early coefficients) and agrees to fp32 rounding"""
     from gspn_amd import mlp as M
     from tests.test_gpu_mlp import make_params, to_layers
     g = torch.Generator().manual_seed(5)
@@ -262,7 +263,7 @@ def test_dw_reduction_placements_agree():
             M.FUSE_DW, M.DEFER_DW = old
         res.append([lp.weights.grad.clone() for lp in layers] + [x.grad.clone()])
     for a_, b_ in zip(res[0], res[1]):
-        assert torch.equal(a_, b_)
+        assert rel_err(b_, a_) < 1e-5
     assert torch.equal(res[0][-1], res[2][-1])
     for a_, b_ in zip(res[0][:-1], res[2][:-1]):
         assert rel_err(b_, a_) < 1e-6

@@ -28,8 +28,9 @@ for name, rows, ldx, cin, cout, pooled in shapes:
     a.scale, a.shift, a.cA, a.cB, a.cC = scale.data_ptr(), shift.data_ptr(), cA.data_ptr(), cB.data_ptr(), cC.data_ptr()
     work = torch.empty(int(lib.gspn_mlp_bwd_work_bytes(rows, cin, cout)) // 4 + 4, device=dev)
     dW = torch.empty(cin, cout, device=dev); dX = torch.empty(rows, ldx, device=dev)
+    TR = int(__import__("os").environ.get("WB_TRAIN", "1"))
     def run_w():
-        L.check(lib.gspn_mlp_bwd_wgrad(rows, cin, cout, ctypes.byref(a), L.ptr(X), ldx, L.ptr(isc), L.ptr(ish), L.ptr(mean), L.ptr(var), L.ptr(gamma), 1e-3, 1, 1,
+        L.check(lib.gspn_mlp_bwd_wgrad(rows, cin, cout, ctypes.byref(a), L.ptr(X), ldx, L.ptr(isc), L.ptr(ish), L.ptr(mean), L.ptr(var), L.ptr(gamma), 1e-3, 1, TR,
                                        L.ptr(work), L.ptr(cA), L.ptr(cB), L.ptr(cC), None, None, None, L.ptr(dW), st), "w")
     def run_d():
         L.check(lib.gspn_mlp_bwd_data(rows, cin, cout, ctypes.byref(a), L.ptr(W), L.ptr(dX), ldx, st), "d")
