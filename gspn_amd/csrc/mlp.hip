@@ -1839,32 +1839,43 @@ extern "C" int gspn_mlp_bwd_wgrad(long rows, int cin, int cout, const gspn_dy_ar
 //   * gspn_mlp_bwd_coef turns the per-workgroup partials into cA/cB/cC, dgamma, dbeta, dbias (what wgrad_small_reduce_kernel does
 //     for the two-product form).
 // ============================================================================================
+// every workgroup takes a slab of groups; thread (sub, col) walks the groups sub, sub + nsub, ... of the slab for its channel(s) in a
+// fixed order and the nsub partial sums of a channel meet in LDS, again in a fixed order: deterministic, one partial row per workgroup
+#define RSUM_POOL_BLOCKS 1024
 __global__ __launch_bounds__(256) void pool_rsum_kernel(long groups, int ns, int c, const float* __restrict__ dPool, const int* __restrict__ arg,
                                                         const float* __restrict__ Y, int ldy, const float* __restrict__ scale,
                                                         const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ var,
                                                         float eps, float* __restrict__ part, long gpb) {
+    extern __shared__ float sred[];                       // [nsub][2][c]
+    const int cw = (c <= 256 && 256 % c == 0) ? c : 256;  // channels covered by one row of threads
+    const int nsub = 256 / cw;
+    const int sub = threadIdx.x / cw, lc = threadIdx.x % cw;
     const long g0 = blockIdx.x * gpb, g1 = min(groups, g0 + gpb);
-    for (int col = threadIdx.x; col < c; col += 256) {
+    for (int col = lc; col < c; col += cw) {
         const float sc = scale[col], sh = shift[col];
         const float rs = (float)(1.0 / sqrt((double)var[col] + (double)eps)), mr = -mean[col] * rs;
         float r0 = 0.f, r1 = 0.f;
-        for (long g = g0; g < g1; ++g) {
+        for (long g = g0 + sub; g < g1; g += nsub) {
             const float dp = dPool[g * c + col];
             const float yv = Y[(g * ns + arg[g * c + col]) * ldy + col];
             const float dyh = __builtin_fmaf(yv, sc, sh) > 0.f ? dp : 0.f;
             r0 += dyh;
             r1 = __builtin_fmaf(dyh, __builtin_fmaf(yv, rs, mr), r1);
         }
-        part[(size_t)blockIdx.x * 2 * c + col] = r0;
-        part[(size_t)blockIdx.x * 2 * c + c + col] = r1;
+        sred[(sub * 2 + 0) * c + col] = r0;
+        sred[(sub * 2 + 1) * c + col] = r1;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * c; i += 256) {
+        float v = 0.f;
+        for (int q = 0; q < nsub; ++q) v += sred[(size_t)q * 2 * c + i];
+        part[(size_t)blockIdx.x * 2 * c + i] = v;
     }
 }
-#define RSUM_POOL_BLOCKS 256
-// partial sums [nparts][2][c] of (dyh, dyh*xhat) for the top layer of a pooled stack; returns nparts through *nparts_out.
-// part: at least gspn_rsum_part_floats(c) floats.
+// floats of a partial-sum buffer [nparts][2][c] large enough for gspn_pool_rsum and for pass B's epilogue (one row per workgroup)
 extern "C" long gspn_rsum_part_floats(long rows, int c) {
     if (c <= 0) return GSPN_ERR_ARG;
-    long n = row_grid(rows > 0 ? rows : 1, 1, 4);            // what pass B's epilogue needs at most (one row of partials per workgroup)
+    long n = row_grid(rows > 0 ? rows : 1, 1, 4);
     if (n < RSUM_POOL_BLOCKS) n = RSUM_POOL_BLOCKS;
     return n * 2 * c;
 }
@@ -1874,8 +1885,9 @@ extern "C" int gspn_pool_rsum(long groups, int ns, int c, const float* dPool, co
     long nblk = groups < RSUM_POOL_BLOCKS ? groups : RSUM_POOL_BLOCKS;
     const long gpb = (groups + nblk - 1) / nblk;
     nblk = (groups + gpb - 1) / gpb;
-    hipLaunchKernelGGL(pool_rsum_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, groups, ns, c, dPool, arg, Y, ldy, scale, shift, mean, var,
-                       eps, part, gpb);
+    const int cw = (c <= 256 && 256 % c == 0) ? c : 256;
+    hipLaunchKernelGGL(pool_rsum_kernel, dim3((unsigned)nblk), dim3(256), sizeof(float) * 2 * c * (256 / cw), (hipStream_t)stream, groups, ns, c, dPool, arg, Y, ldy,
+                       scale, shift, mean, var, eps, part, gpb);
     *nparts_out = (int)nblk;
     return gspn_launch_status();
 }
