@@ -79,6 +79,11 @@ def main():
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d): the line would report n_gpus != --gpus" % (world, args.gpus))
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    # diagnostic knobs (not the default): stream priorities of the layers' stream / the geometry streams
+    MAIN_PRIO = os.environ.get("GSPN_BENCH_MAIN_PRIO")
+    GEO_PRIO = int(os.environ.get("GSPN_BENCH_GEO_PRIO", "0"))
+    if MAIN_PRIO is not None:
+        torch.cuda.set_stream(torch.cuda.Stream(dev, priority=int(MAIN_PRIO)))
 
     # inputs resident in HBM before the timed region; rank r owns scenes [8r, 8r+8) of the global batch; NB distinct batches rotate
     # (NB = 3 slots: the layers of step i read slot i%3 while the geometry of steps i+1 and i+2 is being written into the other two)
@@ -107,7 +112,7 @@ def main():
 
     store = tf_util.set_variable_store(tf_util.VariableStore(device=dev, seed=1234))   # same weights on every rank
     state = {"bucket": None, "opt": None, "i": 0, "pend": None, "t_wait": 0.0}
-    geo = None if args.no_overlap else [GeometryStream(dev) for _ in range(DEPTH)]     # (default priority: a high-priority geometry queue starves the layers, 3.7 -> 8.1 ms per step)
+    geo = None if args.no_overlap else [GeometryStream(dev, priority=GEO_PRIO) for _ in range(DEPTH)]     # (default priority: a high-priority geometry queue starves the layers, 3.7 -> 8.1 ms per step)
     use_graph = geo is not None and not args.no_graph
     pend = {}                   # step index -> PendingGeometry
     done = {}                   # step index -> event after its layers + optimiser step

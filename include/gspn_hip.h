@@ -16,7 +16,7 @@
  * entry points zero their output themselves (stream-ordered), replacing the reference's
  * cudaMemset calls (tf_sampling.cpp:174, tf_grouping.cpp:234,307, tf_nndistance_g.cu:153-154).
  * All pointers are device pointers; tensors are dense row-major float32 / int32.
- * Thread safety: the library holds no mutable global state (tuning knobs are read from the environment once, on first use).
+ * Thread safety: the library holds no mutable global state (its tuning hooks only READ the environment).
  */
 #ifndef GSPN_HIP_H
 #define GSPN_HIP_H
