@@ -87,7 +87,13 @@ def main():
 
     # inputs resident in HBM before the timed region; rank r owns scenes [8r, 8r+8) of the global batch; NB distinct batches rotate
     # (NB = 3 slots: the layers of step i read slot i%3 while the geometry of steps i+1 and i+2 is being written into the other two)
-    NB = 3
+    # PAIRED (default): the geometry of two consecutive steps is submitted TOGETHER, on the two side streams, every other step, so the
+    # two 8-CU FPS kernels run side by side and the chip is free of geometry work for the rest of the two steps.  A resident FPS
+    # workgroup slows the layers' kernels chip-wide while it runs and that cost saturates in the number of busy
+    # workgroups -- so the same work packed into half the time costs the layers less (measured: +0.31 -> +0.21 ms per step for FPS
+    # of SA level 1 alone).  Needs 4 batch slots instead of 3; every step still gets exactly one geometry pass of its own batch.
+    PAIRED = os.environ.get('GSPN_BENCH_PAIRED', '1') != '0'
+    NB = int(os.environ.get('GSPN_BENCH_NB', '4' if PAIRED else '3'))
     DEPTH = int(os.environ.get('GSPN_BENCH_DEPTH', '2'))                   # geometry runs this many steps ahead, on DEPTH side streams (FPS throughput: one CU per scene per stream)
     batches = []
     for k in range(NB):
@@ -174,6 +180,14 @@ def main():
         def part(x):
             if "fps0" in SIDE:
                 tf_sampling.farthest_point_sample(2048, x)
+            if "fps32alt" in SIDE and i % 4 == 0:          # four batches' FPS in one launch every fourth step
+                if "xyz32" not in state:
+                    state["xyz32"] = torch.cat([batches[0][0], batches[1][0], batches[2][0], batches[0][0]], 0).contiguous()
+                tf_sampling.farthest_point_sample(2048, state["xyz32"])
+            if "fps16alt" in SIDE and i % 2 == 0:          # two batches' FPS in ONE launch every other step (same work per step, half the busy time)
+                if "xyz16" not in state:
+                    state["xyz16"] = torch.cat([batches[0][0], batches[1][0]], 0).contiguous()
+                tf_sampling.farthest_point_sample(2048, state["xyz16"])
             if "rest" in SIDE:
                 l1 = G[kj]["sa"][0].new_xyz
                 query_ball_point(0.2, 32, x, l1)
@@ -214,6 +228,8 @@ def main():
             return
         geo[i % DEPTH].submit(part, xyz)
 
+    if PAIRED and DEPTH != 2:
+        raise SystemExit("GSPN_BENCH_PAIRED needs GSPN_BENCH_DEPTH=2")
     if geo is not None and not LAYERS_ONLY:
         for j in range(DEPTH):
             submit_geometry(j)
@@ -230,7 +246,9 @@ def main():
             g = pend.pop(i).get(host_wait=True)               # geometry of THIS step (submitted DEPTH steps ago: long complete)
             state["t_wait"] += time.perf_counter() - tw
         if use_graph:
+            th = time.perf_counter()
             graphs[k].replay()
+            state["t_replay"] = state.get("t_replay", 0.0) + time.perf_counter() - th
         else:
             if state["opt"] is not None:
                 state["opt"].zero_grad(set_to_none=True)      # backward assigns fresh grads; the bucket re-points them at its slices
@@ -241,11 +259,33 @@ def main():
             # of slot (i+DEPTH) % NB = (i-1) % NB, which the layers of step i-1 read: the HOST waits for that step (step i is already
             # queued behind it, so the GPU never idles) instead of making the side stream wait on the layers' stream.
             done[i] = torch.cuda.current_stream().record_event()
-            if (i - 1) in done:
-                tw = time.perf_counter()
-                done.pop(i - 1).synchronize()
-                state["t_wait"] += time.perf_counter() - tw
-            submit_geometry(i + DEPTH)
+            if PAIRED:
+                # even steps submit the geometry of steps i+2 and i+3 at once (slots (i+2)%4 and (i-1)%4, last read by steps i-2 and i-1)
+                if i % 2 == 0:
+                    if (i - 1) in done:
+                        tw = time.perf_counter()
+                        done.pop(i - 1).synchronize()
+                        state["t_wait"] += time.perf_counter() - tw
+                    done.pop(i - 2, None)
+                    submit_geometry(i + 2)
+                    submit_geometry(i + 3)
+            else:
+                if (i - 1) in done:
+                    tw = time.perf_counter()
+                    done.pop(i - 1).synchronize()
+                    state["t_wait"] += time.perf_counter() - tw
+                submit_geometry(i + DEPTH)
+
+    fps_done, bq_done = [], []        # (ms, meta...) of launches whose events have completed
+
+    def drain_events(final=False):
+        """turn completed event pairs into numbers and drop the events: hundreds of live HIP events slow every later launch on the host"""
+        for mod, dst in ((tf_sampling, fps_done), (tf_grouping, bq_done)):
+            src = mod.PROFILE
+            while src and (final or (len(src) > 4 and src[0][1].query())):
+                e = src.pop(0)
+                dst.append((e[0].elapsed_time(e[1]),) + tuple(e[2:]))
+                mod.EVENT_POOL += [e[0], e[1]]            # reused by later launches (no event is created or destroyed in steady state)
 
     for _ in range(args.warmup):
         step()
@@ -255,27 +295,35 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    tf_sampling.PROFILE = []          # HIP-event pairs around every FPS launch on its stream
-    tf_grouping.PROFILE = []          # ... and around every ball-query launch
+    if os.environ.get("GSPN_BENCH_NOPROFILE") != "1":      # (diagnostic switch: no per-launch events)
+        tf_sampling.PROFILE_MIN_N = NPOINTS   # (the roofline kernel only: SA level 1)
+        PSTEPS = int(os.environ.get("GSPN_BENCH_PROFILE_STEPS", "24"))     # steps of the timed region whose FPS / ball-query launches are bracketed
+        tf_sampling.PROFILE_BUDGET[0] = PSTEPS
+        tf_grouping.PROFILE_BUDGET[0] = 3 * PSTEPS
+        tf_sampling.PROFILE = []          # HIP-event pairs around every FPS launch on its stream
+        tf_grouping.PROFILE = []          # ... and around every ball-query launch
     sync()
     state["t_wait"] = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+        if tf_sampling.PROFILE is not None:
+            drain_events()
     t_host = time.perf_counter() - t0 - state["t_wait"]   # host time to enqueue the K steps, net of its waits on the GPU (launch-bound if close to dt)
     sync()
     dt = time.perf_counter() - t0
-    prof = tf_sampling.PROFILE
+    if tf_sampling.PROFILE is not None:
+        drain_events(final=True)
     tf_sampling.PROFILE = None
-    bq_prof = tf_grouping.PROFILE
     tf_grouping.PROFILE = None
+    prof, bq_prof = fps_done, bq_done
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
     # dominant kernel: FPS of SA level 1 (b=8, n=32768 -> m=2048), live HIP-event average over the timed region
-    fps_ms = [e0.elapsed_time(e1) for (e0, e1, b, n, m) in prof if n == NPOINTS]
+    fps_ms = [ms for (ms, b, n, m) in prof if n == NPOINTS]
     b, n, m = SCENES_PER_GPU, NPOINTS, 2048
     alg_bytes = 20.0 * b * (m - 1) * n + 4.0 * b * m            # 20 B/point/round + the index output
     fps_avg_ms = float(np.mean(fps_ms)) if fps_ms else float("nan")
@@ -307,7 +355,8 @@ def main():
             "data": "synthetic" if not LAYERS_ONLY else "DIAGNOSTIC RUN, NOT A RESULT: geometry skipped (GSPN_BENCH_LAYERS_ONLY)",
             "config": {"workload": "BASELINE configs[2]: batch 8 x 32768-pt scenes per GPU, 3-level SA + 3-level FP (three_nn/interpolate) fwd+bwd, "
                                    "pn2_fea_extractor layer spec, BN training mode, Adam step", "scenes_per_gpu": SCENES_PER_GPU,
-                       "schedule": "geometry inline" if args.no_overlap else ("geometry of batches k+1, k+2 on two side streams under the layers of batch k"
+                       "schedule": "geometry inline" if args.no_overlap else (("geometry of batches k+2, k+3 submitted together every other step on two side streams under the layers of batches k, k+1"
+                                                                                if PAIRED else "geometry of batches k+1, k+2 on two side streams under the layers of batch k")
                                                                                + ("; fwd+bwd replayed from a hipGraph" if use_graph else "")),
                        "global_batch": global_batch, "npoints": NPOINTS, "parallelism": "dp%d (scenes sharded, one flat RCCL grad all-reduce)%s" % (world, "; SyncBN" if args.sync_bn else "")},
             # SURVEY 8(d)'s yardstick: `achieved` = ALGORITHMIC bytes (what the reference's kernel moves: 20 B per point per round) / time.
@@ -318,6 +367,8 @@ def main():
                          "achieved_is": "effective rate = algorithmic bytes / time (the kernel is on-chip resident; see traffic)",
                          "avg_launch_ms": fps_avg_ms, "us_per_pick": fps_avg_ms * 1e3 / m, "launches_timed": len(fps_ms)},
             "host_enqueue_ms_per_step": t_host / args.steps * 1e3,
+            "host_wait_ms_per_step": state["t_wait"] / args.steps * 1e3,
+            "host_replay_ms_per_step": state.get("t_replay", 0.0) / (args.steps + args.warmup) * 1e3,
         }
         if world == 1 and not LAYERS_ONLY and not args.no_extra:
             torch.cuda.synchronize()
@@ -356,7 +407,7 @@ def ball_query_roofline(bq_prof, batches, G):
         _, _, visited = O.query_ball_point(radius, ns, cur, new, return_visited=True, mt=True)
         sum_l = float(visited.astype(np.int64).sum())
         alg = 12.0 * sum_l + 12.0 * bsz * npoint + 4.0 * bsz * npoint * (ns + 1)
-        ms = [e0.elapsed_time(e1) for (e0, e1, b_, n_, m_, r_, ns_) in bq_prof if n_ == n and m_ == npoint]
+        ms = [t for (t, b_, n_, m_, r_, ns_) in bq_prof if n_ == n and m_ == npoint]
         avg = float(np.mean(ms)) if ms else float("nan")
         ach = alg / (avg * 1e-3) / 1e9
         out.append({"level": "SA%d" % (lvl + 1), "n": n, "m": npoint, "radius": radius, "nsample": ns, "avg_launch_ms": avg, "launches_timed": len(ms),

@@ -6,6 +6,8 @@ from . import _lib as L
 # bench.py sets this to a list to collect (start_event, end_event, b, n, m, radius, nsample) around every ball-query launch, recorded
 # on the stream the kernel is launched on
 PROFILE = None
+EVENT_POOL = []            # timing events handed back by the consumer of PROFILE: creating / destroying HIP events in a hot loop costs the host
+PROFILE_BUDGET = [1 << 30]  # launches still to be bracketed: event pairs cost host time (on ROCm 7.2 the cost per pair grows with the pairs already recorded), so bench.py brackets the first 24 steps only
 
 
 def query_ball_point(radius, nsample, xyz1, xyz2):
@@ -29,9 +31,11 @@ def query_ball_point(radius, nsample, xyz1, xyz2):
     cnt = torch.empty((b, m), dtype=torch.int32, device=xyz1.device)
     with torch.cuda.device(xyz1.device):
         ev = None
-        if PROFILE is not None:
-            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        if PROFILE is not None and PROFILE_BUDGET[0] > 0:
+            ev = (EVENT_POOL.pop() if EVENT_POOL else torch.cuda.Event(enable_timing=True),
+                      EVENT_POOL.pop() if EVENT_POOL else torch.cuda.Event(enable_timing=True))
             ev[0].record()
+            PROFILE_BUDGET[0] -= 1
         L.check(L.lib().gspn_queryballpoint(b, n, m, radius, nsample, L.ptr(xyz1), L.ptr(xyz2), L.ptr(idx), L.ptr(cnt), L.stream()),
                 "query_ball_point")
         if ev is not None:

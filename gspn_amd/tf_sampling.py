@@ -9,6 +9,9 @@ from . import _lib as L
 # bench.py sets this to a list to collect (start_event, end_event, b, n, m) around every FPS launch,
 # recorded on the stream the kernel is launched on (roofline.achieved is measured live from these)
 PROFILE = None
+EVENT_POOL = []            # timing events handed back by the consumer of PROFILE: creating / destroying HIP events in a hot loop costs the host
+PROFILE_BUDGET = [1 << 30]  # launches still to be bracketed: event pairs cost host time (on ROCm 7.2 the cost per pair grows with the pairs already recorded), so bench.py brackets the first 24 steps only
+PROFILE_MIN_N = 0          # only launches with at least this many points per scene are bracketed
 
 
 # 'cells' (default): HIP spatial pre-pass + fps_cell_kernel (batched, culled; identical output) for n >= FPS_CELLS_MIN_N;
@@ -63,9 +66,11 @@ def farthest_point_sample(npoint, inp):
 
         def tic():
             nonlocal ev
-            if PROFILE is not None:           # events around the sampling kernel alone (the pre-pass is 3 % of the call)
-                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            if PROFILE is not None and PROFILE_BUDGET[0] > 0 and n >= PROFILE_MIN_N:           # events around the sampling kernel alone (the pre-pass is 3 % of the call)
+                ev = (EVENT_POOL.pop() if EVENT_POOL else torch.cuda.Event(enable_timing=True),
+                      EVENT_POOL.pop() if EVENT_POOL else torch.cuda.Event(enable_timing=True))
                 ev[0].record()
+                PROFILE_BUDGET[0] -= 1
 
         if n > 32768 or FPS_MULTI_FORCE:
             # several CUs per scene (sampling_multi.hip); the reference's kernel takes any n (tf_sampling_g.cu:137-141)
