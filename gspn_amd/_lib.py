@@ -46,6 +46,7 @@ SIGNATURES = {
     "gspn_scatteraddpoint": [_I, _I, _I, _P, _P, _P, _P],
     "gspn_probsample": [_I, _I, _I, _P, _P, _P, _P, _P],
     "gspn_queryballpoint": [_I, _I, _I, _F, _I, _P, _P, _P, _P, _P],
+    "gspn_queryballpoint_lds": [_I, _I, _I, _F, _I, _P, _P, _P, _P, _P],
     "gspn_selectionsort": [_I, _I, _I, _I, _P, _P, _P, _P],
     "gspn_knn_point": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
     "gspn_grouppoint": [_I, _I, _I, _I, _I, _P, _P, _P, _P],

@@ -86,6 +86,11 @@ int gspn_probsample(int b, int n, int m, const float* inp_p, const float* inp_r,
  * tf_grouping_g.cu:186-189.  Rows without any hit are zero-filled (uninitialised in the reference). */
 int gspn_queryballpoint(int b, int n, int m, float radius, int nsample, const float* xyz1, const float* xyz2,
                         int* idx, int* pts_cnt, void* stream);
+/* Same output through LDS-staged point tiles shared by the 8 queries of a workgroup (the shape BASELINE.json's north_star sketches).
+ * A measured alternative, not what the Python surface calls: with the reference's early exit the queries of a workgroup need very
+ * different prefixes of the cloud, and the scene is L2-resident anyway (DESIGN.md 4.2 has the numbers). */
+int gspn_queryballpoint_lds(int b, int n, int m, float radius, int nsample, const float* xyz1, const float* xyz2,
+                            int* idx, int* pts_cnt, void* stream);
 
 /* Host helper (no GPU work): the squared-distance threshold T the ball-query kernel compares against,
  * i.e. the smallest float with sqrtf(T) >= radius, so that  s < T  <=>  max(sqrtf(s),1e-20f) < radius
