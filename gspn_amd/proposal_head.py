@@ -8,6 +8,8 @@ import torch
 
 from . import tf_util
 from .mlp import mlp_stack
+from . import pointnet_util as PU
+from .geometry import SAGeometry, sa_front
 from .pointnet_util import _mlp_layers, group_concat
 from .tf_grouping import group_point, query_ball_point
 from .tf_nndistance import nn_distance
@@ -27,12 +29,20 @@ def multi_encoding_net(xyz, points, npoint, radius_list, nsample_list, mlp_list,
         for i in range(len(radius_list)):
             radius, nsample = radius_list[i], nsample_list[i]
             idx, pts_cnt = query_ball_point(radius, nsample, xyz, new_xyz)      # :53
+            pooled = None
             if shift_pred is None and (points is None or use_xyz) and not xyz.requires_grad:
-                # fused: concat([points[idx], xyz[idx] - new_xyz]) written straight into the MLP's input matrix (:54-63)
-                rows = group_concat(xyz, new_xyz, points, idx, xyz_first=False)
                 c = 0 if points is None else points.shape[2]
                 cin = c + 3
-                gcols = (0, c) if c > 0 else None                               # the xyz columns carry no gradient
+                if PU.FUSE_SA_FRONT and points is not None and len(mlp_list[i]) >= 2:
+                    # fused front end (features FIRST here, :61): the grouped tensor is never written, the first conv gathers its rows
+                    rel, gidx = sa_front(xyz.detach(), new_xyz.detach(), idx)
+                    geo = SAGeometry(new_xyz, idx, pts_cnt, npoint, nsample, None, None, rel, gidx)
+                    layers = _mlp_layers(mlp_list[i], cin, 'conv_prev_%d_' % i, bn)
+                    pooled = PU._sa_stack_gathered(points, geo, False, cin, layers, is_training, bn_decay, nsample)
+                if pooled is None:
+                    # fused: concat([points[idx], xyz[idx] - new_xyz]) written straight into the MLP's input matrix (:54-63)
+                    rows = group_concat(xyz, new_xyz, points, idx, xyz_first=False)
+                    gcols = (0, c) if c > 0 else None                           # the xyz columns carry no gradient
             else:
                 grouped_xyz = group_point(xyz, idx) - new_xyz.unsqueeze(2)      # :54-55
                 if shift_pred is not None:
@@ -48,8 +58,9 @@ def multi_encoding_net(xyz, points, npoint, radius_list, nsample_list, mlp_list,
                 if cin % 4:
                     rows = torch.nn.functional.pad(rows, (0, 4 - cin % 4))
                 gcols = None
-            layers = _mlp_layers(mlp_list[i], cin, 'conv_prev_%d_' % i, bn)     # scopes conv_prev_%d_%d (:66)
-            pooled = mlp_stack(rows, cin, layers, bool(is_training), bn_decay, pool_ns=nsample, grad_cols=gcols)   # + reduce_max :68
+            if pooled is None:
+                layers = _mlp_layers(mlp_list[i], cin, 'conv_prev_%d_' % i, bn)     # scopes conv_prev_%d_%d (:66)
+                pooled = mlp_stack(rows, cin, layers, bool(is_training), bn_decay, pool_ns=nsample, grad_cols=gcols)   # + reduce_max :68
             new_points_list.append(pooled.view(b, npoint, mlp_list[i][-1]))
         new_points = torch.cat(new_points_list, dim=-1)                         # :69
         for i, num_out_channel in enumerate(mlp_list2):
