@@ -106,3 +106,30 @@ def test_fps_multi_status_word_is_clean():
     out = torch.empty((b, m), dtype=torch.int32, device="cuda")
     L.check(L.lib().gspn_farthestpointsampling_multi(b, n, m, 0, L.ptr(t), L.ptr(ws), L.ptr(out), L.stream()), "fps multi")
     assert L.lib().gspn_fps_multi_status(L.ptr(ws), b, n, L.stream()) == 0
+
+
+def test_fps_multi_random_shapes(monkeypatch):
+    """seeded sweep over scene size, sample count, workgroup count and cloud kind (uniform / duplicated points / coarse lattice with ties
+    everywhere / clustered): every combination index-exact against the oracle"""
+    rng = np.random.default_rng(2024)
+    for trial in range(24):
+        n = int(rng.integers(40, 60000))
+        m = int(rng.integers(1, min(n + 50, 1500)))
+        b = int(rng.integers(1, 4))
+        gmin = (n + 32767) // 32768
+        G = int(rng.integers(gmin, min(32, gmin + 9) + 1))
+        kind = trial % 4
+        if kind == 0:
+            xyz = rng.random((b, n, 3), dtype=np.float32)
+        elif kind == 1:
+            xyz = rng.random((b, n, 3), dtype=np.float32)
+            k = n // 3
+            xyz[:, n - k:] = xyz[:, :k]                                   # a third of the points are duplicates
+        elif kind == 2:
+            xyz = (rng.integers(0, 7, size=(b, n, 3)) / 4.0).astype(np.float32)      # <= 343 distinct points: ties and the degenerate tail
+        else:
+            centres = rng.random((b, 5, 3)).astype(np.float32)
+            xyz = (centres[:, rng.integers(0, 5, size=n)] + 0.02 * rng.standard_normal((b, n, 3))).astype(np.float32)
+        ref = O.farthest_point_sample(m, xyz, mt=True)
+        got = multi_fps(m, np.ascontiguousarray(xyz), G, monkeypatch)
+        np.testing.assert_array_equal(got, ref, err_msg="trial %d: b=%d n=%d m=%d G=%d kind=%d" % (trial, b, n, m, G, kind))

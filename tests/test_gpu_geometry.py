@@ -313,3 +313,24 @@ def test_ball_query_lds_variant_is_identical(kind, b, n, m, r, ns):
     L.check(L.lib().gspn_queryballpoint_lds(b, n, m, r, ns, L.ptr(tx), L.ptr(tq), L.ptr(idx), L.ptr(cnt), L.stream()), "ball lds")
     np.testing.assert_array_equal(cnt.cpu().numpy(), rcnt)
     np.testing.assert_array_equal(idx.cpu().numpy(), ridx)
+
+
+def test_knn_direct_random_shapes():
+    """seeded sweep of knn_point (direct kernel) over sizes, k and tie-heavy lattices against the oracle's dense construction"""
+    from gspn_amd.tf_grouping import knn_point
+    rng = np.random.default_rng(77)
+    for trial in range(20):
+        n = int(rng.integers(33, 3000))
+        m = int(rng.integers(1, 200))
+        k = int(rng.integers(1, min(32, n) + 1))
+        b = int(rng.integers(1, 3))
+        if trial % 2:
+            x1 = rng.integers(0, 4, size=(b, n, 3)).astype(np.float32)
+            x2 = rng.integers(0, 4, size=(b, m, 3)).astype(np.float32)
+        else:
+            x1 = rng.random((b, n, 3), dtype=np.float32)
+            x2 = rng.random((b, m, 3), dtype=np.float32)
+        v, i = knn_point(k, dev(x1), dev(x2))
+        rv, ri = O.knn_point(k, x1, x2)
+        np.testing.assert_array_equal(i.cpu().numpy(), ri, err_msg="trial %d n=%d m=%d k=%d" % (trial, n, m, k))
+        np.testing.assert_array_equal(v.cpu().numpy(), rv)
