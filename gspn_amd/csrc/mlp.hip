@@ -39,12 +39,15 @@ __device__ __forceinline__ float act1(float v, bool act, float sc, float sh) {
 
 #define MAXCH GSPN_MLP_MAX_CHANNELS      // (1024) per-channel constants are staged in LDS for layers up to this many channels (the 4-level networks of
                         // model_rpointnet.py:109,181 feed fa_layer1 with 256 + 512 = 768 input channels)
-// fill dst[0..MAXCH) with src[0..n) (or `dflt` when src is NULL / beyond n); callers __syncthreads() afterwards
-__device__ __forceinline__ void stage_chan(float* dst, const float* __restrict__ src, int n, float dflt) {
-    for (int i = threadIdx.x; i < MAXCH; i += blockDim.x) dst[i] = (src && i < n) ? src[i] : dflt;
+// The staged constants live in DYNAMIC shared memory sized for the layer at hand (cpad = chan_pad(channels) floats per array): fixed
+// MAXCH-sized arrays cost pass B 20 KB of LDS and a workgroup per CU of occupancy when the limit went from 512 to 1024 channels.
+static inline int chan_pad(int c) { return (c + 3) / 4 * 4 + 4; }
+// fill dst[0..cpad) with src[0..n) (or `dflt` when src is NULL / beyond n); callers __syncthreads() afterwards
+__device__ __forceinline__ void stage_chan(float* dst, const float* __restrict__ src, int n, float dflt, int cpad) {
+    for (int i = threadIdx.x; i < cpad; i += blockDim.x) dst[i] = (src && i < n) ? src[i] : dflt;
 }
-__device__ __forceinline__ float4 lds4(const float* p, int k) {      // 4 consecutive constants, index clamped
-    return make_float4(p[min(k, MAXCH - 1)], p[min(k + 1, MAXCH - 1)], p[min(k + 2, MAXCH - 1)], p[min(k + 3, MAXCH - 1)]);
+__device__ __forceinline__ float4 lds4(const float* p, int k, int cpad) {      // 4 consecutive constants, index clamped
+    return make_float4(p[min(k, cpad - 1)], p[min(k + 1, cpad - 1)], p[min(k + 2, cpad - 1)], p[min(k + 3, cpad - 1)]);
 }
 
 // ---- 4-wide row-segment loads --------------------------------------------------------------------------------
@@ -220,12 +223,15 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(long rows, int cin, int co
     __shared__ __attribute__((aligned(16))) float sA[TK * LDT];
     __shared__ __attribute__((aligned(16))) float sB[TK * LDB];
     __shared__ float sRed[2 * 4 * BN];
-    __shared__ float sSc[MAXCH], sSh[MAXCH];
+    extern __shared__ __attribute__((aligned(16))) float s_chan[];         // [2][cpad]
+    const int cpad = (cin + 3) / 4 * 4 + 4;
+    float* sSc = s_chan;
+    float* sSh = s_chan + cpad;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int n0 = blockIdx.y * BN;
     const bool act = in_scale != nullptr;
-    stage_chan(sSc, in_scale, cin, 1.f);
-    stage_chan(sSh, in_shift, cin, 0.f);
+    stage_chan(sSc, in_scale, cin, 1.f, cpad);
+    stage_chan(sSh, in_shift, cin, 0.f, cpad);
     __syncthreads();
     const long ntiles = (rows + TM - 1) / TM;
     const int nchunks = (cin + TK - 1) / TK;
@@ -260,8 +266,8 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(long rows, int cin, int co
         const long m0 = f_tile * TM;
         const int k = f_c * TK + kq;
         Chan4 ch;
-        ch.sc = lds4(sSc, k);
-        ch.sh = lds4(sSh, k);
+        ch.sc = lds4(sSc, k, cpad);
+        ch.sh = lds4(sSh, k, cpad);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float4 v = act4(ra[i], act, ch, k, cin, (m0 + arow + 32 * i) < rows);
@@ -618,7 +624,8 @@ static inline int pick_bn(long rows, int cols, const char* env) {
 }
 // number of row-blocks (= partial-statistics rows) the forward launch of a (rows, cout) layer uses
 // (workgroups per CU = what the kernel's LDS footprint lets reside at once: a persistent grid larger than that runs a second wave)
-static inline unsigned fwd_blocks(long rows, int cout) { return row_grid(rows, cout <= 64 ? 1 : (cout + 127) / 128, cout <= 64 ? 4 : 3); }
+static inline int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+static inline unsigned fwd_blocks(long rows, int cout) { return row_grid(rows, cout <= 64 ? 1 : (cout + 127) / 128, cout <= 64 ? 4 : env_int("GSPN_FWD_WIDE_BPC", 3)); }
 extern "C" long gspn_mlp_fwd_stats_bytes(long rows, int cout) {
     if (rows < 0 || cout <= 0) return GSPN_ERR_ARG;
     return (long)sizeof(float) * 2 * cout * (long)fwd_blocks(rows > 0 ? rows : 1, cout);
@@ -690,7 +697,7 @@ static int mlp_fwd_impl(long rows, int cin, int cout, const float* X, int ldx, c
     if (gsrc) return GSPN_ERR_UNSUPPORTED;
     const bool v = vec_ok(X, ldx) && vec_ok(W, cout);
 #define FWD_LAUNCH(BN_, V_, YT_)                                                                                                   \
-    hipLaunchKernelGGL((mlp_fwd_kernel<BN_, V_>), dim3(fwd_blocks(rows, cout), YT_), dim3(256), 0, st, rows, cin, cout, X, ldx, \
+    hipLaunchKernelGGL((mlp_fwd_kernel<BN_, V_>), dim3(fwd_blocks(rows, cout), YT_), dim3(256), sizeof(float) * 2 * chan_pad(cin), st, rows, cin, cout, X, ldx, \
                        in_scale, in_shift, W, bias, Y, ldy, stats, po)
     const int bn = pick_bn(rows, cout, "GSPN_FWD_FORCE_BN");
     const int yt = (cout + bn - 1) / bn;
@@ -894,12 +901,15 @@ __global__ __launch_bounds__(256) void mlp_bwd_wgrad_kernel(long rows, int cin, 
     __shared__ __attribute__((aligned(16))) float sA[TKW * LDAW];     // [k=row][m=cin]
     __shared__ __attribute__((aligned(16))) float sB[TKW * LDB];      // [k=row][n=cout]  dyh
     __shared__ __attribute__((aligned(16))) float sX[WANT_GX ? TKW * LDB : 4];   // [k=row][n=cout]  xhat
-    __shared__ float sSc[MAXCH], sSh[MAXCH];
+    extern __shared__ __attribute__((aligned(16))) float s_chan[];         // [2][cpad]
+    const int cpad = (cin + 3) / 4 * 4 + 4;
+    float* sSc = s_chan;
+    float* sSh = s_chan + cpad;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.z * BN;
     const bool act = in_scale != nullptr;
-    stage_chan(sSc, in_scale, cin, 1.f);
-    stage_chan(sSh, in_shift, cin, 0.f);
+    stage_chan(sSc, in_scale, cin, 1.f, cpad);
+    stage_chan(sSh, in_shift, cin, 0.f, cpad);
     __syncthreads();
     const long r_begin = blockIdx.x * rows_per_chunk;
     const long r_end = r_begin + rows_per_chunk < rows ? r_begin + rows_per_chunk : rows;
@@ -952,8 +962,8 @@ __global__ __launch_bounds__(256) void mlp_bwd_wgrad_kernel(long rows, int cin, 
             const int f = t + 256 * i;
             const int kk = f / AQ, mq = (f - kk * AQ) * 4;
             Chan4 cha;
-            cha.sc = lds4(sSc, m0 + mq);
-            cha.sh = lds4(sSh, m0 + mq);
+            cha.sc = lds4(sSc, m0 + mq, cpad);
+            cha.sh = lds4(sSh, m0 + mq, cpad);
             *reinterpret_cast<float4*>(sA + kk * LDAW + mq) = act4(ra[i], act, cha, m0 + mq, cin, (k0 + kk) < r_end);
         }
 #pragma unroll
@@ -1804,7 +1814,7 @@ static int wgrad_impl(long rows, int cin, int cout, const gspn_dy_args* a, const
         // any alignment / pool size: register-staged kernel with scalar loads, 128x128 tiles
         const dim3 grid((unsigned)p.nch, p.nrow, p.ncol);
 #define WG_ARGS rows, cin, cout, *a, X, ldx, in_scale, in_shift, mu, vr, eps, RP, GP, PP, p.rpc, (int)p.nslots
-#define WG_GO(G_, P_) hipLaunchKernelGGL((mlp_bwd_wgrad_kernel<4, 4, 32, false, G_, P_>), grid, dim3(256), 0, st, WG_ARGS)
+#define WG_GO(G_, P_) hipLaunchKernelGGL((mlp_bwd_wgrad_kernel<4, 4, 32, false, G_, P_>), grid, dim3(256), sizeof(float) * 2 * chan_pad(cin), st, WG_ARGS)
         if (tr) { if (pooled) WG_GO(true, true); else WG_GO(true, false); }
         else    { if (pooled) WG_GO(false, true); else WG_GO(false, false); }
 #undef WG_GO
@@ -2033,7 +2043,13 @@ __global__ __launch_bounds__(256) void mlp_bwd_data_kernel(long rows, int cin, i
     constexpr int NB = (TK / 4 * BN) / 256;      // float4 (along k) per thread per chunk
     __shared__ __attribute__((aligned(16))) float sA[TK * LDT];
     __shared__ __attribute__((aligned(16))) float sB[TK * LDBT];
-    __shared__ float sSc[MAXCH], sSh[MAXCH], sCA[MAXCH], sCB[MAXCH], sCC[MAXCH];
+    extern __shared__ __attribute__((aligned(16))) float s_chan[];         // [5][cpad]: forward scale / shift, cA, cB, cC of the cout channels
+    const int cpad = (cout + 3) / 4 * 4 + 4;
+    float* sSc = s_chan;
+    float* sSh = s_chan + cpad;
+    float* sCA = s_chan + 2 * cpad;
+    float* sCB = s_chan + 3 * cpad;
+    float* sCC = s_chan + 4 * cpad;
     unsigned bx = blockIdx.x, gx = gridDim.x;
     if constexpr (DW) {
         if (bx < (unsigned)dwj.nblk) {
@@ -2047,11 +2063,11 @@ __global__ __launch_bounds__(256) void mlp_bwd_data_kernel(long rows, int cin, i
     const int n0 = col0 + blockIdx.y * BN;
     const long ntiles = (rows + TM - 1) / TM;
     const int nchunks = (cout + TK - 1) / TK;
-    stage_chan(sSc, a.scale, cout, 1.f);
-    stage_chan(sSh, a.shift, cout, 0.f);
-    stage_chan(sCA, a.cA, cout, 0.f);         // channels >= cout contribute dY = 0
-    stage_chan(sCB, a.cB, cout, 0.f);
-    stage_chan(sCC, a.cC, cout, 0.f);
+    stage_chan(sSc, a.scale, cout, 1.f, cpad);
+    stage_chan(sSh, a.shift, cout, 0.f, cpad);
+    stage_chan(sCA, a.cA, cout, 0.f, cpad);         // channels >= cout contribute dY = 0
+    stage_chan(sCB, a.cB, cout, 0.f, cpad);
+    stage_chan(sCC, a.cC, cout, 0.f, cpad);
     __syncthreads();
     const int kq = (t & 7) * 4;
     const int arow = t >> 3;
@@ -2082,7 +2098,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_data_kernel(long rows, int cin, i
         const long m0 = f_tile * TM;
         const int c = f_c;
         const int k = c * TK + kq;
-        const float4 q_sc = lds4(sSc, k), q_sh = lds4(sSh, k), q_a = lds4(sCA, k), q_b = lds4(sCB, k), q_c = lds4(sCC, k);
+        const float4 q_sc = lds4(sSc, k, cpad), q_sh = lds4(sSh, k, cpad), q_a = lds4(sCA, k, cpad), q_b = lds4(sCB, k, cpad), q_c = lds4(sCC, k, cpad);
         const float sc[4] = {q_sc.x, q_sc.y, q_sc.z, q_sc.w}, sh[4] = {q_sh.x, q_sh.y, q_sh.z, q_sh.w};
         const float cA[4] = {q_a.x, q_a.y, q_a.z, q_a.w}, cB[4] = {q_b.x, q_b.y, q_b.z, q_b.w}, cC[4] = {q_c.x, q_c.y, q_c.z, q_c.w};
 #pragma unroll
@@ -2231,10 +2247,10 @@ static int bwd_data_launch(long rows, int cin, int cout, const gspn_dy_args* a, 
     const unsigned extra = dwj ? (unsigned)dwj->nblk : 0u;
 #define BD_GO(BN_, V_, P_, YT_)                                                                                                       \
     do {                                                                                                                               \
-        const dim3 g(row_grid(rows, YT_, BN_ >= 128 ? 3 : 4) + extra, YT_);                                                            \
+        const dim3 g(row_grid(rows, YT_, BN_ >= 128 ? env_int("GSPN_BWD_WIDE_BPC", 3) : 4) + extra, YT_);                                                            \
         if (nparts_out) *nparts_out = (int)(g.x - extra);                                                                              \
-        if (dwj) hipLaunchKernelGGL((mlp_bwd_data_kernel<BN_, V_, P_, true>), g, dim3(256), 0, st, rows, cend, cout, *a, W, dX, ldx, col0, *dwj, rs);   \
-        else     hipLaunchKernelGGL((mlp_bwd_data_kernel<BN_, V_, P_, false>), g, dim3(256), 0, st, rows, cend, cout, *a, W, dX, ldx, col0, none, rs);  \
+        if (dwj) hipLaunchKernelGGL((mlp_bwd_data_kernel<BN_, V_, P_, true>), g, dim3(256), sizeof(float) * 5 * chan_pad(cout), st, rows, cend, cout, *a, W, dX, ldx, col0, *dwj, rs);   \
+        else     hipLaunchKernelGGL((mlp_bwd_data_kernel<BN_, V_, P_, false>), g, dim3(256), sizeof(float) * 5 * chan_pad(cout), st, rows, cend, cout, *a, W, dX, ldx, col0, none, rs);  \
     } while (0)
 #define BD_LAUNCH(BN_, V_, YT_) do { if (pooled) BD_GO(BN_, V_, true, YT_); else BD_GO(BN_, V_, false, YT_); } while (0)
     const int bn = pick_bn(rows, ncols, "GSPN_BWD_FORCE_BN");
