@@ -210,7 +210,9 @@ __global__ __launch_bounds__(FPS_T) void fps_resident_kernel(int n, int m, const
 //     barrier.  The degenerate tail (max min-distance == 0: every point already chosen or a
 //     duplicate of one) repeats the rank-minimal point, like the reference.
 // ============================================================================================
+#ifndef FPS_AMAX
 #define FPS_AMAX 6        // max picks accepted per round
+#endif
 #ifdef FPS_PROFILE
 __device__ long long g_cell_prof[32];
 __device__ int g_cell_waves[16 * 4];      // per wave of scene 0: {applies, refreshes, -, -}
