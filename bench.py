@@ -303,15 +303,30 @@ def main():
         tf_sampling.PROFILE = []          # HIP-event pairs around every FPS launch on its stream
         tf_grouping.PROFILE = []          # ... and around every ball-query launch
     sync()
+    # Python's cyclic collector: a full (generation 2) collection walks every live object -- 40-56 ms here, once per ~70 steps, i.e.
+    # +0.2..0.3 ms per step on a 100-200 step run and nothing on a 20-step one.  Collect now and move the survivors (modules, graphs,
+    # parameter objects) to the permanent generation: later collections only look at what the steps themselves allocate.
+    import gc
+    gc.collect()
+    gc.freeze()
     state["t_wait"] = 0.0
     t0 = time.perf_counter()
+    stamps = [] if os.environ.get("GSPN_BENCH_STEP_TIMES") == "1" else None      # (diagnostic: host clock after every step, the host trails the GPU by <= 2 steps)
     for _ in range(args.steps):
         step()
         if tf_sampling.PROFILE is not None:
             drain_events()
+        if stamps is not None:
+            stamps.append(time.perf_counter())
     t_host = time.perf_counter() - t0 - state["t_wait"]   # host time to enqueue the K steps, net of its waits on the GPU (launch-bound if close to dt)
     sync()
     dt = time.perf_counter() - t0
+    if stamps is not None and rank == 0:
+        w = 10
+        print("ms/step by window of %d steps: %s" % (w, " ".join("%.2f" % ((stamps[min(j + w, len(stamps)) - 1] - (stamps[j - 1] if j else t0)) / (min(j + w, len(stamps)) - j) * 1e3)
+                                                               for j in range(0, len(stamps), w))), file=sys.stderr)
+        d = sorted(((stamps[j] - (stamps[j - 1] if j else t0)) * 1e3, j) for j in range(len(stamps)))[-3:]
+        print("longest steps (ms, index): %s" % " ".join("%.2f@%d" % x for x in d), file=sys.stderr)
     if tf_sampling.PROFILE is not None:
         drain_events(final=True)
     tf_sampling.PROFILE = None

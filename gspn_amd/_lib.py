@@ -54,6 +54,7 @@ SIGNATURES = {
     "gspn_groupmaxpool": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     "gspn_groupmaxpool_grad": [_I, _I, _I, _I, _P, _P, _P, _P],
     "gspn_threenn": [_I, _I, _I, _P, _P, _P, _P, _P],
+    "gspn_threenn_ordered": [_I, _I, _I, _P, _P, _P, _P, _P, _P],
     "gspn_threeinterpolate": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
     "gspn_threeinterpolate_grad": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
     "gspn_fp_concat": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P],

@@ -21,7 +21,7 @@
 #define NN_Q 1
 #define NN_B 8             // candidates tested per branch: the rejection values of a batch are independent (ILP), one compare decides
 __global__ __launch_bounds__(NN_BLOCK) void three_nn_kernel(int b, int n, int m, const float* __restrict__ xyz1, const float* __restrict__ xyz2,
-                                                            float* __restrict__ dist, int* __restrict__ idx) {
+                                                            float* __restrict__ dist, int* __restrict__ idx, const int* __restrict__ order) {
     __shared__ float4 tile[NN_TILE + NN_B];
     __shared__ float tile_pm[NN_BLOCK / 64];
     const int scene = blockIdx.x % b;               // scene <-> XCD affinity for the sparse cloud
@@ -29,9 +29,10 @@ __global__ __launch_bounds__(NN_BLOCK) void three_nn_kernel(int b, int n, int m,
     float x1[NN_Q], y1[NN_Q], z1[NN_Q];
 #pragma unroll
     for (int u = 0; u < NN_Q; ++u) {
-        const int j = j0 + u * NN_BLOCK;
+        int j = j0 + u * NN_BLOCK;
         x1[u] = y1[u] = z1[u] = 0.f;
         if (j < n) {
+            if (order) j = order[(size_t)scene * n + j];        // thread t takes dense point order[t]: neighbours in space share a wave
             const float* q = xyz1 + ((size_t)scene * n + j) * 3;
             x1[u] = q[0]; y1[u] = q[1]; z1[u] = q[2];
         }
@@ -113,8 +114,9 @@ __global__ __launch_bounds__(NN_BLOCK) void three_nn_kernel(int b, int n, int m,
     }
 #pragma unroll
     for (int u = 0; u < NN_Q; ++u) {
-        const int j = j0 + u * NN_BLOCK;
+        int j = j0 + u * NN_BLOCK;
         if (j < n) {
+            if (order) j = order[(size_t)scene * n + j];
             float* od = dist + ((size_t)scene * n + j) * 3;
             int* oi = idx + ((size_t)scene * n + j) * 3;
             od[0] = b1[u]; od[1] = b2[u]; od[2] = b3[u];
@@ -127,7 +129,15 @@ extern "C" int gspn_threenn(int b, int n, int m, const float* xyz1, const float*
     if (b == 0 || n == 0) return 0;
     const long long blocks = (long long)b * ((n + NN_BLOCK * NN_Q - 1) / (NN_BLOCK * NN_Q));
     if (blocks > 0x7FFFFFFFll) return GSPN_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(three_nn_kernel, dim3((unsigned)blocks), dim3(NN_BLOCK), 0, (hipStream_t)stream, b, n, m, xyz1, xyz2, dist, idx);
+    hipLaunchKernelGGL(three_nn_kernel, dim3((unsigned)blocks), dim3(NN_BLOCK), 0, (hipStream_t)stream, b, n, m, xyz1, xyz2, dist, idx, (const int*)nullptr);
+    return gspn_launch_status();
+}
+extern "C" int gspn_threenn_ordered(int b, int n, int m, const float* xyz1, const float* xyz2, const int* order, float* dist, int* idx, void* stream) {
+    if (b < 0 || n < 0 || m < 0) return GSPN_ERR_ARG;
+    if (b == 0 || n == 0) return 0;
+    const long long blocks = (long long)b * ((n + NN_BLOCK * NN_Q - 1) / (NN_BLOCK * NN_Q));
+    if (blocks > 0x7FFFFFFFll) return GSPN_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(three_nn_kernel, dim3((unsigned)blocks), dim3(NN_BLOCK), 0, (hipStream_t)stream, b, n, m, xyz1, xyz2, dist, idx, order);
     return gspn_launch_status();
 }
 

@@ -19,7 +19,7 @@ def pn2_geometry(xyz):
         sa.append(g)
         cur = g.new_xyz
     l1, l2, l3 = sa[0].new_xyz, sa[1].new_xyz, sa[2].new_xyz
-    fp = [fp_geometry(l2, l3), fp_geometry(l1, l2), fp_geometry(xyz, l1)]
+    fp = [fp_geometry(l2, l3, sa[2].scan_order), fp_geometry(l1, l2, sa[1].scan_order), fp_geometry(xyz, l1, sa[0].scan_order)]
     return {"sa": sa, "fp": fp}
 
 

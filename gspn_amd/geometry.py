@@ -26,16 +26,18 @@ from .tf_sampling import farthest_point_sample, gather_point
 class SAGeometry:
     """new_xyz (b,npoint,3), idx (b,npoint,nsample) int32, pts_cnt (b,npoint) int32 or None (knn), plus the inverse lists the gradient
     of the grouping gathers through: order (b, npoint*nsample) int32 = grouped positions sorted by data-point index, offsets (b, n+1)."""
-    __slots__ = ("new_xyz", "idx", "pts_cnt", "npoint", "nsample", "order", "offsets", "rel", "gidx")
+    __slots__ = ("new_xyz", "idx", "pts_cnt", "npoint", "nsample", "order", "offsets", "rel", "gidx", "scan_order")
 
-    def __init__(self, new_xyz, idx, pts_cnt, npoint, nsample, order=None, offsets=None, rel=None, gidx=None):
+    def __init__(self, new_xyz, idx, pts_cnt, npoint, nsample, order=None, offsets=None, rel=None, gidx=None, scan_order=None):
         self.new_xyz, self.idx, self.pts_cnt, self.npoint, self.nsample = new_xyz, idx, pts_cnt, npoint, nsample
         self.order, self.offsets = order, offsets
         # fused SA front end (gspn_sa_rel): per grouped row its centred coordinates (b*npoint*nsample, 4) and its source row (int32)
         self.rel, self.gidx = rel, gidx
+        # spatial order of the INPUT cloud left behind by the FPS pre-pass ((b,n) int32 or None): fp_geometry scans in it
+        self.scan_order = scan_order
 
     def tensors(self):
-        return [t for t in (self.new_xyz, self.idx, self.pts_cnt, self.order, self.offsets, self.rel, self.gidx) if t is not None]
+        return [t for t in (self.new_xyz, self.idx, self.pts_cnt, self.order, self.offsets, self.rel, self.gidx, self.scan_order) if t is not None]
 
 
 def inverse_lists(idx2d, n):
@@ -78,7 +80,8 @@ def sa_front(xyz, new_xyz, idx):
 def sa_geometry(xyz, npoint, radius, nsample, knn=False, inverse=True, front=True):
     """pointnet_util.py:38-40: centres by FPS, neighbours by ball query (or kNN); front: also the coordinate half of the grouping."""
     xyz = xyz.detach()
-    new_xyz = gather_point(xyz, farthest_point_sample(npoint, xyz))
+    fps_idx, scan_order = farthest_point_sample(npoint, xyz, return_order=True)
+    new_xyz = gather_point(xyz, fps_idx)
     if knn:
         _, idx = knn_point(nsample, xyz, new_xyz)
         cnt = None
@@ -86,12 +89,13 @@ def sa_geometry(xyz, npoint, radius, nsample, knn=False, inverse=True, front=Tru
         idx, cnt = query_ball_point(radius, nsample, xyz, new_xyz)
     order, offsets = inverse_lists(idx.reshape(idx.shape[0], -1), xyz.shape[1]) if inverse else (None, None)
     rel, gidx = sa_front(xyz, new_xyz, idx) if front else (None, None)
-    return SAGeometry(new_xyz, idx, cnt, npoint, nsample, order, offsets, rel, gidx)
+    return SAGeometry(new_xyz, idx, cnt, npoint, nsample, order, offsets, rel, gidx, scan_order)
 
 
-def fp_geometry(xyz1, xyz2):
-    """pointnet_util.py:155-160: three nearest sparse points of every dense point and their normalised 1/d weights."""
-    dist, idx = three_nn(xyz1.detach(), xyz2.detach())
+def fp_geometry(xyz1, xyz2, scan_order=None):
+    """pointnet_util.py:155-160: three nearest sparse points of every dense point and their normalised 1/d weights.
+    scan_order: a spatial order of xyz1 (SAGeometry.scan_order of the level that sampled xyz1), see three_nn."""
+    dist, idx = three_nn(xyz1.detach(), xyz2.detach(), order=scan_order)
     # :157-160 -- dist = max(dist, 1e-10); norm = sum(1/dist); weight = (1/dist)/norm, in one kernel
     weight = torch.empty_like(dist)
     with torch.cuda.device(dist.device):

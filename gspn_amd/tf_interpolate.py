@@ -4,9 +4,12 @@ import torch
 from . import _lib as L
 
 
-def three_nn(xyz1, xyz2):
+def three_nn(xyz1, xyz2, order=None):
     """tf_interpolate.py:8-18 -- xyz1 (b,n,3) unknown, xyz2 (b,m,3) known ->
-    dist (b,n,3) SQUARED distances, idx (b,n,3) int32.  Non-differentiable."""
+    dist (b,n,3) SQUARED distances, idx (b,n,3) int32.  Non-differentiable.
+    order (extension): (b,n) int32, a permutation of range(n) per scene -- the order in which the unknown points are handed to the
+    threads.  The result does not depend on it; a spatially coherent order (farthest_point_sample(..., return_order=True)) lets the
+    64 queries of a wave agree on which known points are worth an exact evaluation (171 -> 108 us at 8 x 32768 <- 2048)."""
     xyz1 = L.need(xyz1.detach(), torch.float32, 3, "xyz1")
     xyz2 = L.need(xyz2.detach(), torch.float32, 3, "xyz2")
     if xyz1.shape[2] != 3:
@@ -18,7 +21,13 @@ def three_nn(xyz1, xyz2):
     dist = torch.empty((b, n, 3), dtype=torch.float32, device=xyz1.device)
     idx = torch.empty((b, n, 3), dtype=torch.int32, device=xyz1.device)
     with torch.cuda.device(xyz1.device):
-        L.check(L.lib().gspn_threenn(b, n, m, L.ptr(xyz1), L.ptr(xyz2), L.ptr(dist), L.ptr(idx), L.stream()), "three_nn")
+        if order is not None:
+            order = L.need(order, torch.int32, 2, "order")
+            if tuple(order.shape) != (b, n):
+                raise ValueError("three_nn: order must be (b,n)")
+            L.check(L.lib().gspn_threenn_ordered(b, n, m, L.ptr(xyz1), L.ptr(xyz2), L.ptr(order), L.ptr(dist), L.ptr(idx), L.stream()), "three_nn")
+        else:
+            L.check(L.lib().gspn_threenn(b, n, m, L.ptr(xyz1), L.ptr(xyz2), L.ptr(dist), L.ptr(idx), L.stream()), "three_nn")
     return dist, idx
 
 

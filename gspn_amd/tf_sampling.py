@@ -49,9 +49,12 @@ def _cell_prepass(inp):
     return sxyz, perm.to(torch.int32).contiguous(), csz
 
 
-def farthest_point_sample(npoint, inp):
+def farthest_point_sample(npoint, inp, return_order=False):
     """tf_sampling.py:48-57 -- inp (batch, ndataset, 3) float32 -> (batch, npoint) int32.
-    Non-differentiable (ops.NoGradient('FarthestPointSample'))."""
+    Non-differentiable (ops.NoGradient('FarthestPointSample')).
+    return_order (extension): also return the spatial order the pre-pass sorted the scene into -- (batch, ndataset) int32, a
+    permutation of the point indices in which neighbours in space sit together (16 cells), or None when the launch had no pre-pass.
+    three_nn(..., order=) runs markedly faster on it (geometry.py)."""
     npoint = int(npoint)
     if npoint <= 0:
         raise ValueError("FarthestPointSample expects positive npoint")               # tf_sampling.cpp:99
@@ -61,6 +64,7 @@ def farthest_point_sample(npoint, inp):
     b, n, _ = inp.shape
     out = torch.empty((b, npoint), dtype=torch.int32, device=inp.device)
     lib = L.lib()
+    order = None
     with torch.cuda.device(inp.device):
         ev = None
 
@@ -84,6 +88,7 @@ def farthest_point_sample(npoint, inp):
             L.check(lib.gspn_fps_cells_prepass(b, n, L.ptr(inp), L.ptr(ws), L.stream()), "farthest_point_sample(cells pre-pass)")
             tic()
             L.check(lib.gspn_fps_cells_sample(b, n, npoint, L.ptr(inp), L.ptr(ws), L.ptr(out), L.stream()), "farthest_point_sample(cells)")
+            order = ws[:b * n].view(torch.int32).view(b, n)          # perm: sorted position -> original index (first b*n words of ws)
         elif FPS_MODE == "cells_torch" and 64 <= n:
             tic()
             sxyz, perm, csz = _cell_prepass(inp)
@@ -97,6 +102,8 @@ def farthest_point_sample(npoint, inp):
         if ev is not None:
             ev[1].record()
             PROFILE.append((ev[0], ev[1], b, n, npoint))
+    if return_order:
+        return out, order
     return out
 
 

@@ -161,6 +161,28 @@ def test_three_nn_matches_oracle(b, n, m):
     np.testing.assert_array_equal(d.cpu().numpy(), rd)
 
 
+@pytest.mark.parametrize("kind,b,n,m", [("D", 2, 9000, 700), ("S", 3, 12000, 300), ("U", 1, 8192, 3)])
+def test_three_nn_in_a_given_order(kind, b, n, m):
+    """three_nn(..., order=): the order the unknown points are handed to the threads in (a random permutation, and the spatial order
+    the FPS pre-pass leaves behind) changes nothing in the result"""
+    from gspn_amd.tf_interpolate import three_nn
+    from gspn_amd.tf_sampling import farthest_point_sample
+    dense = D.batch(kind, b, n, 10)
+    sparse = D.batch(kind, b, m, 50)
+    rd, ri = O.three_nn(dense, sparse)
+    rng = np.random.default_rng(n)
+    perm = np.stack([rng.permutation(n) for _ in range(b)]).astype(np.int32)
+    _, fps_order = farthest_point_sample(16, dev(dense), return_order=True)
+    assert fps_order is not None and fps_order.shape == (b, n)
+    assert (np.sort(fps_order.cpu().numpy(), axis=1) == np.arange(n)).all()
+    for order in (dev(perm), fps_order):
+        d, i = three_nn(dev(dense), dev(sparse), order=order)
+        np.testing.assert_array_equal(i.cpu().numpy(), ri)
+        np.testing.assert_array_equal(d.cpu().numpy(), rd)
+    with pytest.raises(ValueError):
+        three_nn(dev(dense), dev(sparse), order=dev(perm[:, :-1]))
+
+
 @pytest.mark.parametrize("c", [1, 16, 64, 131])
 def test_three_interpolate_and_grad(c):
     from gspn_amd.tf_interpolate import three_interpolate
