@@ -3,6 +3,7 @@
 // :187,222,262), so every FP module round-trips through the host.  These kernels keep the data
 // on the device and reproduce the host arithmetic: unfused fp32, left to right.
 #include <math.h>
+#include <stdint.h>
 
 #include "common.h"
 
@@ -225,6 +226,41 @@ __global__ void fp_concat_kernel(long total, int n, int m, int c2, int c1, int l
         out[i] = v;
     }
 }
+// The same, four columns per thread (ld and c2 multiples of 4, 16-byte aligned rows -- what the MLP's input matrices are): one
+// dwordx4 gather per neighbour and one dwordx4 store instead of four of each, and the row's three indices / weights fetched once per
+// four outputs.  Same products, same left-to-right sum per element.
+__global__ __launch_bounds__(256) void fp_concat4_kernel(long total4, int n, int m, int c2, int c1, int ld, const float* __restrict__ points2,
+                                                         const int* __restrict__ idx, const float* __restrict__ weight,
+                                                         const float* __restrict__ points1, float* __restrict__ out) {
+    const int ld4 = ld >> 2;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+        const long row = i / ld4;
+        const int l = (int)(i - row * ld4) << 2;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (l < c2) {
+            const long bi = row / n;
+            const int* ii = idx + row * 3;
+            const float* w = weight + row * 3;
+            const float* P = points2 + (size_t)bi * m * c2 + l;
+            const float w0 = w[0], w1 = w[1], w2 = w[2];
+            const float4 a = *reinterpret_cast<const float4*>(P + (size_t)ii[0] * c2);
+            const float4 bq = *reinterpret_cast<const float4*>(P + (size_t)ii[1] * c2);
+            const float4 cq = *reinterpret_cast<const float4*>(P + (size_t)ii[2] * c2);
+            v.x = (a.x * w0 + bq.x * w1) + cq.x * w2;
+            v.y = (a.y * w0 + bq.y * w1) + cq.y * w2;
+            v.z = (a.z * w0 + bq.z * w1) + cq.z * w2;
+            v.w = (a.w * w0 + bq.w * w1) + cq.w * w2;
+        } else {
+            const float* q = points1 + row * c1 - c2;          // column l of the output row is q[l]
+            const int end = c2 + c1;
+            if (l + 0 < end) v.x = q[l + 0];
+            if (l + 1 < end) v.y = q[l + 1];
+            if (l + 2 < end) v.z = q[l + 2];
+            if (l + 3 < end) v.w = q[l + 3];
+        }
+        *reinterpret_cast<float4*>(out + i * 4) = v;
+    }
+}
 // gradient: grad_points2[i_t, l] += g[row, l] * w_t (hardware atomics, like three_interpolate_grad), grad_points1[row, l] = g[row, c2 + l]
 __global__ void fp_concat_grad_kernel(long total, int n, int m, int c2, int c1, int ld, const float* __restrict__ g, const int* __restrict__ idx,
                                       const float* __restrict__ weight, float* __restrict__ grad_points2, float* __restrict__ grad_points1) {
@@ -253,7 +289,11 @@ extern "C" int gspn_fp_concat(int b, int n, int m, int c2, int c1, const float* 
     if (b < 0 || n < 0 || m <= 0 || c2 <= 0 || c1 < 0 || ld < c2 + c1 || (c1 > 0 && !points1)) return GSPN_ERR_ARG;
     const long total = (long)b * n * ld;
     if (total == 0) return 0;
-    hipLaunchKernelGGL(fp_concat_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, total, n, m, c2, c1, ld, points2, idx, weight, points1, out);
+    if (ld % 4 == 0 && c2 % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (reinterpret_cast<uintptr_t>(points2) & 15) == 0)
+        hipLaunchKernelGGL(fp_concat4_kernel, dim3(grid_for(total / 4, 256)), dim3(256), 0, (hipStream_t)stream, total / 4, n, m, c2, c1, ld, points2, idx, weight,
+                           points1, out);
+    else
+        hipLaunchKernelGGL(fp_concat_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, total, n, m, c2, c1, ld, points2, idx, weight, points1, out);
     return gspn_launch_status();
 }
 extern "C" int gspn_fp_concat_grad(int b, int n, int m, int c2, int c1, int ld, const float* grad_out, const int* idx, const float* weight,
