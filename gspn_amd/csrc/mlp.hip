@@ -1643,6 +1643,7 @@ struct DwJob {
     float* dW;
     int plain;                            // the partial tiles ARE dW's (pass A ran with known coefficients): dW = their sum
     int gq, gc_real, gxyz_first;          // gq > 0: rows of the partial tiles are in the gathered layer's internal order (GatherSrc)
+    int rowgrid;                          // (set by the pass-B launcher that carries the job: its GEMM workgroups per column block)
 };
 // One workgroup of NTH threads = DW_OX consecutive outputs x NTH/DW_OX interleaved slot slices; sh = 2 * (NTH/64) * DW_OX doubles.
 template <int NTH>
@@ -1707,7 +1708,7 @@ static DwJob dw_job(long rows, int cin, int cout, long nslots, const float* PP, 
     DwJob j;
     j.rows = rows; j.cin = cin; j.cout = cout; j.nslots = (int)nslots; j.nblk = (int)(((long)cin * cout + DW_OX - 1) / DW_OX);
     j.PP = PP; j.red = red; j.g3 = g3; j.var = var; j.gamma = gamma; j.eps = eps; j.use_bn = use_bn; j.is_training = is_training; j.dW = dW;
-    j.gq = 0; j.gc_real = 0; j.gxyz_first = 0; j.plain = 0;
+    j.gq = 0; j.gc_real = 0; j.gxyz_first = 0; j.plain = 0; j.rowgrid = 0;
     return j;
 }
 
@@ -2050,17 +2051,22 @@ __global__ __launch_bounds__(256) void mlp_bwd_data_kernel(long rows, int cin, i
     float* sCA = s_chan + 2 * cpad;
     float* sCB = s_chan + 3 * cpad;
     float* sCC = s_chan + 4 * cpad;
-    unsigned bx = blockIdx.x, gx = gridDim.x;
+    unsigned bx = blockIdx.x, gx = gridDim.x, by = blockIdx.y;
     if constexpr (DW) {
+        // one-dimensional grid: [dwj.nblk reduction workgroups][column block 0: dwj.rowgrid GEMM workgroups][column block 1: ...]
+        // (a second grid dimension would launch the reduction workgroups once per column block, all but the first to exit at once:
+        //  67 584 empty workgroups for the 384-column layer of the FP stack, 30 us of dispatch)
         if (bx < (unsigned)dwj.nblk) {
-            if (blockIdx.y == 0) wgrad_dw_block<256>(dwj, bx, reinterpret_cast<double*>(sA));
+            wgrad_dw_block<256>(dwj, bx, reinterpret_cast<double*>(sA));
             return;
         }
         bx -= (unsigned)dwj.nblk;
-        gx -= (unsigned)dwj.nblk;
+        gx = (unsigned)dwj.rowgrid;
+        by = bx / gx;
+        bx -= by * gx;
     }
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int n0 = col0 + blockIdx.y * BN;
+    const int n0 = col0 + by * BN;
     const long ntiles = (rows + TM - 1) / TM;
     const int nchunks = (cout + TK - 1) / TK;
     stage_chan(sSc, a.scale, cout, 1.f, cpad);
@@ -2247,9 +2253,12 @@ static int bwd_data_launch(long rows, int cin, int cout, const gspn_dy_args* a, 
     const unsigned extra = dwj ? (unsigned)dwj->nblk : 0u;
 #define BD_GO(BN_, V_, P_, YT_)                                                                                                       \
     do {                                                                                                                               \
-        const dim3 g(row_grid(rows, YT_, BN_ >= 128 ? env_int("GSPN_BWD_WIDE_BPC", 3) : 4) + extra, YT_);                                                            \
-        if (nparts_out) *nparts_out = (int)(g.x - extra);                                                                              \
-        if (dwj) hipLaunchKernelGGL((mlp_bwd_data_kernel<BN_, V_, P_, true>), g, dim3(256), sizeof(float) * 5 * chan_pad(cout), st, rows, cend, cout, *a, W, dX, ldx, col0, *dwj, rs);   \
+        const unsigned rg = row_grid(rows, YT_, BN_ >= 128 ? env_int("GSPN_BWD_WIDE_BPC", 3) : 4);                                      \
+        const dim3 g(dwj ? rg * (unsigned)(YT_) + extra : rg, dwj ? 1 : YT_);                                                          \
+        if (nparts_out) *nparts_out = (int)rg;                                                                                         \
+        DwJob dj = dwj ? *dwj : none;                                                                                                  \
+        dj.rowgrid = (int)rg;                                                                                                          \
+        if (dwj) hipLaunchKernelGGL((mlp_bwd_data_kernel<BN_, V_, P_, true>), g, dim3(256), sizeof(float) * 5 * chan_pad(cout), st, rows, cend, cout, *a, W, dX, ldx, col0, dj, rs);   \
         else     hipLaunchKernelGGL((mlp_bwd_data_kernel<BN_, V_, P_, false>), g, dim3(256), sizeof(float) * 5 * chan_pad(cout), st, rows, cend, cout, *a, W, dX, ldx, col0, none, rs);  \
     } while (0)
 #define BD_LAUNCH(BN_, V_, YT_) do { if (pooled) BD_GO(BN_, V_, true, YT_); else BD_GO(BN_, V_, false, YT_); } while (0)
