@@ -1632,7 +1632,7 @@ __global__ __launch_bounds__(256) void wgrad_small_reduce_kernel(long rows, int 
 // everything the dW reduction needs besides its block index (also carried by mlp_bwd_data_kernel, which can run it in spare workgroups)
 struct DwJob {
     long rows;
-    int cin, cout, nslots, nblk;          // nblk = ceil(cin*cout / DW_OX) workgroups
+    int cin, cout, nslots, nblk;          // nblk = dw_blocks(cin*cout, nslots, 256): workgroups of 256 threads the reduction takes
     const float* PP;
     const double* red;
     const float* g3;
@@ -1646,13 +1646,54 @@ struct DwJob {
     int rowgrid;                          // (set by the pass-B launcher that carries the job: its GEMM workgroups per column block)
 };
 // One workgroup of NTH threads = DW_OX consecutive outputs x NTH/DW_OX interleaved slot slices; sh = 2 * (NTH/64) * DW_OX doubles.
+// the last step of the reduction, shared by both thread mappings: BN correction, scale, (gathered layers) row mapping, store
+__device__ __forceinline__ void wgrad_dw_store(const DwJob& j, long i, double w1, double wx, bool tr) {
+    const int n = (int)(i % j.cout), m = (int)(i / j.cout);
+    double A = 1.0;
+    if (j.use_bn && !j.plain) A = (j.gamma ? (double)j.gamma[n] : 1.0) / sqrt((double)j.var[n] + (double)j.eps);
+    if (tr) w1 -= (j.red[n] / (double)j.rows) * (double)j.g3[m] + (j.red[j.cout + n] / (double)j.rows) * wx;
+    if (j.gq > 0) {                                               // internal row m -> row of the caller's dW (padding rows have none)
+        GatherSrc g{nullptr, nullptr, nullptr, j.gq, j.gc_real, j.gxyz_first};
+        const int mo = gather_w_row(g, m);
+        if (mo >= 0) j.dW[(size_t)mo * j.cout + n] = (float)(A * w1);
+        return;
+    }
+    j.dW[i] = (float)(A * w1);
+}
+// Few slots (the short layers: 4096-32768 rows give 4-16 row chunks, but up to 384 x 256 outputs): one thread per output, the slots summed
+// in order -- NTH outputs per workgroup instead of DW_OX (the sliced mapping below would spend 6144 workgroups, each with fifteen of
+// its sixteen slot slices idle, on the 384 -> 256 layer of the FP stack).
+#define DW_FLAT_MAX 16
+template <int NTH>
+__device__ __forceinline__ void wgrad_dw_block_flat(const DwJob& j, unsigned blk) {
+    const long total = (long)j.cin * j.cout;
+    const long i = blk * (long)NTH + threadIdx.x;
+    if (i >= total) return;
+    const bool tr = j.use_bn && j.is_training && !j.plain;
+    const float* p1 = j.PP + i;
+    const size_t st = 2 * (size_t)total;
+    double w1 = 0.0, wx = 0.0;
+    int p = 0;
+    for (; p + 3 < j.nslots; p += 4) {
+        const float v0 = p1[(size_t)p * st], v1 = p1[(size_t)(p + 1) * st], v2 = p1[(size_t)(p + 2) * st], v3 = p1[(size_t)(p + 3) * st];
+        float u0 = 0.f, u1 = 0.f, u2 = 0.f, u3 = 0.f;
+        if (tr) { u0 = p1[(size_t)p * st + total]; u1 = p1[(size_t)(p + 1) * st + total]; u2 = p1[(size_t)(p + 2) * st + total]; u3 = p1[(size_t)(p + 3) * st + total]; }
+        w1 += (double)v0; w1 += (double)v1; w1 += (double)v2; w1 += (double)v3;
+        wx += (double)u0; wx += (double)u1; wx += (double)u2; wx += (double)u3;
+    }
+    for (; p < j.nslots; ++p) {
+        w1 += (double)p1[(size_t)p * st];
+        if (tr) wx += (double)p1[(size_t)p * st + total];
+    }
+    wgrad_dw_store(j, i, w1, wx, tr);
+}
 template <int NTH>
 __device__ __forceinline__ void wgrad_dw_block(const DwJob& j, unsigned blk, double* sh) {
+    if (j.nslots <= DW_FLAT_MAX) { wgrad_dw_block_flat<NTH>(j, blk); return; }
     constexpr int SL = NTH / DW_OX, NW = NTH / 64;
     double* s1 = sh;
     double* sx = sh + NW * DW_OX;
     const long total = (long)j.cin * j.cout;
-    const double R = (double)j.rows;
     const bool tr = j.use_bn && j.is_training && !j.plain;
     const int ox = threadIdx.x % DW_OX, sl = threadIdx.x / DW_OX, wave = threadIdx.x >> 6;
     const long i = blk * (long)DW_OX + ox;
@@ -1687,18 +1728,10 @@ __device__ __forceinline__ void wgrad_dw_block(const DwJob& j, unsigned blk, dou
     w1 = 0.0; wx = 0.0;
 #pragma unroll
     for (int q = 0; q < NW; ++q) { w1 += s1[q * DW_OX + ox]; wx += sx[q * DW_OX + ox]; }
-    const int n = (int)(i % j.cout), m = (int)(i / j.cout);
-    double A = 1.0;
-    if (j.use_bn && !j.plain) A = (j.gamma ? (double)j.gamma[n] : 1.0) / sqrt((double)j.var[n] + (double)j.eps);
-    if (tr) w1 -= (j.red[n] / R) * (double)j.g3[m] + (j.red[j.cout + n] / R) * wx;
-    if (j.gq > 0) {                                               // internal row m -> row of the caller's dW (padding rows have none)
-        GatherSrc g{nullptr, nullptr, nullptr, j.gq, j.gc_real, j.gxyz_first};
-        const int mo = gather_w_row(g, m);
-        if (mo >= 0) j.dW[(size_t)mo * j.cout + n] = (float)(A * w1);
-        return;
-    }
-    j.dW[i] = (float)(A * w1);
+    wgrad_dw_store(j, i, w1, wx, tr);
 }
+// workgroups of NTH threads the reduction of job j takes
+static long dw_blocks(long total, long nslots, int nth) { return nslots <= DW_FLAT_MAX ? (total + nth - 1) / nth : (total + DW_OX - 1) / DW_OX; }
 __global__ __launch_bounds__(1024) void wgrad_dw_kernel(DwJob j) {
     __shared__ double sh[2 * 16 * DW_OX];
     wgrad_dw_block<1024>(j, blockIdx.x, sh);
@@ -1706,7 +1739,7 @@ __global__ __launch_bounds__(1024) void wgrad_dw_kernel(DwJob j) {
 static DwJob dw_job(long rows, int cin, int cout, long nslots, const float* PP, const double* red, const float* g3, const float* var, const float* gamma,
                     float eps, int use_bn, int is_training, float* dW) {
     DwJob j;
-    j.rows = rows; j.cin = cin; j.cout = cout; j.nslots = (int)nslots; j.nblk = (int)(((long)cin * cout + DW_OX - 1) / DW_OX);
+    j.rows = rows; j.cin = cin; j.cout = cout; j.nslots = (int)nslots; j.nblk = (int)dw_blocks((long)cin * cout, nslots, 256);      // as a ride in pass B (256 threads)
     j.PP = PP; j.red = red; j.g3 = g3; j.var = var; j.gamma = gamma; j.eps = eps; j.use_bn = use_bn; j.is_training = is_training; j.dW = dW;
     j.gq = 0; j.gc_real = 0; j.gxyz_first = 0; j.plain = 0; j.rowgrid = 0;
     return j;
@@ -1829,7 +1862,7 @@ static int wgrad_impl(long rows, int cin, int cout, const gspn_dy_args* a, const
         DwJob j = dw_job(rows, cin, cout, p.nslots, PP, red, g3, var, gamma, eps, use_bn, is_training, dW);
         j.plain = known ? 1 : 0;
         if (gsrc) { j.gq = gsrc->cq; j.gc_real = gsrc->c_real; j.gxyz_first = gsrc->xyz_first; }
-        hipLaunchKernelGGL(wgrad_dw_kernel, dim3((unsigned)j.nblk), dim3(1024), 0, st, j);
+        hipLaunchKernelGGL(wgrad_dw_kernel, dim3((unsigned)dw_blocks((long)j.cin * j.cout, j.nslots, 1024)), dim3(1024), 0, st, j);
     }
     return gspn_launch_status();
 }
@@ -2020,7 +2053,7 @@ extern "C" int gspn_mlp_bwd_dw(long rows, int cin, int cout, const gspn_dy_args*
     const float* g3 = reinterpret_cast<const float*>(wb + ws_off_g3(cout));
     const float* PP = reinterpret_cast<const float*>(wb + ws_off_pp(p.nch, cin, cout));
     const DwJob j = dw_job(rows, cin, cout, p.nslots, PP, red, g3, var, gamma, eps, use_bn, is_training, dW);
-    hipLaunchKernelGGL(wgrad_dw_kernel, dim3((unsigned)j.nblk), dim3(1024), 0, (hipStream_t)stream, j);
+    hipLaunchKernelGGL(wgrad_dw_kernel, dim3((unsigned)dw_blocks((long)j.cin * j.cout, j.nslots, 1024)), dim3(1024), 0, (hipStream_t)stream, j);
     return gspn_launch_status();
 }
 
