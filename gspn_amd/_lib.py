@@ -53,6 +53,9 @@ SIGNATURES = {
     "gspn_grouppoint_grad": [_I, _I, _I, _I, _I, _P, _P, _P, _P],
     "gspn_groupmaxpool": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     "gspn_groupmaxpool_grad": [_I, _I, _I, _I, _P, _P, _P, _P],
+    "gspn_preagg_ok": [_I],
+    "gspn_preagg_fwd": [_L, _I, _I, _P, _P, _P, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P],
+    "gspn_preagg_bwd_dy": [_L, _I, _c.POINTER(DyArgs), _P, _I, _I, _P, _P, _P, _P],
     "gspn_threenn": [_I, _I, _I, _P, _P, _P, _P, _P],
     "gspn_threenn_ordered": [_I, _I, _I, _P, _P, _P, _P, _P, _P],
     "gspn_threeinterpolate": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
@@ -100,6 +103,7 @@ SPECIAL = {
     "gspn_fps_cells_ws_bytes": ([_I, _I], _L),
     "gspn_fps_multi_ws_bytes": ([_I, _I], _L),
     "gspn_rsum_part_floats": ([_L, _I], _L),
+    "gspn_preagg_part_floats": ([_I, _I], _L),
     "gspn_inverse_lists_work_ints": ([_I, _I, _I], _L),
 }
 

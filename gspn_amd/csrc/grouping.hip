@@ -287,7 +287,7 @@ extern "C" int gspn_sa_group_concat(int b, int n, int c, int m, int nsample, con
 }
 extern "C" int gspn_sa_group_concat_grad(int b, int n, int c, int m, int nsample, const int* idx, int xyz_first, int ld_out,
                                          const float* grad_out, float* grad_points, void* stream) {
-    if (b < 0 || n <= 0 || c <= 0 || m < 0 || nsample < 0 || ld_out < 3 + c) return GSPN_ERR_ARG;
+    if (b < 0 || n <= 0 || c <= 0 || m < 0 || nsample < 0 || ld_out < (xyz_first ? 3 : 0) + c) return GSPN_ERR_ARG;
     if (b == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(grad_points, 0, sizeof(float) * (size_t)b * n * c, st);
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256) void sa_group_concat_grad_csr_kernel(int n, in
 }
 extern "C" int gspn_sa_group_concat_grad_csr(int b, int n, int c, int m, int nsample, const int* order, const int* offsets, int xyz_first, int ld_out,
                                              const float* grad_out, float* grad_points, void* stream) {
-    if (b < 0 || n <= 0 || c <= 0 || m < 0 || nsample < 0 || ld_out < 3 + c || !order || !offsets) return GSPN_ERR_ARG;
+    if (b < 0 || n <= 0 || c <= 0 || m < 0 || nsample < 0 || ld_out < (xyz_first ? 3 : 0) + c || !order || !offsets) return GSPN_ERR_ARG;
     if (b == 0) return 0;
     const long nwaves = (long)b * n * ((c + 63) / 64);
     const long blocks = (nwaves + 3) / 4;

@@ -2041,6 +2041,154 @@ extern "C" int gspn_mlp_bwd_wgrad_gather(long rows, const gspn_gather_args* g, i
 // The deferred last kernel of pass A: dW from the partial tiles / sums that gspn_mlp_bwd_wgrad(..., dW = NULL, ...) left in `work`.
 // Nothing downstream of the layer needs dW before the optimiser, so a caller may run this on another stream (after the wgrad call,
 // with the same rows/cin/cout/a/X/ldx so that the workspace layout is found again) and let it overlap the next layer's kernels.
+// ============================================================================================
+// Pre-aggregated first layer.  The first 1x1 layer of an SA module multiplies GROUPED rows [feat[gidx[r]] | rel[r]] -- every point's
+// feature row 8x over at nsample 32 / 4x decimation -- and that of an FP module multiplies interpolated rows sum_t w_t * feat[idx_t[r]].
+// The layer is linear, so the feature part can be multiplied BEFORE the grouping / interpolation, on the source points:
+//     F = feat . W_feat                                   (source rows only: 8x fewer than grouped rows; a small GEMM)
+//     Y[r] = sum_t w_t[r] * F[idx_t[r]] + side[r] . W_side + bias      (T = 1, w = 1: grouping;  T = 3: 3-NN interpolation)
+// with `side` the <= 4 columns that exist per output row only (centred coordinates / the skip-link colours).  The second line is an
+// element-wise kernel bound by the write of Y; it also takes the column statistics of Y for the batch norm (same partial layout as
+// the GEMM kernels, so gspn_bn_finalize follows unchanged).  Backward: dY is rebuilt once from (dz, Y, coefficients) and written out;
+// its transpose-gather onto the source points (the inverse lists' kernels) gives G = d(loss)/dF, and dW_feat = feat^T . G,
+// d(feat) = G . W_feat^T are small GEMMs again; dW_side = side^T . dY is accumulated by the kernel that writes dY.
+// (Same mathematics, a different order of fp32 additions than the grouped GEMM: results agree to rounding, not bit for bit.)
+// ============================================================================================
+struct PreaggSrc {
+    const float* F;        // (source rows, cout)
+    const int* idx;        // (rows, T) source rows; scene-local when per_scene_rows > 0
+    const float* w;        // (rows, T) weights or NULL (= 1)
+    int per_scene_rows;    // rows per scene of the OUTPUT (0: idx are global source rows)
+    int per_scene_src;     // source rows per scene
+    const float* side;     // (rows, side_ld), side_n <= 4 columns used
+    int side_ld, side_n;
+};
+template <int T>
+__global__ __launch_bounds__(256) void preagg_fwd_kernel(long rows, int cout, PreaggSrc ps, const float* __restrict__ Ws, const float* __restrict__ bias,
+                                                         float* __restrict__ Y, float* __restrict__ stats) {
+    extern __shared__ float pa_sh[];                 // [2][rpi][cout]
+    const int cq = cout >> 2, rpi = 256 / cq;
+    const int q = threadIdx.x % cq, rr = threadIdx.x / cq;
+    float4 wsd[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) wsd[k] = k < ps.side_n ? *reinterpret_cast<const float4*>(Ws + (size_t)k * cout + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 bq = bias ? *reinterpret_cast<const float4*>(bias + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    for (long r = (long)blockIdx.x * rpi + rr; r < rows; r += (long)gridDim.x * rpi) {
+        const long base = ps.per_scene_rows > 0 ? (r / ps.per_scene_rows) * (long)ps.per_scene_src : 0;
+        float4 f[T];
+        float wt[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const long src = base + ps.idx[r * T + t];
+            f[t] = *reinterpret_cast<const float4*>(ps.F + (size_t)src * cout + 4 * q);
+            wt[t] = ps.w ? ps.w[r * T + t] : 1.f;
+        }
+        float sd[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sd[k] = k < ps.side_n ? ps.side[(size_t)r * ps.side_ld + k] : 0.f;
+        float4 y;
+        if (T == 1 && !ps.w) y = f[0];
+        else {
+            y = make_float4(f[0].x * wt[0], f[0].y * wt[0], f[0].z * wt[0], f[0].w * wt[0]);
+#pragma unroll
+            for (int t = 1; t < T; ++t) { y.x += f[t].x * wt[t]; y.y += f[t].y * wt[t]; y.z += f[t].z * wt[t]; y.w += f[t].w * wt[t]; }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { y.x += sd[k] * wsd[k].x; y.y += sd[k] * wsd[k].y; y.z += sd[k] * wsd[k].z; y.w += sd[k] * wsd[k].w; }
+        y.x += bq.x; y.y += bq.y; y.z += bq.z; y.w += bq.w;
+        *reinterpret_cast<float4*>(Y + (size_t)r * cout + 4 * q) = y;
+        s1.x += y.x; s1.y += y.y; s1.z += y.z; s1.w += y.w;
+        s2.x += y.x * y.x; s2.y += y.y * y.y; s2.z += y.z * y.z; s2.w += y.w * y.w;
+    }
+    if (!stats) return;
+    *reinterpret_cast<float4*>(pa_sh + ((size_t)0 * rpi + rr) * cout + 4 * q) = s1;
+    *reinterpret_cast<float4*>(pa_sh + ((size_t)1 * rpi + rr) * cout + 4 * q) = s2;
+    __syncthreads();
+    for (int j = threadIdx.x; j < 2 * cout; j += 256) {
+        const int h = j / cout, c = j - h * cout;
+        float v = 0.f;
+        for (int k = 0; k < rpi; ++k) v += pa_sh[((size_t)h * rpi + k) * cout + c];
+        stats[(size_t)blockIdx.x * 2 * cout + j] = v;                // [block][2][cout]: sum, sum of squares
+    }
+}
+static bool preagg_shape_ok(int cout) { return cout >= 4 && cout <= 1024 && (cout & 3) == 0 && ((cout >> 2) & ((cout >> 2) - 1)) == 0; }
+extern "C" int gspn_preagg_ok(int cout) { return preagg_shape_ok(cout) ? 1 : 0; }
+extern "C" int gspn_preagg_fwd(long rows, int cout, int T, const float* F, const int* idx, const float* w, int per_scene_rows, int per_scene_src,
+                               const float* side, int side_ld, int side_n, const float* Wside, const float* bias, float* Y, float* stats, void* stream) {
+    if (rows <= 0 || !F || !idx || !Y || (T != 1 && T != 3) || side_n < 0 || side_n > 4 || (side_n > 0 && (!side || !Wside || side_ld < side_n))) return GSPN_ERR_ARG;
+    if (!preagg_shape_ok(cout) || rows >= (1L << 31)) return GSPN_ERR_UNSUPPORTED;
+    if (((uintptr_t)F % 16) || ((uintptr_t)Y % 16) || (Wside && ((uintptr_t)Wside % 16)) || (bias && ((uintptr_t)bias % 16))) return GSPN_ERR_ARG;
+    const PreaggSrc ps{F, idx, w, per_scene_rows, per_scene_src, side, side_ld, side_n};
+    const unsigned nb = fwd_blocks(rows, cout);          // = the number of partial rows gspn_bn_finalize sums for (rows, cout)
+    const size_t sh = sizeof(float) * 2 * 256 * 4;       // 2 * rpi * cout floats, rpi * cout = 1024
+    if (T == 1) hipLaunchKernelGGL(preagg_fwd_kernel<1>, dim3(nb), dim3(256), sh, (hipStream_t)stream, rows, cout, ps, Wside, bias, Y, stats);
+    else hipLaunchKernelGGL(preagg_fwd_kernel<3>, dim3(nb), dim3(256), sh, (hipStream_t)stream, rows, cout, ps, Wside, bias, Y, stats);
+    return gspn_launch_status();
+}
+// dY = cA * relu'(y*scale+shift) * dz + cB * y + cC, written out (rows, cout); per workgroup the partial side^T . dY (side_n x cout) into
+// part[workgroup][2][side_n*cout] (first half; the layout of the dW reduction's slots)
+#define PREAGG_BWD_BLOCKS 1024
+__global__ __launch_bounds__(256) void preagg_bwd_dy_kernel(long rows, int cout, gspn_dy_args a, const float* __restrict__ side, int side_ld, int side_n,
+                                                            float* __restrict__ dY, float* __restrict__ part) {
+    extern __shared__ float pa_sh[];                 // [rpi][side_n][cout]
+    const int cq = cout >> 2, rpi = 256 / cq;
+    const int q = threadIdx.x % cq, rr = threadIdx.x / cq;
+    const float4 sc = *reinterpret_cast<const float4*>(a.scale + 4 * q), sh = *reinterpret_cast<const float4*>(a.shift + 4 * q);
+    const float4 cA = *reinterpret_cast<const float4*>(a.cA + 4 * q), cB = *reinterpret_cast<const float4*>(a.cB + 4 * q);
+    const float4 cC = *reinterpret_cast<const float4*>(a.cC + 4 * q);
+    float4 acc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (long r = (long)blockIdx.x * rpi + rr; r < rows; r += (long)gridDim.x * rpi) {
+        const float4 y = *reinterpret_cast<const float4*>(a.Y + (size_t)r * a.ldy + 4 * q);
+        const float4 z = *reinterpret_cast<const float4*>(a.dZ + (size_t)r * a.ldz + 4 * q);
+        float4 d;
+        d.x = cA.x * (y.x * sc.x + sh.x > 0.f ? z.x : 0.f) + cB.x * y.x + cC.x;
+        d.y = cA.y * (y.y * sc.y + sh.y > 0.f ? z.y : 0.f) + cB.y * y.y + cC.y;
+        d.z = cA.z * (y.z * sc.z + sh.z > 0.f ? z.z : 0.f) + cB.z * y.z + cC.z;
+        d.w = cA.w * (y.w * sc.w + sh.w > 0.f ? z.w : 0.f) + cB.w * y.w + cC.w;
+        *reinterpret_cast<float4*>(dY + (size_t)r * cout + 4 * q) = d;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < side_n) {
+                const float sv = side[(size_t)r * side_ld + k];
+                acc[k].x += sv * d.x; acc[k].y += sv * d.y; acc[k].z += sv * d.z; acc[k].w += sv * d.w;
+            }
+    }
+    if (side_n == 0 || !part) return;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (k < side_n) *reinterpret_cast<float4*>(pa_sh + ((size_t)rr * side_n + k) * cout + 4 * q) = acc[k];
+    __syncthreads();
+    const int tot = side_n * cout;
+    for (int j = threadIdx.x; j < tot; j += 256) {
+        float v = 0.f;
+        for (int k = 0; k < rpi; ++k) v += pa_sh[(size_t)k * tot + j];
+        part[(size_t)blockIdx.x * 2 * tot + j] = v;
+    }
+}
+extern "C" long gspn_preagg_part_floats(int cout, int side_n) { return (long)PREAGG_BWD_BLOCKS * 2 * side_n * cout + 4; }
+// dY (rows, cout) from (a.dZ, a.Y, a.scale/shift, a.cA/cB/cC); dWside (side_n, cout) = side^T . dY (deterministic two-level sum)
+extern "C" int gspn_preagg_bwd_dy(long rows, int cout, const gspn_dy_args* a, const float* side, int side_ld, int side_n, float* dY, float* part,
+                                  float* dWside, void* stream) {
+    if (rows <= 0 || !a || !a->Y || !a->dZ || !a->scale || !a->shift || !a->cA || !a->cB || !a->cC || !dY || side_n < 0 || side_n > 4) return GSPN_ERR_ARG;
+    if (side_n > 0 && (!side || !part || !dWside || side_ld < side_n)) return GSPN_ERR_ARG;
+    if (!preagg_shape_ok(cout) || rows >= (1L << 31) || (a->ldy & 3) || (a->ldz & 3)) return GSPN_ERR_UNSUPPORTED;
+    if (((uintptr_t)a->Y % 16) || ((uintptr_t)a->dZ % 16) || ((uintptr_t)dY % 16)) return GSPN_ERR_ARG;
+    const int rpi = 256 / (cout >> 2);
+    long nb = (rows + rpi - 1) / rpi;
+    if (nb > PREAGG_BWD_BLOCKS) nb = PREAGG_BWD_BLOCKS;
+    const size_t sh = sizeof(float) * 4 * 1024;
+    hipLaunchKernelGGL(preagg_bwd_dy_kernel, dim3((unsigned)nb), dim3(256), sh, (hipStream_t)stream, rows, cout, *a, side, side_ld, side_n, dY, part);
+    if (side_n > 0) {
+        DwJob j = dw_job(rows, side_n, cout, nb, part, nullptr, nullptr, nullptr, nullptr, 0.f, 0, 0, dWside);
+        j.plain = 1;
+        hipLaunchKernelGGL(wgrad_dw_kernel, dim3((unsigned)dw_blocks((long)side_n * cout, nb, 1024)), dim3(1024), 0, (hipStream_t)stream, j);
+    }
+    return gspn_launch_status();
+}
+
 extern "C" int gspn_mlp_bwd_dw(long rows, int cin, int cout, const gspn_dy_args* a, const float* X, int ldx, const float* var, const float* gamma,
                                float eps, int use_bn, int is_training, const float* work, float* dW, void* stream) {
     if (rows <= 0 || cin <= 0 || cout <= 0 || ldx < cin || !a || !a->Y || !work || !dW) return GSPN_ERR_ARG;

@@ -27,6 +27,10 @@ FUSE_POOL32 = os.environ.get("GSPN_FUSE_POOL32", "1") != "0"
 # early coefficients (mlp.hip, "Early coefficients"): the BN reductions of a layer are taken before its pass A -- by the epilogue of the
 # next layer's pass B, or from the pool arg-max for the top layer of a pooled stack -- so that pass A is one GEMM instead of two
 EARLY_R = os.environ.get("GSPN_EARLY_R", "1") != "0"
+# pre-aggregated first layer (mlp.hip, "Pre-aggregated first layer"): the feature part of an SA / FP module's first layer is multiplied on the
+# source points, the grouped / interpolated rows are formed from the product.  Training-mode BN stacks with early coefficients only.
+PREAGG = os.environ.get("GSPN_PREAGG", "1") != "0"
+PREAGG_MIN_C = int(os.environ.get("GSPN_PREAGG_MIN_C", "16"))      # below this many feature columns the grouped GEMM is as cheap
 # one launch for pass B + the dW reduction of the same layer (gspn_mlp_bwd_data_dw) instead of two
 FUSE_DW = os.environ.get("GSPN_FUSE_DW", "1") != "0"
 _side_streams = {}
@@ -99,6 +103,10 @@ class _MlpStack(torch.autograd.Function):
             ctx.gather_x = x                     # the backward pass gathers from it again: keep the storage alive
         else:
             rows, ld = x.shape
+        pre = spec.get("preagg")                 # pre-aggregated first layer: x is the (source rows, ldf) feature matrix
+        if pre is not None:
+            rows, ld = pre["rows"], 0
+            ctx.pre_x = x
         layers = spec["layers"]
         is_training = bool(spec["is_training"])
         decay = float(spec["decay"])
@@ -121,6 +129,16 @@ class _MlpStack(torch.autograd.Function):
                     L.check(lib.gspn_mlp_fwd_pool32(rows, cin, cout, L.ptr(cur), cur_ld, L.ptr(in_scale), L.ptr(in_shift), L.ptr(lp.weights),
                                                     L.ptr(lp.biases), L.ptr(y), cout, L.ptr(stats), L.ptr(pool[0]), L.ptr(pool[1]), st),
                             "mlp_fwd_pool32")
+                elif li == 0 and pre is not None:
+                    # F = feat . W_feat on the source rows, then the output rows from F (+ side . W_side + bias) and their column sums
+                    wf = lp.weights[pre["wf0"]:pre["wf0"] + pre["c"]]
+                    ws = lp.weights[pre["ws0"]:pre["ws0"] + pre["side_n"]]
+                    fsrc = torch.empty((x.shape[0], cout), dtype=torch.float32, device=dev)
+                    L.check(lib.gspn_mlp_fwd(x.shape[0], pre["c"], cout, L.ptr(x), x.shape[1], None, None, L.ptr(wf), None, L.ptr(fsrc), cout, None, st),
+                            "mlp_fwd(pre-aggregation)")
+                    L.check(lib.gspn_preagg_fwd(rows, cout, pre["T"], L.ptr(fsrc), L.ptr(pre["idx"]), L.ptr(pre["w"]), pre["per_scene_rows"],
+                                                pre["per_scene_src"], L.ptr(pre["side"]), pre["side_ld"], pre["side_n"], L.ptr(ws), L.ptr(lp.biases),
+                                                L.ptr(y), L.ptr(stats), st), "preagg_fwd")
                 elif li == 0 and gather is not None:
                     L.check(lib.gspn_mlp_fwd_gather(rows, ctypes.byref(ga), cout, L.ptr(lp.weights), L.ptr(lp.biases), L.ptr(y), cout, L.ptr(stats), st),
                             "mlp_fwd_gather")
@@ -141,7 +159,7 @@ class _MlpStack(torch.autograd.Function):
                     shift.zero_()
                     mean.zero_()
                     var.fill_(1.0)
-                saved.append((None if (li == 0 and gather is not None) else cur, cur_ld, cin, in_scale, in_shift, y, mean, var, scale, shift))
+                saved.append((None if (li == 0 and (gather is not None or pre is not None)) else cur, cur_ld, cin, in_scale, in_shift, y, mean, var, scale, shift))
                 cur, cur_ld, cin, in_scale, in_shift = y, cout, cout, scale, shift
             cl = cin
             arg = None
@@ -159,6 +177,7 @@ class _MlpStack(torch.autograd.Function):
                 out = torch.empty((rows, cl), dtype=torch.float32, device=dev)
                 L.check(lib.gspn_bnrelu_apply(rows, cl, L.ptr(cur), cur_ld, L.ptr(in_scale), L.ptr(in_shift), L.ptr(out), cl, st), "bnrelu_apply")
         ctx.gather = gather
+        ctx.pre = pre
         ctx.saved = saved
         # backward re-reads the weights and gamma: an in-place update between forward and backward would silently change the result
         # (autograd's own check only covers save_for_backward tensors; these are kept as attributes so the layer list stays one object)
@@ -223,6 +242,16 @@ class _MlpStack(torch.autograd.Function):
                     dbeta = torch.empty(cout, dtype=torch.float32, device=dev) if lp.bn else None
                     dbias = torch.empty(cout, dtype=torch.float32, device=dev)
                 a.cA, a.cB, a.cC = cA.data_ptr(), cB.data_ptr(), cC.data_ptr()
+                if li == 0 and ctx.pre is not None:
+                    if known is None:
+                        raise RuntimeError("mlp_stack(preagg=): the first layer's BN coefficients must be known before its backward (EARLY_R)")
+                    dW, dx0 = _preagg_backward(lib, ctx.pre, ctx.pre_x, lp, a, rows, cout, ctx.x_needs_grad, dev, st)
+                    g = [dW, dbias]
+                    if lp.bn:
+                        g += [dbeta, dgamma]
+                    grads = g + grads
+                    del a
+                    continue
                 dW = torch.empty_like(lp.weights)
                 wcin = int(lib.gspn_mlp_gather_cin(ctypes.byref(ctx.gargs))) if gather0 is not None else cin
                 work = torch.empty(int(lib.gspn_mlp_bwd_work_bytes(rows, wcin, cout)) // 4 + 4, dtype=torch.float32, device=dev)
@@ -327,6 +356,41 @@ class _MlpStack(torch.autograd.Function):
         return (dx0, None, None) + tuple(grads)
 
 
+def _preagg_backward(lib, pre, x, lp, a, rows, cout, need_dx, dev, st):
+    """backward of a pre-aggregated first layer: dY written once (+ dW_side), its transpose-gather G onto the source rows, then
+    dW_feat = feat^T . G and d(feat) = G . W_feat^T as small GEMMs without BN (always-open mask: scale 0, shift 1, dY = dz)"""
+    c, side_n = pre["c"], pre["side_n"]
+    dW = torch.zeros_like(lp.weights) if pre["c"] + side_n < lp.weights.shape[0] else torch.empty_like(lp.weights)
+    dy = torch.empty((rows, cout), dtype=torch.float32, device=dev)
+    part = torch.empty(int(lib.gspn_preagg_part_floats(cout, max(side_n, 1))), dtype=torch.float32, device=dev)
+    dws = dW[pre["ws0"]:pre["ws0"] + side_n]
+    L.check(lib.gspn_preagg_bwd_dy(rows, cout, ctypes.byref(a), L.ptr(pre["side"]), pre["side_ld"], side_n, L.ptr(dy), L.ptr(part), L.ptr(dws), st),
+            "preagg_bwd_dy")
+    nsrc = x.shape[0]
+    gsrc = pre["scatter"](dy, cout)                                 # (source rows, cout): sum over the output rows each source row fed
+    one = torch.ones(cout, dtype=torch.float32, device=dev)
+    zero = torch.zeros(cout, dtype=torch.float32, device=dev)
+    cA, cB, cC = torch.empty_like(one), torch.empty_like(one), torch.empty_like(one)
+    a2 = L.DyArgs()
+    a2.Y, a2.ldy = gsrc.data_ptr(), cout
+    a2.dZ, a2.ldz, a2.dPool, a2.pool_arg, a2.ns = gsrc.data_ptr(), cout, None, None, 0
+    a2.scale, a2.shift = zero.data_ptr(), one.data_ptr()
+    a2.cA, a2.cB, a2.cC = cA.data_ptr(), cB.data_ptr(), cC.data_ptr()
+    dwf = dW[pre["wf0"]:pre["wf0"] + c]
+    wf = lp.weights[pre["wf0"]:pre["wf0"] + c]
+    dbias_unused = torch.empty(cout, dtype=torch.float32, device=dev)
+    work = torch.empty(int(lib.gspn_mlp_bwd_work_bytes(nsrc, c, cout)) // 4 + 4, dtype=torch.float32, device=dev)
+    L.check(lib.gspn_mlp_bwd_wgrad(nsrc, c, cout, ctypes.byref(a2), L.ptr(x), x.shape[1], None, None, None, None, None, BN_EPS, 0, 0,
+                                   L.ptr(work), L.ptr(cA), L.ptr(cB), L.ptr(cC), None, None, L.ptr(dbias_unused), L.ptr(dwf), st), "mlp_bwd_wgrad(pre-aggregation)")
+    dx = None
+    if need_dx:
+        dx = torch.empty((nsrc, x.shape[1]), dtype=torch.float32, device=dev)
+        if x.shape[1] > c:
+            dx.zero_()
+        L.check(lib.gspn_mlp_bwd_data(nsrc, c, cout, ctypes.byref(a2), L.ptr(wf), L.ptr(dx), x.shape[1], st), "mlp_bwd_data(pre-aggregation)")
+    return dW, dx
+
+
 def _coef_from_parts(lib, rows, c, nparts, part, mean, var, lp, dev, st):
     """gspn_mlp_bwd_coef: partial sums [nparts][2][c] of (dyh, dyh*xhat) -> the layer's final BN-backward coefficients and its
     dgamma / dbeta / dbias, before its pass A runs"""
@@ -411,11 +475,21 @@ def _mlp_stack_sync_bn(x, cin, layers, decay, pool_ns):
     return cur
 
 
-def mlp_stack(x, cin, layers, is_training, bn_decay, pool_ns=None, grad_cols=None, gather=None):
+def preagg_ok(layers, is_training, c):
+    """can the stack's first layer be pre-aggregated?  (training-mode BN on the first two layers -- the second layer's pass B hands the
+    first its BN coefficients --, a kernel-friendly width, enough feature columns for the saved GEMM work to matter)"""
+    return (PREAGG and EARLY_R and not DEFER_DW and not SYNC_BN and is_training and len(layers) >= 2 and layers[0].bn and layers[1].bn
+            and c >= PREAGG_MIN_C and bool(L.lib().gspn_preagg_ok(layers[0].weights.shape[1])))
+
+
+def mlp_stack(x, cin, layers, is_training, bn_decay, pool_ns=None, grad_cols=None, gather=None, preagg=None):
     """x: (rows, ld>=cin) float32 on a ROCm device.  Returns (rows/pool_ns, C_last) if pool_ns else (rows, C_last).
     grad_cols = (col0, ncols): the only columns of x whose gradient the caller will read (the rest of x.grad is left undefined).
     gather (fused SA front end): x is then the (b*n, ldf) FEATURE matrix and the stack's input rows are virtual --
     dict(rows, c, xyz_first, gidx, rel, dims=(b, n, m, ns), idx, order, offsets), see pointnet_util.pointnet_sa_module; cin = 3 + c.
+    preagg (pre-aggregated first layer): x is the (source rows, ldf) feature matrix; dict(rows, c, T, idx, w, per_scene_rows,
+    per_scene_src, side, side_ld, side_n, wf0, ws0 [first rows of W_feat / W_side inside the layer's weights], scatter [callable:
+    (dY (rows, cout), cout) -> (source rows, cout), the transpose of the aggregation]) -- see pointnet_util.
     Raises NotImplementedError (before anything has run) when the first layer's shape is outside what the gathering kernels take."""
     if not layers:
         raise ValueError("mlp_stack needs at least one layer")
@@ -425,7 +499,10 @@ def mlp_stack(x, cin, layers, is_training, bn_decay, pool_ns=None, grad_cols=Non
             raise NotImplementedError("mlp_stack(gather=): needs 16-byte feature rows, >= 2 layers and a first layer of 4k output channels")
         if SYNC_BN:
             raise NotImplementedError("mlp_stack(gather=) with SYNC_BN")
-    if pool_ns and (gather["rows"] if gather is not None else x.shape[0]) % pool_ns:
+    if preagg is not None:
+        if gather is not None or not preagg_ok(layers, is_training, preagg["c"]) or cin != preagg["c"] + preagg["side_n"]:
+            raise NotImplementedError("mlp_stack(preagg=): training-mode BN stacks of >= 2 layers, cin = c + side_n, no gather")
+    if pool_ns and (preagg["rows"] if preagg is not None else (gather["rows"] if gather is not None else x.shape[0])) % pool_ns:
         raise ValueError("rows must be a multiple of pool_ns")
     if grad_cols is not None and not (0 <= grad_cols[0] and grad_cols[1] > 0 and grad_cols[0] + grad_cols[1] <= cin):
         raise ValueError("grad_cols must be a column range inside [0, cin)")
@@ -434,7 +511,7 @@ def mlp_stack(x, cin, layers, is_training, bn_decay, pool_ns=None, grad_cols=Non
         if dist.is_initialized() and dist.get_world_size() > 1:
             return _mlp_stack_sync_bn(x, cin, layers, 0.9 if bn_decay is None else float(bn_decay), pool_ns)
     spec = {"layers": layers, "is_training": is_training, "decay": 0.9 if bn_decay is None else float(bn_decay), "pool_ns": pool_ns,
-            "grad_cols": grad_cols, "gather": gather}
+            "grad_cols": grad_cols, "gather": gather, "preagg": preagg}
     flat = []
     for lp in layers:
         flat += lp.tensors()

@@ -13,7 +13,7 @@ import torch
 from . import _lib as L
 from . import tf_util
 from .geometry import fp_geometry, sa_geometry
-from .mlp import mlp_stack
+from .mlp import mlp_stack, preagg_ok
 from .tf_grouping import group_point, knn_point, query_ball_point
 from .tf_interpolate import three_interpolate, three_nn
 from .tf_sampling import farthest_point_sample, gather_point
@@ -138,6 +138,22 @@ def _sa_stack_gathered(points, geometry, xyz_first, cin, layers, is_training, bn
     m, ns = geometry.idx.shape[1], geometry.idx.shape[2]
     feat = points if c % 4 == 0 else torch.nn.functional.pad(points, (0, 4 - c % 4))     # 16-byte feature rows (the pad columns are ignored)
     feat = feat.reshape(b * n, feat.shape[2])
+    if preagg_ok(layers, bool(is_training), c):
+        # the first layer's feature part on the b*n points instead of the b*m*ns grouped rows (mlp.py: PREAGG)
+        order, offsets, idx = geometry.order, geometry.offsets, geometry.idx
+
+        def scatter(dy, cout):
+            gp = torch.empty((b, n, cout), dtype=torch.float32, device=dy.device)
+            if order is not None:
+                L.check(L.lib().gspn_sa_group_concat_grad_csr(b, n, cout, m, ns, L.ptr(order), L.ptr(offsets), 0, cout, L.ptr(dy), L.ptr(gp), L.stream()),
+                        "sa_group_concat_grad_csr")
+            else:
+                L.check(L.lib().gspn_sa_group_concat_grad(b, n, cout, m, ns, L.ptr(idx), 0, cout, L.ptr(dy), L.ptr(gp), L.stream()), "sa_group_concat_grad")
+            return gp.view(b * n, cout)
+
+        pre = {"rows": b * m * ns, "c": c, "T": 1, "idx": geometry.gidx, "w": None, "per_scene_rows": 0, "per_scene_src": 0,
+               "side": geometry.rel, "side_ld": 4, "side_n": 3, "wf0": 3 if xyz_first else 0, "ws0": 0 if xyz_first else c, "scatter": scatter}
+        return mlp_stack(feat, cin, layers, bool(is_training), bn_decay, pool_ns=nsample, preagg=pre)
     g = {"rows": b * m * ns, "c": c, "xyz_first": xyz_first, "gidx": geometry.gidx, "rel": geometry.rel, "dims": (b, n, m, ns),
          "idx": geometry.idx, "order": geometry.order, "offsets": geometry.offsets}
     try:

@@ -303,6 +303,24 @@ int gspn_mlp_bwd_data_ex(long rows, int cin, int cout, const gspn_dy_args* a, co
                          const float* Yp, int ldyp, const float* scale_p, const float* shift_p, const float* mean_p, const float* var_p,
                          float eps_p, float* part, int* nparts_out, void* stream);
 
+/* Pre-aggregated first layer of an SA / FP module (gspn_amd/csrc/mlp.hip, "Pre-aggregated first layer"): the layer is linear, so its
+ * feature part is multiplied on the SOURCE points (F = feat.W_feat, a small GEMM through gspn_mlp_fwd) and the grouped / interpolated
+ * rows are then formed from F:   Y[r] = sum_t w[r,t] * F[idx[r,t]] + side[r,:side_n] . Wside + bias,   T = 1 (grouping, w = NULL) or 3
+ * (3-NN interpolation).  idx are global source rows, or scene-local ones when per_scene_rows > 0 (output rows / source rows per scene).
+ * stats: the column sums of Y in the layout gspn_bn_finalize(rows, cout, stats, ...) reads (gspn_mlp_fwd_stats_bytes), or NULL.
+ * cout must be 4 * 2^k (gspn_preagg_ok); F, Y 16-byte aligned.  Same result as the GEMM over materialised rows up to fp32 rounding
+ * (a different order of additions). */
+int gspn_preagg_ok(int cout);
+int gspn_preagg_fwd(long rows, int cout, int T, const float* F, const int* idx, const float* w, int per_scene_rows, int per_scene_src,
+                    const float* side, int side_ld, int side_n, const float* Wside, const float* bias, float* Y, float* stats, void* stream);
+/* backward half that touches the (rows, cout) tensors: dY = cA*relu'(y*scale+shift)*dz + cB*y + cC written to dY (rows, cout), and
+ * dWside (side_n, cout) = side^T . dY (per-workgroup partials in part, gspn_preagg_part_floats(cout, side_n) floats, summed in double in a
+ * fixed order).  The rest of the layer's backward runs on source rows: G = transpose-gather of dY (gspn_sa_group_concat_grad_csr /
+ * gspn_fp_concat_grad_csr on dY), dW_feat = feat^T . G, d(feat) = G . W_feat^T (gspn_mlp_bwd_wgrad / gspn_mlp_bwd_data, no BN). */
+long gspn_preagg_part_floats(int cout, int side_n);
+int gspn_preagg_bwd_dy(long rows, int cout, const gspn_dy_args* a, const float* side, int side_ld, int side_n, float* dY, float* part,
+                       float* dWside, void* stream);
+
 /* ---- fused set-abstraction front end: sample_and_group's concat (pointnet_util.py:36-52) + the first conv2d (:109-113)
  * without the grouped (b, npoint, nsample, 3+c) tensor.  gspn_sa_rel writes, per grouped row r = ((i*m + j)*ns + k), its centred
  * coordinates rel[r] = (xyz[i, idx[r]] - new_xyz[i, j], 0) and its source row gidx[r] = i*n + idx[r] (20 bytes per row).  The first

@@ -219,31 +219,36 @@ def test_three_nn_metre_scale_rooms(n, m, offset):
 ])
 def test_fused_sa_front_end_equals_the_materialised_path(kind, b, n, c, npoint, radius, ns, mlp, expect_gather, monkeypatch):
     """the first conv2d gathers its rows from (b,n,c) features + 20 bytes per grouped row (gspn_sa_rel) instead of reading
-    a (b,npoint,nsample,3+c) tensor.  Same module output and gradients as the materialised path to fp32 rounding (the k order of the
-    first GEMM differs: features first), and both against the float64 composition on oracle geometry."""
+    a (b,npoint,nsample,3+c) tensor -- or, with >= 16 feature columns, is pre-aggregated: its feature part is multiplied on the b*n points
+    and the grouped rows are formed from the product (mlp.PREAGG).  Same module output and gradients as the materialised path to fp32
+    rounding (the order of the first layer's additions differs), and all against the float64 composition on oracle geometry."""
+    from gspn_amd import mlp as M
     from gspn_amd import pointnet_util as PU
     from gspn_amd.geometry import sa_geometry
     xyz = D.batch(kind, b, n, 6)
     pts = np.random.default_rng(12).standard_normal((b, n, c)).astype(np.float32)
     tx = dev(xyz)
     res = {}
-    for fused in (True, False):
-        monkeypatch.setattr(PU, "FUSE_SA_FRONT", fused)
+    for mode in ("preagg", "gather", "rows"):
+        monkeypatch.setattr(PU, "FUSE_SA_FRONT", mode != "rows")
+        monkeypatch.setattr(M, "PREAGG", mode == "preagg")
         store = fresh_store(55)
         tp = dev(pts).requires_grad_(True)
-        if fused:       # the gathering kernels must really take this shape (or really decline it)
+        if mode != "rows":       # the kernels must really take this shape (or really decline it)
             geo = sa_geometry(tx, npoint, radius, ns)
             layers = PU._mlp_layers(mlp, 3 + c, 'probe', True)
+            assert M.preagg_ok(layers, True, c) == (mode == "preagg" and c >= 16)
             got = PU._sa_stack_gathered(tp.detach(), geo, True, 3 + c, layers, True, 0.5, ns)
-            assert (got is not None) == expect_gather
+            assert (got is not None) == (expect_gather or M.preagg_ok(layers, True, c))
             store = fresh_store(55)
         new_xyz, new_points, idx = PU.pointnet_sa_module(tx, tp, npoint, radius, ns, mlp, None, False, True, 0.5, 'sa')
         g = torch.from_numpy(np.random.default_rng(5).standard_normal(tuple(new_points.shape)).astype(np.float32)).cuda()
         new_points.backward(g)
-        res[fused] = (new_points.detach(), tp.grad.clone(), {k: v.grad.clone() for k, v in store.named_parameters()}, store)
-    assert rel_err(res[True][0], res[False][0]) < 2e-6
-    assert rel_err(res[True][1], res[False][1]) < 1e-5
-    for k in res[True][2]:
-        assert rel_err(res[True][2][k], res[False][2][k]) < 1e-5, k
-    rnew, ref, ridx, leaves = ref_sa(res[True][3], 'sa', xyz, pts, npoint, radius, ns, mlp, None, False, 'max', False, True, 0.5)
-    assert rel_err(res[True][0], ref) < 1e-5
+        res[mode] = (new_points.detach(), tp.grad.clone(), {k: v.grad.clone() for k, v in store.named_parameters()}, store)
+    for mode in ("preagg", "gather"):
+        assert rel_err(res[mode][0], res["rows"][0]) < 2e-6, mode
+        assert rel_err(res[mode][1], res["rows"][1]) < 1e-5, mode
+        for k in res[mode][2]:
+            assert rel_err(res[mode][2][k], res["rows"][2][k]) < 1e-5, (mode, k)
+    rnew, ref, ridx, leaves = ref_sa(res["preagg"][3], 'sa', xyz, pts, npoint, radius, ns, mlp, None, False, 'max', False, True, 0.5)
+    assert rel_err(res["preagg"][0], ref) < 1e-5
