@@ -767,6 +767,17 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(long rows, int c, cons
     scale[j] = inv;
     shift[j] = be - (float)mu * inv;                                     // beta - mean*inv
 }
+// the same for column sums that did not come from gspn_mlp_fwd: nparts partial rows [nparts][2][c]
+extern "C" int gspn_bn_finalize_parts(long rows, int c, const float* stats, int nparts, const float* gamma, const float* beta, float eps, float decay,
+                                      int is_training, float* moving_mean, float* moving_var, float* mean, float* var, float* scale, float* shift,
+                                      void* stream) {
+    if (rows <= 0 || c <= 0 || !mean || !var || !scale || !shift || nparts < 0) return GSPN_ERR_ARG;
+    if (is_training && !stats) return GSPN_ERR_ARG;
+    if (!is_training && (!moving_mean || !moving_var)) return GSPN_ERR_ARG;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(c), dim3(256), 0, (hipStream_t)stream, rows, c, stats, nparts, gamma, beta,
+                       eps, decay, is_training, moving_mean, moving_var, mean, var, scale, shift);
+    return gspn_launch_status();
+}
 extern "C" int gspn_bn_finalize(long rows, int c, const float* stats, const float* gamma, const float* beta, float eps, float decay,
                                 int is_training, float* moving_mean, float* moving_var, float* mean, float* var,
                                 float* scale, float* shift, void* stream) {
@@ -2067,6 +2078,7 @@ template <int T>
 __global__ __launch_bounds__(256) void preagg_fwd_kernel(long rows, int cout, PreaggSrc ps, const float* __restrict__ Ws, const float* __restrict__ bias,
                                                          float* __restrict__ Y, float* __restrict__ stats) {
     extern __shared__ float pa_sh[];                 // [2][rpi][cout]
+    constexpr int U = 4;                             // rows per thread in flight (the chain index -> gathered row -> store is all latency)
     const int cq = cout >> 2, rpi = 256 / cq;
     const int q = threadIdx.x % cq, rr = threadIdx.x / cq;
     float4 wsd[4];
@@ -2074,32 +2086,42 @@ __global__ __launch_bounds__(256) void preagg_fwd_kernel(long rows, int cout, Pr
     for (int k = 0; k < 4; ++k) wsd[k] = k < ps.side_n ? *reinterpret_cast<const float4*>(Ws + (size_t)k * cout + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 bq = bias ? *reinterpret_cast<const float4*>(bias + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
     float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
-    for (long r = (long)blockIdx.x * rpi + rr; r < rows; r += (long)gridDim.x * rpi) {
-        const long base = ps.per_scene_rows > 0 ? (r / ps.per_scene_rows) * (long)ps.per_scene_src : 0;
-        float4 f[T];
-        float wt[T];
+    const long stride = (long)gridDim.x * rpi;
+    for (long r0 = (long)blockIdx.x * rpi + rr; r0 < rows; r0 += U * stride) {
+        float4 f[U][T];
+        float wt[U][T], sd[U][4];
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
-            const long src = base + ps.idx[r * T + t];
-            f[t] = *reinterpret_cast<const float4*>(ps.F + (size_t)src * cout + 4 * q);
-            wt[t] = ps.w ? ps.w[r * T + t] : 1.f;
-        }
-        float sd[4];
+        for (int u = 0; u < U; ++u) {
+            const long r = r0 + u * stride;
+            const long rc = r < rows ? r : rows - 1;             // clamped: unconditional loads, masked at the store
+            const long base = ps.per_scene_rows > 0 ? (rc / ps.per_scene_rows) * (long)ps.per_scene_src : 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) sd[k] = k < ps.side_n ? ps.side[(size_t)r * ps.side_ld + k] : 0.f;
-        float4 y;
-        if (T == 1 && !ps.w) y = f[0];
-        else {
-            y = make_float4(f[0].x * wt[0], f[0].y * wt[0], f[0].z * wt[0], f[0].w * wt[0]);
+            for (int t = 0; t < T; ++t) {
+                const long src = base + ps.idx[rc * T + t];
+                f[u][t] = *reinterpret_cast<const float4*>(ps.F + (size_t)src * cout + 4 * q);
+                wt[u][t] = ps.w ? ps.w[rc * T + t] : 1.f;
+            }
 #pragma unroll
-            for (int t = 1; t < T; ++t) { y.x += f[t].x * wt[t]; y.y += f[t].y * wt[t]; y.z += f[t].z * wt[t]; y.w += f[t].w * wt[t]; }
+            for (int k = 0; k < 4; ++k) sd[u][k] = k < ps.side_n ? ps.side[(size_t)rc * ps.side_ld + k] : 0.f;
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { y.x += sd[k] * wsd[k].x; y.y += sd[k] * wsd[k].y; y.z += sd[k] * wsd[k].z; y.w += sd[k] * wsd[k].w; }
-        y.x += bq.x; y.y += bq.y; y.z += bq.z; y.w += bq.w;
-        *reinterpret_cast<float4*>(Y + (size_t)r * cout + 4 * q) = y;
-        s1.x += y.x; s1.y += y.y; s1.z += y.z; s1.w += y.w;
-        s2.x += y.x * y.x; s2.y += y.y * y.y; s2.z += y.z * y.z; s2.w += y.w * y.w;
+        for (int u = 0; u < U; ++u) {
+            const long r = r0 + u * stride;
+            if (r >= rows) break;
+            float4 y;
+            if (T == 1 && !ps.w) y = f[u][0];
+            else {
+                y = make_float4(f[u][0].x * wt[u][0], f[u][0].y * wt[u][0], f[u][0].z * wt[u][0], f[u][0].w * wt[u][0]);
+#pragma unroll
+                for (int t = 1; t < T; ++t) { y.x += f[u][t].x * wt[u][t]; y.y += f[u][t].y * wt[u][t]; y.z += f[u][t].z * wt[u][t]; y.w += f[u][t].w * wt[u][t]; }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { y.x += sd[u][k] * wsd[k].x; y.y += sd[u][k] * wsd[k].y; y.z += sd[u][k] * wsd[k].z; y.w += sd[u][k] * wsd[k].w; }
+            y.x += bq.x; y.y += bq.y; y.z += bq.z; y.w += bq.w;
+            *reinterpret_cast<float4*>(Y + (size_t)r * cout + 4 * q) = y;
+            s1.x += y.x; s1.y += y.y; s1.z += y.z; s1.w += y.w;
+            s2.x += y.x * y.x; s2.y += y.y * y.y; s2.z += y.z * y.z; s2.w += y.w * y.w;
+        }
     }
     if (!stats) return;
     *reinterpret_cast<float4*>(pa_sh + ((size_t)0 * rpi + rr) * cout + 4 * q) = s1;
@@ -2114,13 +2136,22 @@ __global__ __launch_bounds__(256) void preagg_fwd_kernel(long rows, int cout, Pr
 }
 static bool preagg_shape_ok(int cout) { return cout >= 4 && cout <= 1024 && (cout & 3) == 0 && ((cout >> 2) & ((cout >> 2) - 1)) == 0; }
 extern "C" int gspn_preagg_ok(int cout) { return preagg_shape_ok(cout) ? 1 : 0; }
+// workgroups (= partial statistics rows) of gspn_preagg_fwd: every thread gets about four rows, 2048 workgroups at most
+#define PREAGG_FWD_BLOCKS 2048
+static unsigned preagg_fwd_blocks(long rows, int cout) {
+    const long rpi = 256 / (cout >> 2);
+    long nb = (rows + 4 * rpi - 1) / (4 * rpi);
+    if (nb > PREAGG_FWD_BLOCKS) nb = PREAGG_FWD_BLOCKS;
+    return (unsigned)(nb < 1 ? 1 : nb);
+}
+extern "C" long gspn_preagg_fwd_parts(long rows, int cout) { return (rows > 0 && preagg_shape_ok(cout)) ? (long)preagg_fwd_blocks(rows, cout) : GSPN_ERR_ARG; }
 extern "C" int gspn_preagg_fwd(long rows, int cout, int T, const float* F, const int* idx, const float* w, int per_scene_rows, int per_scene_src,
                                const float* side, int side_ld, int side_n, const float* Wside, const float* bias, float* Y, float* stats, void* stream) {
     if (rows <= 0 || !F || !idx || !Y || (T != 1 && T != 3) || side_n < 0 || side_n > 4 || (side_n > 0 && (!side || !Wside || side_ld < side_n))) return GSPN_ERR_ARG;
     if (!preagg_shape_ok(cout) || rows >= (1L << 31)) return GSPN_ERR_UNSUPPORTED;
     if (((uintptr_t)F % 16) || ((uintptr_t)Y % 16) || (Wside && ((uintptr_t)Wside % 16)) || (bias && ((uintptr_t)bias % 16))) return GSPN_ERR_ARG;
     const PreaggSrc ps{F, idx, w, per_scene_rows, per_scene_src, side, side_ld, side_n};
-    const unsigned nb = fwd_blocks(rows, cout);          // = the number of partial rows gspn_bn_finalize sums for (rows, cout)
+    const unsigned nb = preagg_fwd_blocks(rows, cout);   // = the number of partial rows: gspn_bn_finalize_parts(..., gspn_preagg_fwd_parts(rows, cout), ...)
     const size_t sh = sizeof(float) * 2 * 256 * 4;       // 2 * rpi * cout floats, rpi * cout = 1024
     if (T == 1) hipLaunchKernelGGL(preagg_fwd_kernel<1>, dim3(nb), dim3(256), sh, (hipStream_t)stream, rows, cout, ps, Wside, bias, Y, stats);
     else hipLaunchKernelGGL(preagg_fwd_kernel<3>, dim3(nb), dim3(256), sh, (hipStream_t)stream, rows, cout, ps, Wside, bias, Y, stats);

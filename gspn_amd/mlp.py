@@ -121,7 +121,12 @@ class _MlpStack(torch.autograd.Function):
                 cout = lp.weights.shape[1]
                 y = torch.empty((rows, cout), dtype=torch.float32, device=dev)
                 use_stats = lp.bn and is_training
-                stats = torch.empty(int(lib.gspn_mlp_fwd_stats_bytes(rows, cout)) // 4, dtype=torch.float32, device=dev) if use_stats else None
+                pre0 = pre if li == 0 else None
+                if pre0 is not None:
+                    nparts0 = int(lib.gspn_preagg_fwd_parts(rows, cout))
+                    stats = torch.empty(nparts0 * 2 * cout, dtype=torch.float32, device=dev) if use_stats else None
+                else:
+                    stats = torch.empty(int(lib.gspn_mlp_fwd_stats_bytes(rows, cout)) // 4, dtype=torch.float32, device=dev) if use_stats else None
                 ev = _tic()
                 if FUSE_POOL32 and pool_ns == 32 and li == len(layers) - 1 and rows % 32 == 0:
                     g32 = rows // 32
@@ -150,7 +155,11 @@ class _MlpStack(torch.autograd.Function):
                 var = torch.empty(cout, dtype=torch.float32, device=dev)
                 scale = torch.empty(cout, dtype=torch.float32, device=dev)
                 shift = torch.empty(cout, dtype=torch.float32, device=dev)
-                if lp.bn:
+                if lp.bn and pre0 is not None:
+                    L.check(lib.gspn_bn_finalize_parts(rows, cout, L.ptr(stats), nparts0, L.ptr(lp.gamma), L.ptr(lp.beta), BN_EPS, decay,
+                                                       int(is_training), L.ptr(lp.moving_mean), L.ptr(lp.moving_variance),
+                                                       L.ptr(mean), L.ptr(var), L.ptr(scale), L.ptr(shift), st), "bn_finalize")
+                elif lp.bn:
                     L.check(lib.gspn_bn_finalize(rows, cout, L.ptr(stats), L.ptr(lp.gamma), L.ptr(lp.beta), BN_EPS, decay,
                                                  int(is_training), L.ptr(lp.moving_mean), L.ptr(lp.moving_variance),
                                                  L.ptr(mean), L.ptr(var), L.ptr(scale), L.ptr(shift), st), "bn_finalize")
@@ -356,6 +365,18 @@ class _MlpStack(torch.autograd.Function):
         return (dx0, None, None) + tuple(grads)
 
 
+_consts = {}
+
+
+def _const_vectors(dev, c):
+    """(ones(c), zeros(c)) on dev, made once: read-only operands of the no-BN GEMM calls"""
+    key = (dev.type, dev.index, c)
+    v = _consts.get(key)
+    if v is None:
+        v = _consts[key] = (torch.ones(c, dtype=torch.float32, device=dev), torch.zeros(c, dtype=torch.float32, device=dev))
+    return v
+
+
 def _preagg_backward(lib, pre, x, lp, a, rows, cout, need_dx, dev, st):
     """backward of a pre-aggregated first layer: dY written once (+ dW_side), its transpose-gather G onto the source rows, then
     dW_feat = feat^T . G and d(feat) = G . W_feat^T as small GEMMs without BN (always-open mask: scale 0, shift 1, dY = dz)"""
@@ -368,20 +389,17 @@ def _preagg_backward(lib, pre, x, lp, a, rows, cout, need_dx, dev, st):
             "preagg_bwd_dy")
     nsrc = x.shape[0]
     gsrc = pre["scatter"](dy, cout)                                 # (source rows, cout): sum over the output rows each source row fed
-    one = torch.ones(cout, dtype=torch.float32, device=dev)
-    zero = torch.zeros(cout, dtype=torch.float32, device=dev)
-    cA, cB, cC = torch.empty_like(one), torch.empty_like(one), torch.empty_like(one)
+    one, zero = _const_vectors(dev, cout)
     a2 = L.DyArgs()
     a2.Y, a2.ldy = gsrc.data_ptr(), cout
     a2.dZ, a2.ldz, a2.dPool, a2.pool_arg, a2.ns = gsrc.data_ptr(), cout, None, None, 0
-    a2.scale, a2.shift = zero.data_ptr(), one.data_ptr()
-    a2.cA, a2.cB, a2.cC = cA.data_ptr(), cB.data_ptr(), cC.data_ptr()
+    a2.scale, a2.shift = zero.data_ptr(), one.data_ptr()           # always-open mask
+    a2.cA, a2.cB, a2.cC = one.data_ptr(), zero.data_ptr(), zero.data_ptr()      # known coefficients: dY = dz
     dwf = dW[pre["wf0"]:pre["wf0"] + c]
     wf = lp.weights[pre["wf0"]:pre["wf0"] + c]
-    dbias_unused = torch.empty(cout, dtype=torch.float32, device=dev)
     work = torch.empty(int(lib.gspn_mlp_bwd_work_bytes(nsrc, c, cout)) // 4 + 4, dtype=torch.float32, device=dev)
-    L.check(lib.gspn_mlp_bwd_wgrad(nsrc, c, cout, ctypes.byref(a2), L.ptr(x), x.shape[1], None, None, None, None, None, BN_EPS, 0, 0,
-                                   L.ptr(work), L.ptr(cA), L.ptr(cB), L.ptr(cC), None, None, L.ptr(dbias_unused), L.ptr(dwf), st), "mlp_bwd_wgrad(pre-aggregation)")
+    L.check(lib.gspn_mlp_bwd_wgrad_known(nsrc, c, cout, ctypes.byref(a2), L.ptr(x), x.shape[1], None, None, None, L.ptr(work), L.ptr(dwf), st),
+            "mlp_bwd_wgrad_known(pre-aggregation)")
     dx = None
     if need_dx:
         dx = torch.empty((nsrc, x.shape[1]), dtype=torch.float32, device=dev)

@@ -218,6 +218,10 @@ long gspn_mlp_fwd_stats_bytes(long rows, int cout);
 int gspn_bn_finalize(long rows, int c, const float* stats, const float* gamma, const float* beta, float eps, float decay,
                      int is_training, float* moving_mean, float* moving_var, float* mean, float* var,
                      float* scale, float* shift, void* stream);
+/* the same on nparts partial rows [nparts][2][c] of column sums from any producer (e.g. gspn_preagg_fwd) */
+int gspn_bn_finalize_parts(long rows, int c, const float* stats, int nparts, const float* gamma, const float* beta, float eps, float decay,
+                           int is_training, float* moving_mean, float* moving_var, float* mean, float* var, float* scale, float* shift,
+                           void* stream);
 
 /* out(groups,c) = max over the ns rows of each group of relu(Y*scale+shift)   (tf.reduce_max,
  * pointnet_util.py:123-124); arg (groups,c) gets the row offset (0..ns-1) of the first maximum. */
@@ -307,10 +311,11 @@ int gspn_mlp_bwd_data_ex(long rows, int cin, int cout, const gspn_dy_args* a, co
  * feature part is multiplied on the SOURCE points (F = feat.W_feat, a small GEMM through gspn_mlp_fwd) and the grouped / interpolated
  * rows are then formed from F:   Y[r] = sum_t w[r,t] * F[idx[r,t]] + side[r,:side_n] . Wside + bias,   T = 1 (grouping, w = NULL) or 3
  * (3-NN interpolation).  idx are global source rows, or scene-local ones when per_scene_rows > 0 (output rows / source rows per scene).
- * stats: the column sums of Y in the layout gspn_bn_finalize(rows, cout, stats, ...) reads (gspn_mlp_fwd_stats_bytes), or NULL.
+ * stats: the column sums of Y, gspn_preagg_fwd_parts(rows, cout) partial rows for gspn_bn_finalize_parts, or NULL.
  * cout must be 4 * 2^k (gspn_preagg_ok); F, Y 16-byte aligned.  Same result as the GEMM over materialised rows up to fp32 rounding
  * (a different order of additions). */
 int gspn_preagg_ok(int cout);
+long gspn_preagg_fwd_parts(long rows, int cout);     /* partial rows [parts][2][cout] gspn_preagg_fwd writes into stats */
 int gspn_preagg_fwd(long rows, int cout, int T, const float* F, const int* idx, const float* w, int per_scene_rows, int per_scene_src,
                     const float* side, int side_ld, int side_n, const float* Wside, const float* bias, float* Y, float* stats, void* stream);
 /* backward half that touches the (rows, cout) tensors: dY = cA*relu'(y*scale+shift)*dz + cB*y + cC written to dY (rows, cout), and
