@@ -128,6 +128,7 @@ def group_concat(xyz, new_xyz, points, idx, xyz_first=True, order=None, offsets=
 
 
 # fused SA front end: first conv2d straight from (b, n, c) features + 20 bytes per grouped row, no (b,m,ns,3+c) tensor
+FUSE_FP_FRONT = os.environ.get("GSPN_FUSE_FP_FRONT", "1") != "0"
 FUSE_SA_FRONT = os.environ.get("GSPN_FUSE_SA_FRONT", "1") != "0"
 
 
@@ -266,6 +267,31 @@ def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_al
         return new_xyz, new_points, idx
 
 
+def _fp_stack_preagg(points2, points1, geometry, cin, layers, is_training, bn_decay):
+    """the FP module's conv stack with a pre-aggregated first layer (mlp_stack(preagg=)): T = 3 weighted source rows per dense row"""
+    points2 = L.need(points2, torch.float32, 3, "points2")
+    b, m, c2 = points2.shape
+    idx = L.need(geometry.idx, torch.int32, 3, "idx")
+    weight = L.need(geometry.weight.detach(), torch.float32, 3, "weight")
+    n1 = idx.shape[1]
+    side = None if points1 is None else L.need(points1.detach(), torch.float32, 3, "points1")
+    c1 = 0 if side is None else side.shape[2]
+    order, offsets = geometry.order, geometry.offsets
+
+    def scatter(dy, cout):
+        g2 = torch.empty((b, m, cout), dtype=torch.float32, device=dy.device)
+        if order is not None:
+            L.check(L.lib().gspn_fp_concat_grad_csr(b, n1, m, cout, 0, cout, L.ptr(dy), L.ptr(order), L.ptr(offsets), L.ptr(weight), L.ptr(g2), None,
+                                                    L.stream()), "fp_concat_grad_csr")
+        else:
+            L.check(L.lib().gspn_fp_concat_grad(b, n1, m, cout, 0, cout, L.ptr(dy), L.ptr(idx), L.ptr(weight), L.ptr(g2), None, L.stream()), "fp_concat_grad")
+        return g2.view(b * m, cout)
+
+    pre = {"rows": b * n1, "c": c2, "T": 3, "idx": idx, "w": weight, "per_scene_rows": n1, "per_scene_src": m,
+           "side": side, "side_ld": max(c1, 1), "side_n": c1, "wf0": 0, "ws0": c2, "scatter": scatter}
+    return mlp_stack(points2.reshape(b * m, c2), cin, layers, bool(is_training), bn_decay, pool_ns=None, preagg=pre)
+
+
 def pointnet_fp_module(xyz1, xyz2, points1, points2, mlp, is_training, bn_decay, scope, bn=True, reuse=False, geometry=None):
     """pointnet_util.py:142-174.  xyz1 (b,n1,3) dense, xyz2 (b,n2,3) sparse, points1 (b,n1,c1) or None,
     points2 (b,n2,c2) -> (b,n1,mlp[-1])  (or the concatenated features when mlp == []).
@@ -282,8 +308,15 @@ def pointnet_fp_module(xyz1, xyz2, points1, points2, mlp, is_training, bn_decay,
         # fused: interpolate + concat + 16-byte row pitch in one pass, straight into the MLP's input matrix
         b, n1 = idx.shape[0], idx.shape[1]
         cin = points2.shape[2] + (0 if points1 is None else points1.shape[2])
-        x2d = fp_concat(points2, idx, weight, points1, geometry.order, geometry.offsets)
         layers = _mlp_layers(mlp, cin, 'conv_', bn)
+        c1 = 0 if points1 is None else points1.shape[2]
+        if (FUSE_FP_FRONT and c1 <= 4 and (points1 is None or not points1.requires_grad) and points2.shape[2] % 4 == 0
+                and preagg_ok(layers, bool(is_training), points2.shape[2])):
+            # the first layer's interpolated part on the n2 sparse points (linear: interpolate(points2) . W = interpolate(points2 . W)),
+            # the <= 4 skip-link columns per dense row on the side (mlp.py: PREAGG) -- the (b*n1, c2 + c1) matrix is never written
+            out = _fp_stack_preagg(points2, points1, geometry, cin, layers, is_training, bn_decay)
+            return out.view(b, n1, mlp[-1])
+        x2d = fp_concat(points2, idx, weight, points1, geometry.order, geometry.offsets)
         # fp_concat's gradient reads the points1 columns only if points1 wants a gradient (the last FP level gets raw colours)
         c2 = points2.shape[2]
         gcols = (0, c2) if (points1 is not None and not points1.requires_grad) else None

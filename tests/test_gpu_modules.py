@@ -121,6 +121,55 @@ def test_fp_module_matches_oracle(b, n1, n2, c1, c2, mlp):
         assert rel_err(t1.grad, p1r.grad) < 1e-4
 
 
+@pytest.mark.parametrize("b,n1,n2,c1,c2,mlp", [(2, 4096, 512, 3, 64, [64, 64, 64]), (1, 1500, 200, 0, 32, [32, 16]), (2, 900, 128, 4, 128, [64, 32])])
+def test_fp_module_preaggregated_first_layer(b, n1, n2, c1, c2, mlp, monkeypatch):
+    """FP module whose skip link carries no gradient and has <= 4 columns (the last FP level: raw colours): the first layer's
+    interpolated part is multiplied on the n2 sparse points (mlp.PREAGG).  Against the float64 composition and against the path that
+    writes the concatenated matrix (outputs, d(points2), every parameter gradient)."""
+    from gspn_amd import pointnet_util as PU
+    xyz1 = D.batch("D", b, n1, 3)
+    xyz2 = O.gather_point(xyz1, O.farthest_point_sample(n2, xyz1))
+    rng = np.random.default_rng(23)
+    p1 = rng.standard_normal((b, n1, c1)).astype(np.float32) if c1 else None
+    p2 = rng.standard_normal((b, n2, c2)).astype(np.float32)
+    g = rng.standard_normal((b, n1, mlp[-1])).astype(np.float32)
+    res = {}
+    for pre in (True, False):
+        monkeypatch.setattr(PU, "FUSE_FP_FRONT", pre)
+        store = fresh_store(99)
+        t1 = torch.from_numpy(p1).cuda() if c1 else None
+        t2 = torch.from_numpy(p2).cuda().requires_grad_(True)
+        if pre:
+            calls = []
+            real = PU._fp_stack_preagg
+            monkeypatch.setattr(PU, "_fp_stack_preagg", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+        out = PU.pointnet_fp_module(torch.from_numpy(xyz1).cuda(), torch.from_numpy(xyz2).cuda(), t1, t2, mlp, True, 0.5, 'fa')
+        if pre:
+            assert calls, "the pre-aggregated path did not take this shape"
+            monkeypatch.setattr(PU, "_fp_stack_preagg", real)
+        out.backward(torch.from_numpy(g).cuda())
+        res[pre] = (out.detach(), t2.grad.clone(), {k: v.grad.clone() for k, v in store.named_parameters()}, store)
+    assert rel_err(res[True][0], res[False][0]) < 2e-6
+    assert rel_err(res[True][1], res[False][1]) < 1e-5
+    for k in res[True][2]:
+        assert rel_err(res[True][2][k], res[False][2][k]) < 1e-5, k
+    rd, ri = O.three_nn(xyz1, xyz2)
+    w64 = R.fp_weights(torch.from_numpy(rd).double())
+    p2r = torch.from_numpy(p2).double().requires_grad_(True)
+    gi = torch.from_numpy(ri.astype(np.int64))
+    bi = torch.arange(b)[:, None, None].expand_as(gi)
+    interp = (p2r[bi, gi] * w64[..., None]).sum(2)
+    cat = torch.cat([interp, torch.from_numpy(p1).double()], 2) if c1 else interp
+    ps = ref_params(res[True][3], 'fa', ['conv_%d' % i for i in range(len(mlp))])
+    for p in ps:
+        p["moving_mean"] = torch.zeros_like(p["moving_mean"])
+        p["moving_var"] = torch.ones_like(p["moving_var"])
+    ref, _ = R.stack(cat.reshape(b * n1, -1), ps, True, 0.5, None)
+    assert rel_err(res[True][0], ref.view(b, n1, mlp[-1])) < 1e-5
+    ref.view(b, n1, mlp[-1]).backward(torch.from_numpy(g).double())
+    assert rel_err(res[True][1], p2r.grad) < 1e-4
+
+
 def test_fea_extractor_runs_and_backprops():
     """BASELINE config 3 graph at a reduced cloud size: shapes, finiteness, every parameter gets a gradient"""
     from gspn_amd import tf_util
