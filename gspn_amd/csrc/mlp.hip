@@ -2074,11 +2074,11 @@ struct PreaggSrc {
     const float* side;     // (rows, side_ld), side_n <= 4 columns used
     int side_ld, side_n;
 };
-template <int T>
+template <int T, int U>
 __global__ __launch_bounds__(256) void preagg_fwd_kernel(long rows, int cout, PreaggSrc ps, const float* __restrict__ Ws, const float* __restrict__ bias,
                                                          float* __restrict__ Y, float* __restrict__ stats) {
     extern __shared__ float pa_sh[];                 // [2][rpi][cout]
-    constexpr int U = 4;                             // rows per thread in flight (the chain index -> gathered row -> store is all latency)
+    // U rows per thread in flight (the chain index -> gathered row -> store is all latency)
     const int cq = cout >> 2, rpi = 256 / cq;
     const int q = threadIdx.x % cq, rr = threadIdx.x / cq;
     float4 wsd[4];
@@ -2086,14 +2086,21 @@ __global__ __launch_bounds__(256) void preagg_fwd_kernel(long rows, int cout, Pr
     for (int k = 0; k < 4; ++k) wsd[k] = k < ps.side_n ? *reinterpret_cast<const float4*>(Ws + (size_t)k * cout + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 bq = bias ? *reinterpret_cast<const float4*>(bias + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
     float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
-    const long stride = (long)gridDim.x * rpi;
-    for (long r0 = (long)blockIdx.x * rpi + rr; r0 < rows; r0 += U * stride) {
+    // workgroup b runs on XCD b % 8: give each XCD one contiguous eighth of the rows (with 8 scenes, one scene), so that the source rows
+    // it gathers -- one scene's slice of F -- stay in that XCD's L2 instead of all of F in every L2
+    const int nx = (gridDim.x % 8 == 0 && rows >= 8L * 256) ? 8 : 1;
+    const long part = (rows + nx - 1) / nx;
+    const long p0 = (long)(blockIdx.x % nx) * part, p1 = min(rows, p0 + part);
+    const long stride = (long)(gridDim.x / nx) * rpi;
+    for (long r0 = p0 + (long)(blockIdx.x / nx) * rpi + rr; r0 < p1; r0 += U * stride) {
         float4 f[U][T];
         float wt[U][T], sd[U][4];
+        long rowq[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const long r = r0 + u * stride;
-            const long rc = r < rows ? r : rows - 1;             // clamped: unconditional loads, masked at the store
+            long rc = r < p1 ? r : p1 - 1;                       // clamped: unconditional loads, masked at the store
+            rowq[u] = rc;
             const long base = ps.per_scene_rows > 0 ? (rc / ps.per_scene_rows) * (long)ps.per_scene_src : 0;
 #pragma unroll
             for (int t = 0; t < T; ++t) {
@@ -2106,8 +2113,8 @@ __global__ __launch_bounds__(256) void preagg_fwd_kernel(long rows, int cout, Pr
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const long r = r0 + u * stride;
-            if (r >= rows) break;
+            if (r0 + u * stride >= p1) break;
+            const long r = rowq[u];
             float4 y;
             if (T == 1 && !ps.w) y = f[u][0];
             else {
@@ -2141,7 +2148,9 @@ extern "C" int gspn_preagg_ok(int cout) { return preagg_shape_ok(cout) ? 1 : 0; 
 static unsigned preagg_fwd_blocks(long rows, int cout) {
     const long rpi = 256 / (cout >> 2);
     long nb = (rows + 4 * rpi - 1) / (4 * rpi);
-    if (nb > PREAGG_FWD_BLOCKS) nb = PREAGG_FWD_BLOCKS;
+    static const int cap = env_int("GSPN_PREAGG_BLOCKS", PREAGG_FWD_BLOCKS);
+    if (nb > cap) nb = cap;
+    if (nb >= 64) nb = nb / 8 * 8;                       // a multiple of the 8 XCDs: the kernel then gives each XCD its own eighth of the rows
     return (unsigned)(nb < 1 ? 1 : nb);
 }
 extern "C" long gspn_preagg_fwd_parts(long rows, int cout) { return (rows > 0 && preagg_shape_ok(cout)) ? (long)preagg_fwd_blocks(rows, cout) : GSPN_ERR_ARG; }
@@ -2153,8 +2162,11 @@ extern "C" int gspn_preagg_fwd(long rows, int cout, int T, const float* F, const
     const PreaggSrc ps{F, idx, w, per_scene_rows, per_scene_src, side, side_ld, side_n};
     const unsigned nb = preagg_fwd_blocks(rows, cout);   // = the number of partial rows: gspn_bn_finalize_parts(..., gspn_preagg_fwd_parts(rows, cout), ...)
     const size_t sh = sizeof(float) * 2 * 256 * 4;       // 2 * rpi * cout floats, rpi * cout = 1024
-    if (T == 1) hipLaunchKernelGGL(preagg_fwd_kernel<1>, dim3(nb), dim3(256), sh, (hipStream_t)stream, rows, cout, ps, Wside, bias, Y, stats);
-    else hipLaunchKernelGGL(preagg_fwd_kernel<3>, dim3(nb), dim3(256), sh, (hipStream_t)stream, rows, cout, ps, Wside, bias, Y, stats);
+    static const int uu = env_int("GSPN_PREAGG_U", 2);
+#define PA_GO(T_, U_) hipLaunchKernelGGL((preagg_fwd_kernel<T_, U_>), dim3(nb), dim3(256), sh, (hipStream_t)stream, rows, cout, ps, Wside, bias, Y, stats)
+    if (T == 1) { if (uu == 1) PA_GO(1, 1); else if (uu == 2) PA_GO(1, 2); else PA_GO(1, 4); }
+    else { if (uu == 1) PA_GO(3, 1); else if (uu == 2) PA_GO(3, 2); else PA_GO(3, 4); }
+#undef PA_GO
     return gspn_launch_status();
 }
 // dY = cA * relu'(y*scale+shift) * dz + cB * y + cC, written out (rows, cout); per workgroup the partial side^T . dY (side_n x cout) into
