@@ -254,7 +254,9 @@ class _MlpStack(torch.autograd.Function):
                 if li == 0 and ctx.pre is not None:
                     if known is None:
                         raise RuntimeError("mlp_stack(preagg=): the first layer's BN coefficients must be known before its backward (EARLY_R)")
+                    ev = _tic()
                     dW, dx0 = _preagg_backward(lib, ctx.pre, ctx.pre_x, lp, a, rows, cout, ctx.x_needs_grad, dev, st)
+                    _toc(ev, "bwd", rows, cin, cout)          # (the whole backward of the layer, both "passes")
                     g = [dW, dbias]
                     if lp.bn:
                         g += [dbeta, dgamma]
