@@ -2259,8 +2259,15 @@ extern "C" int gspn_mlp_bwd_dw(long rows, int cin, int cout, const gspn_dy_args*
 // scale/shift); the epilogue also takes that layer's BN reductions sum(dyh), sum(dyh*xhat) from the finished tiles -- per-workgroup
 // partials part[workgroup][2][cin], summed by gspn_mlp_bwd_coef -- so its pass A can run with final coefficients (one GEMM).
 struct RsumArgs { const float* Yp; int ldyp; const float* scale; const float* shift; const float* mean; const float* var; float eps; float* part; };
+#ifndef GSPN_BWD_WPE32
+#define GSPN_BWD_WPE32 3
+#endif
+#ifndef GSPN_BWD_WPE64
+#define GSPN_BWD_WPE64 3
+#endif
 template <int BN, bool VEC, bool POOLED, bool DW>
-__global__ __launch_bounds__(256) void mlp_bwd_data_kernel(long rows, int cin, int cout, gspn_dy_args a, const float* __restrict__ W,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN <= 32 ? GSPN_BWD_WPE32 : (BN <= 64 ? GSPN_BWD_WPE64 : 2))))
+void mlp_bwd_data_kernel(long rows, int cin, int cout, gspn_dy_args a, const float* __restrict__ W,
                                                            float* __restrict__ dX, int ldx, int col0, DwJob dwj, RsumArgs rs) {
     // `cin` is the END of the column range [col0, cin) of dX this launch produces (gspn_mlp_bwd_data_cols)
     constexpr int NT = BN / 32;
@@ -2475,9 +2482,13 @@ static int bwd_data_launch(long rows, int cin, int cout, const gspn_dy_args* a, 
     const int cend = col0 + ncols;
     const DwJob none = dw_job(0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0, 0, nullptr);
     const unsigned extra = dwj ? (unsigned)dwj->nblk : 0u;
+    // workgroups per CU the grid is sized for.  3 reside (waves per SIMD: the amdgpu_waves_per_eu attribute of the kernel keeps the 32- and
+    // 64-column tiles under 168 VGPRs; 2 for 128), yet 4 measures best (pass B of the bench step: 648 / 596 / 581 us at 2 / 3 / 4):
+    // the fourth quarter of the workgroups fills the slots the first finishers free.  GSPN_BWD_BPC overrides (tuning hook).
+    static const int bpc_narrow = env_int("GSPN_BWD_BPC", 4);
 #define BD_GO(BN_, V_, P_, YT_)                                                                                                       \
     do {                                                                                                                               \
-        const unsigned rg = row_grid(rows, YT_, BN_ >= 128 ? env_int("GSPN_BWD_WIDE_BPC", 3) : 4);                                      \
+        const unsigned rg = row_grid(rows, YT_, BN_ >= 128 ? 2 : bpc_narrow);                                                          \
         const dim3 g(dwj ? rg * (unsigned)(YT_) + extra : rg, dwj ? 1 : YT_);                                                          \
         if (nparts_out) *nparts_out = (int)rg;                                                                                         \
         DwJob dj = dwj ? *dwj : none;                                                                                                  \
