@@ -211,8 +211,11 @@ extern "C" int gspn_pool32_select(long groups, int c, const float* vmax, const i
 // sA is K-major [TK][129] (written transposed from float4 row segments, 2 x ds_write2_b32),
 // sB is [TK][BN+4] (straight float4 copy of W rows).
 // ============================================================================================
+// (waves per SIMD: left alone, the 128-column instance takes 277 registers = ONE workgroup per CU; capped at 256 it spills nothing that
+//  matters and two reside: 45 -> 33 us on the 32768 x 128 -> 256 layer.  Three waves for the 64-column instance measured no gain.)
 template <int BN, bool VEC>
-__global__ __launch_bounds__(256) void mlp_fwd_kernel(long rows, int cin, int cout, const float* __restrict__ X, int ldx,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN <= 32 ? 3 : 2)))
+void mlp_fwd_kernel(long rows, int cin, int cout, const float* __restrict__ X, int ldx,
                                                       const float* __restrict__ in_scale, const float* __restrict__ in_shift,
                                                       const float* __restrict__ W, const float* __restrict__ bias,
                                                       float* __restrict__ Y, int ldy, float* __restrict__ stats, PoolOut po) {
