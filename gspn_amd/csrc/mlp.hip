@@ -2262,6 +2262,9 @@ extern "C" int gspn_mlp_bwd_dw(long rows, int cin, int cout, const gspn_dy_args*
 // scale/shift); the epilogue also takes that layer's BN reductions sum(dyh), sum(dyh*xhat) from the finished tiles -- per-workgroup
 // partials part[workgroup][2][cin], summed by gspn_mlp_bwd_coef -- so its pass A can run with final coefficients (one GEMM).
 struct RsumArgs { const float* Yp; int ldyp; const float* scale; const float* shift; const float* mean; const float* var; float eps; float* part; };
+#ifndef GSPN_BWD_TK
+#define GSPN_BWD_TK 32
+#endif
 #ifndef GSPN_BWD_WPE32
 #define GSPN_BWD_WPE32 3
 #endif
@@ -2275,9 +2278,13 @@ void mlp_bwd_data_kernel(long rows, int cin, int cout, gspn_dy_args a, const flo
     // `cin` is the END of the column range [col0, cin) of dX this launch produces (gspn_mlp_bwd_data_cols)
     constexpr int NT = BN / 32;
     constexpr int LDBT = BN + 1;                 // B written transposed: odd pitch
-    constexpr int NB = (TK / 4 * BN) / 256;      // float4 (along k) per thread per chunk
-    __shared__ __attribute__((aligned(16))) float sA[TK * LDT];
-    __shared__ __attribute__((aligned(16))) float sB[TK * LDBT];
+    constexpr int TKB = GSPN_BWD_TK;             // K chunk of THIS kernel: the chunk sequence (fetch, barrier, transform, barrier, MFMA) bounds it
+    constexpr int TPR = TKB / 4;                 // threads per row of a chunk (one float4 each)
+    constexpr int RPP = 256 / TPR;               // rows per pass
+    constexpr int NPASS = TM / RPP;
+    constexpr int NB = (TKB / 4 * BN) / 256;     // float4 (along k) per thread per chunk
+    __shared__ __attribute__((aligned(16))) float sA[TKB * LDT];
+    __shared__ __attribute__((aligned(16))) float sB[TKB * LDBT];
     extern __shared__ __attribute__((aligned(16))) float s_chan[];         // [5][cpad]: forward scale / shift, cA, cB, cC of the cout channels
     const int cpad = (cout + 3) / 4 * 4 + 4;
     float* sSc = s_chan;
@@ -2302,26 +2309,26 @@ void mlp_bwd_data_kernel(long rows, int cin, int cout, gspn_dy_args a, const flo
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int n0 = col0 + by * BN;
     const long ntiles = (rows + TM - 1) / TM;
-    const int nchunks = (cout + TK - 1) / TK;
+    const int nchunks = (cout + TKB - 1) / TKB;
     stage_chan(sSc, a.scale, cout, 1.f, cpad);
     stage_chan(sSh, a.shift, cout, 0.f, cpad);
     stage_chan(sCA, a.cA, cout, 0.f, cpad);         // channels >= cout contribute dY = 0
     stage_chan(sCB, a.cB, cout, 0.f, cpad);
     stage_chan(sCC, a.cC, cout, 0.f, cpad);
     __syncthreads();
-    const int kq = (t & 7) * 4;
-    const int arow = t >> 3;
-    float4 ry[4], rb[NB];
-    DzRaw rz[4];
+    const int kq = (t % TPR) * 4;
+    const int arow = t / TPR;
+    float4 ry[NPASS], rb[NB];
+    DzRaw rz[NPASS];
     long f_tile = 0;
     int f_c = 0;
     auto fetch = [&](long tile, int c) {              // raw, unconditional loads
         f_tile = tile; f_c = c;
         const long m0 = tile * TM;
-        const int k = c * TK + kq;
+        const int k = c * TKB + kq;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const long row = m0 + arow + 32 * i;
+        for (int i = 0; i < NPASS; ++i) {
+            const long row = m0 + arow + RPP * i;
             const long rc = row < rows ? row : rows - 1;
             ry[i] = load4_raw<VEC>(a.Y, rc, a.ldy, k, cout);
             rz[i] = dz4_raw<VEC, POOLED>(a, rc, k, cout);
@@ -2329,25 +2336,25 @@ void mlp_bwd_data_kernel(long rows, int cin, int cout, gspn_dy_args a, const flo
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int f = t + 256 * i;
-            const int j = f >> 3, kk4 = (f & 7) * 4;       // W row n0+j, columns c*TK + kk4 ..
+            const int j = f / TPR, kk4 = (f % TPR) * 4;    // W row n0+j, columns c*TKB + kk4 ..
             const int n = n0 + j;
-            rb[i] = load4_raw<VEC>(W, n < cin ? n : cin - 1, cout, c * TK + kk4, cout);
+            rb[i] = load4_raw<VEC>(W, n < cin ? n : cin - 1, cout, c * TKB + kk4, cout);
         }
     };
     auto commit = [&]() {
         const long m0 = f_tile * TM;
         const int c = f_c;
-        const int k = c * TK + kq;
+        const int k = c * TKB + kq;
         const float4 q_sc = lds4(sSc, k, cpad), q_sh = lds4(sSh, k, cpad), q_a = lds4(sCA, k, cpad), q_b = lds4(sCB, k, cpad), q_c = lds4(sCC, k, cpad);
         const float sc[4] = {q_sc.x, q_sc.y, q_sc.z, q_sc.w}, sh[4] = {q_sh.x, q_sh.y, q_sh.z, q_sh.w};
         const float cA[4] = {q_a.x, q_a.y, q_a.z, q_a.w}, cB[4] = {q_b.x, q_b.y, q_b.z, q_b.w}, cC[4] = {q_c.x, q_c.y, q_c.z, q_c.w};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const long row = m0 + arow + 32 * i;
+        for (int i = 0; i < NPASS; ++i) {
+            const long row = m0 + arow + RPP * i;
             const float4 dzv = dz4_resolve<POOLED>(a, rz[i], row < rows ? row : rows - 1);
             const float yv[4] = {ry[i].x, ry[i].y, ry[i].z, ry[i].w};
             const float zv[4] = {dzv.x, dzv.y, dzv.z, dzv.w};
-            float* d = sA + kq * LDT + arow + 32 * i;
+            float* d = sA + kq * LDT + arow + RPP * i;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float dyh = (yv[j] * sc[j] + sh[j]) > 0.f ? zv[j] : 0.f;
@@ -2357,8 +2364,8 @@ void mlp_bwd_data_kernel(long rows, int cin, int cout, gspn_dy_args a, const flo
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int f = t + 256 * i;
-            const int j = f >> 3, kk4 = (f & 7) * 4;
-            const float4 w = mask4(rb[i], c * TK + kk4, cout, (n0 + j) < cin);
+            const int j = f / TPR, kk4 = (f % TPR) * 4;
+            const float4 w = mask4(rb[i], c * TKB + kk4, cout, (n0 + j) < cin);
             float* d = sB + kk4 * LDBT + j;
             d[0 * LDBT] = w.x; d[1 * LDBT] = w.y; d[2 * LDBT] = w.z; d[3 * LDBT] = w.w;
         }
@@ -2393,7 +2400,7 @@ void mlp_bwd_data_kernel(long rows, int cin, int cout, gspn_dy_args a, const flo
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
             }
-            const int kmax = min(TK, (cout - c * TK + 1) & ~1);
+            const int kmax = min(TKB, (cout - c * TKB + 1) & ~1);
             for (int kk = 0; kk < kmax; kk += 2) {
                 const float av = sA[(kk + (lane >> 5)) * LDT + wave * 32 + (lane & 31)];
 #pragma unroll
