@@ -2266,7 +2266,7 @@ struct RsumArgs { const float* Yp; int ldyp; const float* scale; const float* sh
 #define GSPN_BWD_TK 32
 #endif
 #ifndef GSPN_BWD_WPE32
-#define GSPN_BWD_WPE32 3
+#define GSPN_BWD_WPE32 4         // measured on the bench step (pass B of SA1's two 32-column layers): 3 -> 4 waves per SIMD: 147 -> 130 us
 #endif
 #ifndef GSPN_BWD_WPE64
 #define GSPN_BWD_WPE64 3
