@@ -104,6 +104,7 @@ def main():
     gout = torch.from_numpy(np.random.default_rng(777).standard_normal((SCENES_PER_GPU, NPOINTS, 64)).astype(np.float32)).to(dev)
 
     gout_scaled = (gout * (1.0 / gout.numel())).contiguous()
+    one = torch.ones((), dtype=torch.float32, device=dev)
 
     class _DotLoss(torch.autograd.Function):
         """loss = sum(out * g) for a constant g; d loss / d out = g -- returned as is (the incoming gradient of a scalar loss is 1)."""
@@ -128,7 +129,7 @@ def main():
         xyz, col = batches[k]
         out = pn2_fea_extractor(xyz, col, 'fea', True, 0.5, geometry=g)
         loss = _DotLoss.apply(out, gout_scaled)       # <out, gout> / numel: one reduction kernel; its gradient IS gout_scaled (no kernel)
-        loss.backward()
+        loss.backward(gradient=one)                   # (a given gradient: autograd would otherwise fill a one-element tensor, a 5 us kernel)
         if state["bucket"] is None:
             params = store.parameters()
             state["bucket"] = parallel.FlatGradBucket(params)

@@ -66,6 +66,7 @@ SIGNATURES = {
     "gspn_nmdistance": [_I, _I, _P, _I, _P, _P, _P, _P, _P, _P],
     "gspn_nmdistance_grad": [_I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P],
     "gspn_sa_group_concat": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P],
+    "gspn_pad_rows": [_L, _I, _I, _P, _P, _P],
     "gspn_sa_group_concat_grad": [_I, _I, _I, _I, _I, _P, _I, _I, _P, _P, _P],
     "gspn_sa_group_concat_grad_csr": [_I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P, _P],
     "gspn_mlp_fwd": [_L, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P],

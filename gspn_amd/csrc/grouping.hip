@@ -275,6 +275,20 @@ __global__ void sa_group_concat_grad_kernel(long total, int n, int c, int m_ns, 
         atomicAdd(grad_points + ((size_t)bi * n + ii) * c + fc, g);
     }
 }
+// (rows, c) -> (rows, ld) with zero padding columns, one launch (the 16-byte feature rows the gathering first layer reads)
+__global__ void pad_rows_kernel(long total, int c, int ld, const float* __restrict__ src, float* __restrict__ dst) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / ld;
+        const int k = (int)(i - r * ld);
+        dst[i] = k < c ? src[r * c + k] : 0.f;
+    }
+}
+extern "C" int gspn_pad_rows(long rows, int c, int ld, const float* src, float* dst, void* stream) {
+    if (rows < 0 || c <= 0 || ld < c || !src || !dst) return GSPN_ERR_ARG;
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(pad_rows_kernel, dim3(grid_for(rows * ld, 256)), dim3(256), 0, (hipStream_t)stream, rows * ld, c, ld, src, dst);
+    return gspn_launch_status();
+}
 extern "C" int gspn_sa_group_concat(int b, int n, int c, int m, int nsample, const float* xyz, const float* new_xyz, const float* points,
                                     const int* idx, int xyz_first, int ld_out, float* out, void* stream) {
     if (b < 0 || n <= 0 || c < 0 || m < 0 || nsample < 0 || ld_out < 3 + c) return GSPN_ERR_ARG;

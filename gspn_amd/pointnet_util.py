@@ -132,13 +132,31 @@ FUSE_FP_FRONT = os.environ.get("GSPN_FUSE_FP_FRONT", "1") != "0"
 FUSE_SA_FRONT = os.environ.get("GSPN_FUSE_SA_FRONT", "1") != "0"
 
 
+class _PadCols(torch.autograd.Function):
+    """(rows, c) -> (rows, ld) with zero columns appended, in one launch; gradient = the first c columns"""
+
+    @staticmethod
+    def forward(ctx, x, ld):
+        rows, c = x.shape
+        out = torch.empty((rows, ld), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            L.check(L.lib().gspn_pad_rows(rows, c, ld, L.ptr(x), L.ptr(out), L.stream()), "pad_rows")
+        ctx.c = c
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[:, :ctx.c].contiguous(), None
+
+
 def _sa_stack_gathered(points, geometry, xyz_first, cin, layers, is_training, bn_decay, nsample):
     """the SA module's conv stack + max-pool with the first layer gathering its input rows (mlp_stack(gather=)); None when the shape is
     outside what the gathering kernels take (the caller then materialises the grouped rows as before)"""
     b, n, c = points.shape
     m, ns = geometry.idx.shape[1], geometry.idx.shape[2]
-    feat = points if c % 4 == 0 else torch.nn.functional.pad(points, (0, 4 - c % 4))     # 16-byte feature rows (the pad columns are ignored)
-    feat = feat.reshape(b * n, feat.shape[2])
+    feat = L.need(points, torch.float32, 3, "points").reshape(b * n, c)
+    if c % 4:
+        feat = _PadCols.apply(feat, (c + 3) // 4 * 4)                                      # 16-byte feature rows (the pad columns are ignored)
     if preagg_ok(layers, bool(is_training), c):
         # the first layer's feature part on the b*n points instead of the b*m*ns grouped rows (mlp.py: PREAGG)
         order, offsets, idx = geometry.order, geometry.offsets, geometry.idx

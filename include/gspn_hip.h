@@ -163,6 +163,9 @@ int gspn_nmdistance_grad(int b, int n, const float* xyz1, int m, const float* xy
 
 /* ---------------- utils/pointnet_util.py composition helpers --------------------------- */
 
+/* (rows, c) -> (rows, ld >= c), the extra columns zero: the 16-byte feature rows gspn_mlp_fwd_gather reads */
+int gspn_pad_rows(long rows, int c, int ld, const float* src, float* dst, void* stream);
+
 /* sample_and_group's tail in one pass (pointnet_util.py:41-52): out (b,m,ns,cx+c) where the cx=3
  * xyz channels are xyz[idx]-new_xyz (:41-42) and the c feature channels are points[idx] (:46);
  * xyz_first=1 gives concat([grouped_xyz, grouped_points]) (:48), 0 gives the features-first order
