@@ -121,3 +121,25 @@ def test_shard_range_and_bucket():
     bk = FlatGradBucket(ps)
     flat = bk.all_reduce_mean()                        # world 1: identity
     assert flat.numel() == 17 and float(flat[:12].sum()) == 66 and float(ps[1].grad.abs().sum()) == 0
+
+
+def test_preagg_host_side_rules():
+    """which first layers the pre-aggregated path takes (host logic only): cout = 4 * 2^k, training-mode BN on the first two layers,
+    enough feature columns; the forward's partial-row count is what the finalize call is told to sum"""
+    from gspn_amd import _lib, mlp
+    lib = _lib.lib()
+    assert [c for c in (4, 8, 12, 32, 48, 64, 96, 128, 256, 1024, 2048, 6, 0) if lib.gspn_preagg_ok(c)] == [4, 8, 32, 64, 128, 256, 1024]
+    for rows, cout in ((1, 64), (100, 64), (131072, 64), (262144, 64), (32768, 128), (10 ** 7, 32)):
+        p = int(lib.gspn_preagg_fwd_parts(rows, cout))
+        assert 1 <= p <= 2048 and (p < 64 or p % 8 == 0)
+    assert lib.gspn_preagg_fwd_parts(0, 64) < 0 and lib.gspn_preagg_fwd_parts(100, 48) < 0
+    assert lib.gspn_preagg_part_floats(64, 3) >= 1024 * 2 * 3 * 64
+
+    def layer(cout, bn=True):
+        return mlp.LayerParams(torch.zeros(67, cout), torch.zeros(cout), bn=bn)
+    assert mlp.preagg_ok([layer(64), layer(64)], True, 64)
+    assert not mlp.preagg_ok([layer(64), layer(64)], False, 64)            # inference: the coefficients of backward do not exist
+    assert not mlp.preagg_ok([layer(64)], True, 64)                        # the second layer's pass B hands the first its coefficients
+    assert not mlp.preagg_ok([layer(64, bn=False), layer(64)], True, 64)
+    assert not mlp.preagg_ok([layer(48), layer(64)], True, 64)
+    assert not mlp.preagg_ok([layer(64), layer(64)], True, 3)              # SA level 1: three colour channels, the gathered GEMM is as cheap

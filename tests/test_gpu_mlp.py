@@ -10,6 +10,10 @@ from oracle import mlp_ref as R
 pytestmark = pytest.mark.gpu
 
 
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
 def rel_err(a, b):
     a = a.double().cpu()
     b = b.double().cpu()
@@ -248,3 +252,77 @@ def test_early_coefficients_equal_the_two_product_pass(rows, cin, chans, ns, mon
     for a_, b_ in zip(res[0], res[1]):
         scale = float(b_.abs().max())
         assert float((a_ - b_).abs().max()) <= 2e-5 * max(scale, 1e-3)
+
+
+@pytest.mark.parametrize("T,rows,nsrc,cout,side_n,per_scene", [(1, 5000, 700, 64, 3, 0), (3, 4096, 300, 32, 4, 2), (3, 999, 128, 128, 0, 1), (1, 64, 9, 8, 1, 0)])
+def test_preagg_entry_points_against_numpy(T, rows, nsrc, cout, side_n, per_scene):
+    """gspn_preagg_fwd / gspn_bn_finalize_parts / gspn_preagg_bwd_dy called directly: Y = sum_t w_t F[idx_t] + side.Wside + b and its column
+    sums; dY = cA*relu'(.)*dz + cB*y + cC and dWside = side^T dY -- against float64 NumPy"""
+    import ctypes
+    from gspn_amd import _lib as L
+    lib = L.lib()
+    rng = np.random.default_rng(rows + cout)
+    if per_scene:       # scene-local indices: per_scene scenes of rows/per_scene output rows and nsrc source rows each
+        assert rows % per_scene == 0 or per_scene == 1
+        nscene = per_scene
+        rps = rows // nscene
+        rows = rps * nscene
+        idx = rng.integers(0, nsrc, size=(rows, T)).astype(np.int32)
+        gidx = idx + (np.arange(rows) // rps)[:, None] * nsrc
+        F = rng.standard_normal((nscene * nsrc, cout)).astype(np.float32)
+    else:
+        rps = 0
+        idx = rng.integers(0, nsrc, size=(rows, T)).astype(np.int32)
+        gidx = idx
+        F = rng.standard_normal((nsrc, cout)).astype(np.float32)
+    w = rng.random((rows, T)).astype(np.float32) if T == 3 else None
+    side_ld = max(side_n, 1) + (1 if side_n == 3 else 0)
+    side = rng.standard_normal((rows, side_ld)).astype(np.float32)
+    Ws = rng.standard_normal((max(side_n, 1), cout)).astype(np.float32)
+    bias = rng.standard_normal(cout).astype(np.float32)
+    ref = (F.astype(np.float64)[gidx] * (w.astype(np.float64)[..., None] if w is not None else 1.0)).sum(1)
+    ref = ref + side[:, :side_n].astype(np.float64) @ Ws[:side_n].astype(np.float64) + bias
+    dF, didx, dside, dWs, dbias = dev(F), dev(idx), dev(side), dev(Ws), dev(bias)
+    dw = dev(w) if w is not None else None
+    Y = torch.empty((rows, cout), device="cuda")
+    nparts = int(lib.gspn_preagg_fwd_parts(rows, cout))
+    stats = torch.full((nparts * 2 * cout,), float("nan"), device="cuda")
+    L.check(lib.gspn_preagg_fwd(rows, cout, T, L.ptr(dF), L.ptr(didx), L.ptr(dw), rps, nsrc if per_scene else 0, L.ptr(dside), side_ld, side_n,
+                                L.ptr(dWs), L.ptr(dbias), L.ptr(Y), L.ptr(stats), L.stream()), "preagg_fwd")
+    assert rel_err(Y, torch.from_numpy(ref)) < 2e-6
+    gamma = rng.random(cout).astype(np.float32) + 0.5
+    beta = rng.standard_normal(cout).astype(np.float32)
+    mm, mv = torch.zeros(cout, device="cuda"), torch.ones(cout, device="cuda")
+    mean, var, scale, shift = (torch.empty(cout, device="cuda") for _ in range(4))
+    L.check(lib.gspn_bn_finalize_parts(rows, cout, L.ptr(stats), nparts, L.ptr(dev(gamma)), L.ptr(dev(beta)), 1e-3, 0.9, 1, L.ptr(mm), L.ptr(mv),
+                                       L.ptr(mean), L.ptr(var), L.ptr(scale), L.ptr(shift), L.stream()), "bn_finalize_parts")
+    assert rel_err(mean, torch.from_numpy(ref.mean(0))) < 1e-5
+    assert rel_err(var, torch.from_numpy(ref.var(0))) < 1e-4
+    # backward half
+    dz = rng.standard_normal((rows, cout)).astype(np.float32)
+    cA, cB, cC = (rng.standard_normal(cout).astype(np.float32) for _ in range(3))
+    sc, sh = scale.cpu().numpy().astype(np.float64), shift.cpu().numpy().astype(np.float64)
+    y64 = Y.cpu().numpy().astype(np.float64)
+    dy_ref = cA * np.where(y64 * sc + sh > 0, dz, 0.0) + cB * y64 + cC
+    a = L.DyArgs()
+    ddz, dcA, dcB, dcC = dev(dz), dev(cA), dev(cB), dev(cC)
+    a.Y, a.ldy, a.dZ, a.ldz, a.dPool, a.pool_arg, a.ns = Y.data_ptr(), cout, ddz.data_ptr(), cout, None, None, 0
+    a.scale, a.shift, a.cA, a.cB, a.cC = scale.data_ptr(), shift.data_ptr(), dcA.data_ptr(), dcB.data_ptr(), dcC.data_ptr()
+    dY = torch.empty((rows, cout), device="cuda")
+    part = torch.empty(int(lib.gspn_preagg_part_floats(cout, max(side_n, 1))), device="cuda")
+    dWs_out = torch.full((max(side_n, 1), cout), float("nan"), device="cuda")
+    L.check(lib.gspn_preagg_bwd_dy(rows, cout, ctypes.byref(a), L.ptr(dside), side_ld, side_n, L.ptr(dY), L.ptr(part), L.ptr(dWs_out), L.stream()),
+            "preagg_bwd_dy")
+    fragile = np.abs(y64 * sc + sh) < 1e-5            # the ReLU mask of an element this close to the kink may flip between fp32 and fp64
+    got = dY.cpu().numpy().astype(np.float64)
+    assert np.abs(np.where(fragile, 0.0, got - dy_ref)).max() / np.abs(dy_ref).max() < 1e-5
+    if side_n:
+        assert rel_err(dWs_out[:side_n], torch.from_numpy(side[:, :side_n].astype(np.float64).T @ got)) < 1e-5
+
+
+def test_pad_rows():
+    from gspn_amd import _lib as L
+    x = torch.randn(1000, 3, device="cuda")
+    out = torch.full((1000, 4), 7.0, device="cuda")
+    L.check(L.lib().gspn_pad_rows(1000, 3, 4, L.ptr(x), L.ptr(out), L.stream()), "pad_rows")
+    assert torch.equal(out[:, :3], x) and (out[:, 3] == 0).all()
