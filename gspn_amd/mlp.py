@@ -400,14 +400,19 @@ def _preagg_backward(lib, pre, x, lp, a, rows, cout, need_dx, dev, st):
     dwf = dW[pre["wf0"]:pre["wf0"] + c]
     wf = lp.weights[pre["wf0"]:pre["wf0"] + c]
     work = torch.empty(int(lib.gspn_mlp_bwd_work_bytes(nsrc, c, cout)) // 4 + 4, dtype=torch.float32, device=dev)
-    L.check(lib.gspn_mlp_bwd_wgrad_known(nsrc, c, cout, ctypes.byref(a2), L.ptr(x), x.shape[1], None, None, None, L.ptr(work), L.ptr(dwf), st),
-            "mlp_bwd_wgrad_known(pre-aggregation)")
+    ride = need_dx and FUSE_DW               # the reduction of dW_feat's partial tiles rides in the d(feat) launch
+    L.check(lib.gspn_mlp_bwd_wgrad_known(nsrc, c, cout, ctypes.byref(a2), L.ptr(x), x.shape[1], None, None, None, L.ptr(work),
+                                         None if ride else L.ptr(dwf), st), "mlp_bwd_wgrad_known(pre-aggregation)")
     dx = None
     if need_dx:
         dx = torch.empty((nsrc, x.shape[1]), dtype=torch.float32, device=dev)
         if x.shape[1] > c:
             dx.zero_()
-        L.check(lib.gspn_mlp_bwd_data(nsrc, c, cout, ctypes.byref(a2), L.ptr(wf), L.ptr(dx), x.shape[1], st), "mlp_bwd_data(pre-aggregation)")
+        if ride:
+            L.check(lib.gspn_mlp_bwd_data_dw(nsrc, c, cout, ctypes.byref(a2), L.ptr(wf), 0, c, L.ptr(dx), x.shape[1], L.ptr(x), x.shape[1], None, None,
+                                             BN_EPS, 0, 0, L.ptr(work), L.ptr(dwf), st), "mlp_bwd_data_dw(pre-aggregation)")
+        else:
+            L.check(lib.gspn_mlp_bwd_data(nsrc, c, cout, ctypes.byref(a2), L.ptr(wf), L.ptr(dx), x.shape[1], st), "mlp_bwd_data(pre-aggregation)")
     return dW, dx
 
 
