@@ -55,7 +55,7 @@ SIGNATURES = {
     "gspn_groupmaxpool_grad": [_I, _I, _I, _I, _P, _P, _P, _P],
     "gspn_preagg_ok": [_I],
     "gspn_preagg_fwd": [_L, _I, _I, _P, _P, _P, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P],
-    "gspn_preagg_bwd_dy": [_L, _I, _c.POINTER(DyArgs), _P, _I, _I, _P, _P, _P, _P],
+    "gspn_preagg_bwd_dy": [_L, _I, _c.POINTER(DyArgs), _P, _I, _I, _P, _P, _P, _c.POINTER(_I), _P],
     "gspn_threenn": [_I, _I, _I, _P, _P, _P, _P, _P],
     "gspn_threenn_ordered": [_I, _I, _I, _P, _P, _P, _P, _P, _P],
     "gspn_threeinterpolate": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
@@ -89,6 +89,7 @@ SIGNATURES = {
     "gspn_mlp_bwd_dw": [_L, _I, _I, _c.POINTER(DyArgs), _P, _I, _P, _P, _F, _I, _I, _P, _P, _P],
     "gspn_mlp_bwd_data": [_L, _I, _I, _c.POINTER(DyArgs), _P, _P, _I, _P],
     "gspn_mlp_bwd_data_cols": [_L, _I, _I, _c.POINTER(DyArgs), _P, _I, _I, _P, _I, _P],
+    "gspn_mlp_bwd_data_dw2": [_L, _I, _I, _c.POINTER(DyArgs), _P, _I, _I, _P, _I, _P, _I, _P, _P, _F, _I, _I, _P, _P, _P, _I, _I, _P, _P],
     "gspn_mlp_bwd_data_dw": [_L, _I, _I, _c.POINTER(DyArgs), _P, _I, _I, _P, _I, _P, _I, _P, _P, _F, _I, _I, _P, _P, _P],
     "gspn_inverse_lists": [_I, _I, _I, _P, _P, _P, _P, _P],
     "gspn_multi_copy": [_I, _P, _P, _P, _P],

@@ -1658,6 +1658,10 @@ struct DwJob {
     int plain;                            // the partial tiles ARE dW's (pass A ran with known coefficients): dW = their sum
     int gq, gc_real, gxyz_first;          // gq > 0: rows of the partial tiles are in the gathered layer's internal order (GatherSrc)
     int rowgrid;                          // (set by the pass-B launcher that carries the job: its GEMM workgroups per column block)
+    // an optional second, plain job riding along (the side-column dW of a pre-aggregated layer): dW2 (cin2, cout) = sum of nslots2 tiles
+    const float* PP2;
+    float* dW2;
+    int cin2, nslots2, nblk2;
 };
 // One workgroup of NTH threads = DW_OX consecutive outputs x NTH/DW_OX interleaved slot slices; sh = 2 * (NTH/64) * DW_OX doubles.
 // the last step of the reduction, shared by both thread mappings: BN correction, scale, (gathered layers) row mapping, store
@@ -1756,6 +1760,7 @@ static DwJob dw_job(long rows, int cin, int cout, long nslots, const float* PP, 
     j.rows = rows; j.cin = cin; j.cout = cout; j.nslots = (int)nslots; j.nblk = (int)dw_blocks((long)cin * cout, nslots, 256);      // as a ride in pass B (256 threads)
     j.PP = PP; j.red = red; j.g3 = g3; j.var = var; j.gamma = gamma; j.eps = eps; j.use_bn = use_bn; j.is_training = is_training; j.dW = dW;
     j.gq = 0; j.gc_real = 0; j.gxyz_first = 0; j.plain = 0; j.rowgrid = 0;
+    j.PP2 = nullptr; j.dW2 = nullptr; j.cin2 = 0; j.nslots2 = 0; j.nblk2 = 0;
     return j;
 }
 
@@ -2215,11 +2220,12 @@ __global__ __launch_bounds__(256) void preagg_bwd_dy_kernel(long rows, int cout,
     }
 }
 extern "C" long gspn_preagg_part_floats(int cout, int side_n) { return (long)PREAGG_BWD_BLOCKS * 2 * side_n * cout + 4; }
-// dY (rows, cout) from (a.dZ, a.Y, a.scale/shift, a.cA/cB/cC); dWside (side_n, cout) = side^T . dY (deterministic two-level sum)
+// dY (rows, cout) from (a.dZ, a.Y, a.scale/shift, a.cA/cB/cC); dWside (side_n, cout) = side^T . dY (deterministic two-level sum).
+// dWside == NULL leaves the second level to the caller: *nslots_out partial tiles at part (gspn_mlp_bwd_data_dw2 can carry it).
 extern "C" int gspn_preagg_bwd_dy(long rows, int cout, const gspn_dy_args* a, const float* side, int side_ld, int side_n, float* dY, float* part,
-                                  float* dWside, void* stream) {
+                                  float* dWside, int* nslots_out, void* stream) {
     if (rows <= 0 || !a || !a->Y || !a->dZ || !a->scale || !a->shift || !a->cA || !a->cB || !a->cC || !dY || side_n < 0 || side_n > 4) return GSPN_ERR_ARG;
-    if (side_n > 0 && (!side || !part || !dWside || side_ld < side_n)) return GSPN_ERR_ARG;
+    if (side_n > 0 && (!side || !part || (!dWside && !nslots_out) || side_ld < side_n)) return GSPN_ERR_ARG;
     if (!preagg_shape_ok(cout) || rows >= (1L << 31) || (a->ldy & 3) || (a->ldz & 3)) return GSPN_ERR_UNSUPPORTED;
     if (((uintptr_t)a->Y % 16) || ((uintptr_t)a->dZ % 16) || ((uintptr_t)dY % 16)) return GSPN_ERR_ARG;
     const int rpi = 256 / (cout >> 2);
@@ -2227,7 +2233,8 @@ extern "C" int gspn_preagg_bwd_dy(long rows, int cout, const gspn_dy_args* a, co
     if (nb > PREAGG_BWD_BLOCKS) nb = PREAGG_BWD_BLOCKS;
     const size_t sh = sizeof(float) * 4 * 1024;
     hipLaunchKernelGGL(preagg_bwd_dy_kernel, dim3((unsigned)nb), dim3(256), sh, (hipStream_t)stream, rows, cout, *a, side, side_ld, side_n, dY, part);
-    if (side_n > 0) {
+    if (nslots_out) *nslots_out = (int)nb;
+    if (side_n > 0 && dWside) {
         DwJob j = dw_job(rows, side_n, cout, nb, part, nullptr, nullptr, nullptr, nullptr, 0.f, 0, 0, dWside);
         j.plain = 1;
         hipLaunchKernelGGL(wgrad_dw_kernel, dim3((unsigned)dw_blocks((long)side_n * cout, nb, 1024)), dim3(1024), 0, (hipStream_t)stream, j);
@@ -2297,11 +2304,16 @@ void mlp_bwd_data_kernel(long rows, int cin, int cout, gspn_dy_args a, const flo
         // one-dimensional grid: [dwj.nblk reduction workgroups][column block 0: dwj.rowgrid GEMM workgroups][column block 1: ...]
         // (a second grid dimension would launch the reduction workgroups once per column block, all but the first to exit at once:
         //  67 584 empty workgroups for the 384-column layer of the FP stack, 30 us of dispatch)
-        if (bx < (unsigned)dwj.nblk) {
-            wgrad_dw_block<256>(dwj, bx, reinterpret_cast<double*>(sA));
+        if (bx < (unsigned)(dwj.nblk + dwj.nblk2)) {
+            if (bx < (unsigned)dwj.nblk) wgrad_dw_block<256>(dwj, bx, reinterpret_cast<double*>(sA));
+            else {
+                DwJob j2 = dwj;
+                j2.PP = dwj.PP2; j2.dW = dwj.dW2; j2.cin = dwj.cin2; j2.nslots = dwj.nslots2; j2.plain = 1; j2.use_bn = 0; j2.gq = 0;
+                wgrad_dw_block<256>(j2, bx - (unsigned)dwj.nblk, reinterpret_cast<double*>(sA));
+            }
             return;
         }
-        bx -= (unsigned)dwj.nblk;
+        bx -= (unsigned)(dwj.nblk + dwj.nblk2);
         gx = (unsigned)dwj.rowgrid;
         by = bx / gx;
         bx -= by * gx;
@@ -2491,7 +2503,7 @@ static int bwd_data_launch(long rows, int cin, int cout, const gspn_dy_args* a, 
                    (pooled ? (((uintptr_t)a->dPool) % 16 == 0 && ((uintptr_t)a->pool_arg) % 16 == 0) : vec_ok(a->dZ, a->ldz));
     const int cend = col0 + ncols;
     const DwJob none = dw_job(0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0, 0, nullptr);
-    const unsigned extra = dwj ? (unsigned)dwj->nblk : 0u;
+    const unsigned extra = dwj ? (unsigned)(dwj->nblk + dwj->nblk2) : 0u;
     // workgroups per CU the grid is sized for.  3 reside (waves per SIMD: the amdgpu_waves_per_eu attribute of the kernel keeps the 32- and
     // 64-column tiles under 168 VGPRs; 2 for 128), yet 4 measures best (pass B of the bench step: 648 / 596 / 581 us at 2 / 3 / 4):
     // the fourth quarter of the workgroups fills the slots the first finishers free.  GSPN_BWD_BPC overrides (tuning hook).
@@ -2547,6 +2559,26 @@ extern "C" int gspn_mlp_bwd_data_dw(long rows, int cin, int cout, const gspn_dy_
     const char* wb = reinterpret_cast<const char*>(work);
     const DwJob j = dw_job(rows, cin, cout, p.nslots, reinterpret_cast<const float*>(wb + ws_off_pp(p.nch, cin, cout)), reinterpret_cast<const double*>(wb),
                            reinterpret_cast<const float*>(wb + ws_off_g3(cout)), var, gamma, eps, use_bn, is_training, dW);
+    return bwd_data_launch(rows, cin, cout, a, W, col0, ncols, dX, ldx, &j, (hipStream_t)stream);
+}
+// gspn_mlp_bwd_data_dw with a second, plain reduction riding along: dW2 (cin2, cout) = the sum of nslots2 partial tiles at part2
+// (layout [slot][2][cin2*cout], first half used -- what gspn_preagg_bwd_dy leaves when it is not asked to reduce them itself)
+extern "C" int gspn_mlp_bwd_data_dw2(long rows, int cin, int cout, const gspn_dy_args* a, const float* W, int col0, int ncols, float* dX, int ldx,
+                                     const float* X, int ldx_in, const float* var, const float* gamma, float eps, int use_bn, int is_training,
+                                     const float* work, float* dW, const float* part2, int cin2, int nslots2, float* dW2, void* stream) {
+    const int rc = bwd_data_check(rows, cin, cout, a, col0, ncols, ldx);
+    if (rc) return rc;
+    if (rows <= 0 || !work || !dW || ldx_in < cin || (use_bn && !var)) return GSPN_ERR_ARG;
+    if (cin2 < 0 || nslots2 < 0 || (cin2 > 0 && (!part2 || !dW2 || nslots2 <= 0))) return GSPN_ERR_ARG;
+    bool use_stream;
+    const WgradPlan p = wgrad_choose(rows, cin, cout, a, X, ldx_in, &use_stream);
+    const char* wb = reinterpret_cast<const char*>(work);
+    DwJob j = dw_job(rows, cin, cout, p.nslots, reinterpret_cast<const float*>(wb + ws_off_pp(p.nch, cin, cout)), reinterpret_cast<const double*>(wb),
+                     reinterpret_cast<const float*>(wb + ws_off_g3(cout)), var, gamma, eps, use_bn, is_training, dW);
+    if (cin2 > 0) {
+        j.PP2 = part2; j.dW2 = dW2; j.cin2 = cin2; j.nslots2 = nslots2;
+        j.nblk2 = (int)dw_blocks((long)cin2 * cout, nslots2, 256);
+    }
     return bwd_data_launch(rows, cin, cout, a, W, col0, ncols, dX, ldx, &j, (hipStream_t)stream);
 }
 // Pass B with both options: the fused dW reduction of gspn_mlp_bwd_data_dw (work != NULL) and the previous layer's BN reductions in the

@@ -387,8 +387,10 @@ def _preagg_backward(lib, pre, x, lp, a, rows, cout, need_dx, dev, st):
     dy = torch.empty((rows, cout), dtype=torch.float32, device=dev)
     part = torch.empty(int(lib.gspn_preagg_part_floats(cout, max(side_n, 1))), dtype=torch.float32, device=dev)
     dws = dW[pre["ws0"]:pre["ws0"] + side_n]
-    L.check(lib.gspn_preagg_bwd_dy(rows, cout, ctypes.byref(a), L.ptr(pre["side"]), pre["side_ld"], side_n, L.ptr(dy), L.ptr(part), L.ptr(dws), st),
-            "preagg_bwd_dy")
+    ride = need_dx and FUSE_DW               # the reductions of dW_side's and dW_feat's partial tiles ride in the d(feat) launch
+    nsl = ctypes.c_int(0)
+    L.check(lib.gspn_preagg_bwd_dy(rows, cout, ctypes.byref(a), L.ptr(pre["side"]), pre["side_ld"], side_n, L.ptr(dy), L.ptr(part),
+                                   None if (ride and side_n) else L.ptr(dws), ctypes.byref(nsl), st), "preagg_bwd_dy")
     nsrc = x.shape[0]
     gsrc = pre["scatter"](dy, cout)                                 # (source rows, cout): sum over the output rows each source row fed
     one, zero = _const_vectors(dev, cout)
@@ -400,7 +402,6 @@ def _preagg_backward(lib, pre, x, lp, a, rows, cout, need_dx, dev, st):
     dwf = dW[pre["wf0"]:pre["wf0"] + c]
     wf = lp.weights[pre["wf0"]:pre["wf0"] + c]
     work = torch.empty(int(lib.gspn_mlp_bwd_work_bytes(nsrc, c, cout)) // 4 + 4, dtype=torch.float32, device=dev)
-    ride = need_dx and FUSE_DW               # the reduction of dW_feat's partial tiles rides in the d(feat) launch
     L.check(lib.gspn_mlp_bwd_wgrad_known(nsrc, c, cout, ctypes.byref(a2), L.ptr(x), x.shape[1], None, None, None, L.ptr(work),
                                          None if ride else L.ptr(dwf), st), "mlp_bwd_wgrad_known(pre-aggregation)")
     dx = None
@@ -409,8 +410,9 @@ def _preagg_backward(lib, pre, x, lp, a, rows, cout, need_dx, dev, st):
         if x.shape[1] > c:
             dx.zero_()
         if ride:
-            L.check(lib.gspn_mlp_bwd_data_dw(nsrc, c, cout, ctypes.byref(a2), L.ptr(wf), 0, c, L.ptr(dx), x.shape[1], L.ptr(x), x.shape[1], None, None,
-                                             BN_EPS, 0, 0, L.ptr(work), L.ptr(dwf), st), "mlp_bwd_data_dw(pre-aggregation)")
+            L.check(lib.gspn_mlp_bwd_data_dw2(nsrc, c, cout, ctypes.byref(a2), L.ptr(wf), 0, c, L.ptr(dx), x.shape[1], L.ptr(x), x.shape[1], None, None,
+                                              BN_EPS, 0, 0, L.ptr(work), L.ptr(dwf), L.ptr(part), side_n, nsl.value if side_n else 0, L.ptr(dws), st),
+                    "mlp_bwd_data_dw2(pre-aggregation)")
         else:
             L.check(lib.gspn_mlp_bwd_data(nsrc, c, cout, ctypes.byref(a2), L.ptr(wf), L.ptr(dx), x.shape[1], st), "mlp_bwd_data(pre-aggregation)")
     return dW, dx

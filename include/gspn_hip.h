@@ -286,6 +286,11 @@ int gspn_mlp_bwd_data_cols(long rows, int cin, int cout, const gspn_dy_args* a, 
 int gspn_mlp_bwd_data_dw(long rows, int cin, int cout, const gspn_dy_args* a, const float* W, int col0, int ncols, float* dX, int ldx,
                          const float* X, int ldx_in, const float* var, const float* gamma, float eps, int use_bn, int is_training,
                          const float* work, float* dW, void* stream);
+/* the same with a second, plain reduction riding along: dW2 (cin2, cout) = the sum of nslots2 partial tiles at part2 ([slot][2][cin2*cout],
+ * first half) -- the side-column weight gradient gspn_preagg_bwd_dy leaves behind */
+int gspn_mlp_bwd_data_dw2(long rows, int cin, int cout, const gspn_dy_args* a, const float* W, int col0, int ncols, float* dX, int ldx,
+                          const float* X, int ldx_in, const float* var, const float* gamma, float eps, int use_bn, int is_training,
+                          const float* work, float* dW, const float* part2, int cin2, int nslots2, float* dW2, void* stream);
 
 /* ---- early coefficients: pass A as ONE GEMM ------------------------------------------------------------------------------------
  * Training-mode BN's backward needs r0 = sum(dyh) and r1 = sum(dyh*xhat) over all rows before dY exists; gspn_mlp_bwd_wgrad side-steps
@@ -327,7 +332,8 @@ int gspn_preagg_fwd(long rows, int cout, int T, const float* F, const int* idx, 
  * gspn_fp_concat_grad_csr on dY), dW_feat = feat^T . G, d(feat) = G . W_feat^T (gspn_mlp_bwd_wgrad / gspn_mlp_bwd_data, no BN). */
 long gspn_preagg_part_floats(int cout, int side_n);
 int gspn_preagg_bwd_dy(long rows, int cout, const gspn_dy_args* a, const float* side, int side_ld, int side_n, float* dY, float* part,
-                       float* dWside, void* stream);
+                       float* dWside, int* nslots_out, void* stream);
+/* (dWside == NULL: the partial tiles stay at part, *nslots_out of them, for gspn_mlp_bwd_data_dw2 to sum in a launch that exists anyway) */
 
 /* ---- fused set-abstraction front end: sample_and_group's concat (pointnet_util.py:36-52) + the first conv2d (:109-113)
  * without the grouped (b, npoint, nsample, 3+c) tensor.  gspn_sa_rel writes, per grouped row r = ((i*m + j)*ns + k), its centred

@@ -311,8 +311,10 @@ def test_preagg_entry_points_against_numpy(T, rows, nsrc, cout, side_n, per_scen
     dY = torch.empty((rows, cout), device="cuda")
     part = torch.empty(int(lib.gspn_preagg_part_floats(cout, max(side_n, 1))), device="cuda")
     dWs_out = torch.full((max(side_n, 1), cout), float("nan"), device="cuda")
-    L.check(lib.gspn_preagg_bwd_dy(rows, cout, ctypes.byref(a), L.ptr(dside), side_ld, side_n, L.ptr(dY), L.ptr(part), L.ptr(dWs_out), L.stream()),
-            "preagg_bwd_dy")
+    nsl = ctypes.c_int(0)
+    L.check(lib.gspn_preagg_bwd_dy(rows, cout, ctypes.byref(a), L.ptr(dside), side_ld, side_n, L.ptr(dY), L.ptr(part), L.ptr(dWs_out), ctypes.byref(nsl),
+                                   L.stream()), "preagg_bwd_dy")
+    assert 1 <= nsl.value <= 1024
     fragile = np.abs(y64 * sc + sh) < 1e-5            # the ReLU mask of an element this close to the kink may flip between fp32 and fp64
     got = dY.cpu().numpy().astype(np.float64)
     assert np.abs(np.where(fragile, 0.0, got - dy_ref)).max() / np.abs(dy_ref).max() < 1e-5
