@@ -93,8 +93,9 @@ def main():
     # workgroups -- so the same work packed into half the time costs the layers less (measured: +0.31 -> +0.21 ms per step for FPS
     # of SA level 1 alone).  Needs 4 batch slots instead of 3; every step still gets exactly one geometry pass of its own batch.
     PAIRED = os.environ.get('GSPN_BENCH_PAIRED', '1') != '0'
-    NB = int(os.environ.get('GSPN_BENCH_NB', '4' if PAIRED else '3'))
-    DEPTH = int(os.environ.get('GSPN_BENCH_DEPTH', '2'))                   # geometry runs this many steps ahead, on DEPTH side streams (FPS throughput: one CU per scene per stream)
+    GROUP = int(os.environ.get('GSPN_BENCH_GROUP', '2')) if PAIRED else 1   # steps whose geometry is submitted together (diagnostic: 4 = four FPS launches side by side every fourth step)
+    NB = int(os.environ.get('GSPN_BENCH_NB', str(2 * GROUP) if PAIRED else '3'))
+    DEPTH = int(os.environ.get('GSPN_BENCH_DEPTH', str(GROUP) if PAIRED else '2'))     # geometry runs this many steps ahead, on DEPTH side streams (FPS throughput: one CU per scene per stream)
     batches = []
     for k in range(NB):
         xyz_np, col_np = synth(SCENES_PER_GPU, NPOINTS, seed0=(k * 1000 + rank) * SCENES_PER_GPU)
@@ -229,8 +230,8 @@ def main():
             return
         geo[i % DEPTH].submit(part, xyz)
 
-    if PAIRED and DEPTH != 2:
-        raise SystemExit("GSPN_BENCH_PAIRED needs GSPN_BENCH_DEPTH=2")
+    if PAIRED and (DEPTH != GROUP or NB != 2 * GROUP):
+        raise SystemExit("GSPN_BENCH_PAIRED needs GSPN_BENCH_DEPTH = GSPN_BENCH_GROUP and 2 x GROUP batch slots")
     if geo is not None and not LAYERS_ONLY:
         for j in range(DEPTH):
             submit_geometry(j)
@@ -261,15 +262,17 @@ def main():
             # queued behind it, so the GPU never idles) instead of making the side stream wait on the layers' stream.
             done[i] = torch.cuda.current_stream().record_event()
             if PAIRED:
-                # even steps submit the geometry of steps i+2 and i+3 at once (slots (i+2)%4 and (i-1)%4, last read by steps i-2 and i-1)
-                if i % 2 == 0:
+                # every GROUP-th step submits the geometry of steps i+GROUP .. i+2*GROUP-1 at once (their slots were last read by steps
+                # i-GROUP .. i-1: the host waits for step i-1)
+                if i % GROUP == 0:
                     if (i - 1) in done:
                         tw = time.perf_counter()
                         done.pop(i - 1).synchronize()
                         state["t_wait"] += time.perf_counter() - tw
-                    done.pop(i - 2, None)
-                    submit_geometry(i + 2)
-                    submit_geometry(i + 3)
+                    for r in range(2, GROUP + 1):
+                        done.pop(i - r, None)
+                    for r in range(GROUP):
+                        submit_geometry(i + GROUP + r)
             else:
                 if (i - 1) in done:
                     tw = time.perf_counter()
