@@ -187,6 +187,7 @@ __global__ void pool_select_kernel(long total, int c, PoolOut po, const float* _
             const float* p = Y + g * 32 * ldy + col;
             y = p[0]; a = 0;
             for (int k = 1; k < 32; ++k) { const float t = p[(size_t)k * ldy]; if (t < y) { y = t; a = k; } }
+            po.vmax[i] = y;                                          // vmax leaves as "y at the arg row" for every channel (gspn_pool_rsum)
         }
         float z = y * sc + sh;                                       // two roundings, as every other BN application here
         z = z > 0.f ? z : 0.f;
@@ -195,12 +196,12 @@ __global__ void pool_select_kernel(long total, int c, PoolOut po, const float* _
     }
 }
 // finishes a pool the forward launch started (gspn_mlp_fwd_pool32): out (groups, c), arg (groups, c) row offset of the maximum
-extern "C" int gspn_pool32_select(long groups, int c, const float* vmax, const int* amax, const float* Y, int ldy,
+extern "C" int gspn_pool32_select(long groups, int c, float* vmax, const int* amax, const float* Y, int ldy,
                                   const float* scale, const float* shift, float* out, int* arg, void* stream) {
     if (groups < 0 || c <= 0 || !scale || !shift || !out || !Y || ldy < c) return GSPN_ERR_ARG;
     const long total = groups * c;
     if (total == 0) return 0;
-    PoolOut po{const_cast<float*>(vmax), const_cast<int*>(amax)};
+    PoolOut po{vmax, const_cast<int*>(amax)};
     hipLaunchKernelGGL(pool_select_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, total, c, po, Y, ldy, scale, shift, out, arg);
     return gspn_launch_status();
 }
@@ -1920,7 +1921,7 @@ __global__ __launch_bounds__(256) void pool_rsum_kernel(long groups, int ns, int
         float r0 = 0.f, r1 = 0.f;
         for (long g = g0 + sub; g < g1; g += nsub) {
             const float dp = dPool[g * c + col];
-            const float yv = Y[(g * ns + arg[g * c + col]) * ldy + col];
+            const float yv = ldy ? Y[(g * ns + arg[g * c + col]) * ldy + col] : Y[g * c + col];     // ldy == 0: Y is (groups, c), y at the arg row
             const float dyh = __builtin_fmaf(yv, sc, sh) > 0.f ? dp : 0.f;
             r0 += dyh;
             r1 = __builtin_fmaf(dyh, __builtin_fmaf(yv, rs, mr), r1);

@@ -192,6 +192,7 @@ class _MlpStack(torch.autograd.Function):
         # (autograd's own check only covers save_for_backward tensors; these are kept as attributes so the layer list stays one object)
         ctx.versions = [(lp.weights._version, lp.gamma._version if lp.bn else 0) for lp in layers]
         ctx.arg = arg
+        ctx.pool_yarg = pool[0] if pool is not None else None
         ctx.spec = spec
         ctx.rows = rows
         ctx.x_needs_grad = x.requires_grad
@@ -237,7 +238,9 @@ class _MlpStack(torch.autograd.Function):
                 if tr_all and lp.bn and dz is None and li not in coef:
                     part = torch.empty(int(lib.gspn_rsum_part_floats(rows, cout)), dtype=torch.float32, device=dev)
                     npart = ctypes.c_int(0)
-                    L.check(lib.gspn_pool_rsum(rows // pool_ns, pool_ns, cout, L.ptr(d_out), L.ptr(ctx.arg), L.ptr(y), cout, L.ptr(scale), L.ptr(shift),
+                    yarg = ctx.pool_yarg           # y at the arg row, left by gspn_pool32_select (None: gather it from Y)
+                    L.check(lib.gspn_pool_rsum(rows // pool_ns, pool_ns, cout, L.ptr(d_out), L.ptr(ctx.arg), L.ptr(y if yarg is None else yarg),
+                                               cout if yarg is None else 0, L.ptr(scale), L.ptr(shift),
                                                L.ptr(mean), L.ptr(var), BN_EPS, L.ptr(part), ctypes.byref(npart), st), "pool_rsum")
                     coef[li] = _coef_from_parts(lib, rows, cout, npart.value, part, mean, var, lp, dev, st)
                 known = coef.get(li)

@@ -205,10 +205,11 @@ int gspn_mlp_fwd(long rows, int cin, int cout, const float* X, int ldx, const fl
  * and channel the largest raw output and its row offset, taken from the accumulators (vmax, amax: each (rows/32, cout)).  BN+ReLU is
  * increasing in y for scale >= 0, so gspn_pool32_select finishes the pool from these once scale/shift exist:
  * out = relu(scale*vmax + shift), arg = amax -- the (rows, cout) tensor is not read again, except for channels with a negative scale
- * (their group minimum is taken from Y by the select kernel). */
+ * (their group minimum is taken from Y by the select kernel, which also stores it back: on return vmax holds y at the arg row for every
+ * channel -- what gspn_pool_rsum needs in backward, so that pass need not gather from Y either). */
 int gspn_mlp_fwd_pool32(long rows, int cin, int cout, const float* X, int ldx, const float* in_scale, const float* in_shift,
                         const float* W, const float* bias, float* Y, int ldy, float* stats, float* vmax, int* amax, void* stream);
-int gspn_pool32_select(long groups, int c, const float* vmax, const int* amax, const float* Y, int ldy,
+int gspn_pool32_select(long groups, int c, float* vmax, const int* amax, const float* Y, int ldy,
                        const float* scale, const float* shift, float* out, int* arg, void* stream);
 /* bytes of the `stats` workspace for a (rows, cout) layer */
 long gspn_mlp_fwd_stats_bytes(long rows, int cout);
@@ -297,7 +298,8 @@ int gspn_mlp_bwd_data_dw2(long rows, int cin, int cout, const gspn_dy_args* a, c
  * that with a second product (Gx) inside the GEMM -- twice the matrix work.  When the two sums are taken BEFORE pass A, the coefficients
  * cA/cB/cC are final and gspn_mlp_bwd_wgrad_known runs one GEMM dW = act(X)^T . dY (g: optional gspn_gather_args of a fused first layer,
  * defined below; dW may be NULL, the sum over partial tiles then rides in gspn_mlp_bwd_data_ex / _dw called with use_bn = 0):
- *   - top layer of a pooled stack: gspn_pool_rsum takes the sums from (dPool, pool_arg, Y) -- (groups x c) work;
+ *   - top layer of a pooled stack: gspn_pool_rsum takes the sums from (dPool, pool_arg, Y) -- (groups x c) work; ldy == 0 says Y is
+ *     already the (groups, c) tensor of y at the arg row (vmax after gspn_pool32_select): no gather from the (rows, c) output;
  *   - any other layer l: its dz is the dX of layer l+1's pass B, whose epilogue takes them (gspn_mlp_bwd_data_ex, Yp = Y of layer l);
  *   - gspn_mlp_bwd_coef(rows, c, nparts, part, ...) sums the partial rows [nparts][2][c] in double and writes cA, cB, cC, dgamma, dbeta,
  *     dbias (the same formulas as gspn_mlp_bwd_wgrad's).  part: gspn_rsum_part_floats(rows, c) floats. */
