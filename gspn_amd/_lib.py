@@ -85,6 +85,8 @@ SIGNATURES = {
     "gspn_bn_finalize_parts": [_L, _I, _P, _I, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P],
     "gspn_bnrelu_maxpool": [_L, _I, _I, _P, _I, _P, _P, _P, _P, _P],
     "gspn_bnrelu_apply": [_L, _I, _P, _I, _P, _P, _P, _I, _P],
+    "gspn_mlp_bwd_data_pooltop": [_L, _I, _I, _c.POINTER(DyArgs), _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _F, _I, _I, _P, _P,
+                                  _P, _I, _P, _P, _P, _P, _F, _P, _c.POINTER(_I), _P],
     "gspn_mlp_bwd_wgrad": [_L, _I, _I, _c.POINTER(DyArgs), _P, _I, _P, _P, _P, _P, _P, _F, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "gspn_mlp_bwd_dw": [_L, _I, _I, _c.POINTER(DyArgs), _P, _I, _P, _P, _F, _I, _I, _P, _P, _P],
     "gspn_mlp_bwd_data": [_L, _I, _I, _c.POINTER(DyArgs), _P, _P, _I, _P],
@@ -108,6 +110,7 @@ SPECIAL = {
     "gspn_rsum_part_floats": ([_L, _I], _L),
     "gspn_preagg_part_floats": ([_I, _I], _L),
     "gspn_preagg_fwd_parts": ([_L, _I], _L),
+    "gspn_pooltop_scratch_floats": ([_L, _I, _I], _L),
     "gspn_inverse_lists_work_ints": ([_I, _I, _I], _L),
 }
 

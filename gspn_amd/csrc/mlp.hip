@@ -408,12 +408,29 @@ __device__ __forceinline__ int gather_w_row(const GatherSrc& g, int k) {        
     const int a = k - 4 * g.cq;
     return a < 3 ? (g.xyz_first ? a : g.c_real + a) : -1;
 }
-template <int BN, int TRG, bool GATHER>
+// BWDP: the same streaming structure as pass B of a POOLED TOP layer (pool groups of 32 rows = one wave's row group).  With
+// dY = cA*dyh + cB*y + cC and y = xhat.W + b,
+//     dX = dY.W^T = xhat.(W diag(cB) W^T) + S.W^T + 1.((b*cB + cC).W^T),      S = cA*dyh: ONE non-zero per (pool group, channel),
+// so the layer's own (rows, ctop) output is not needed: X is the previous layer's pre-BN output (xhat = relu(bn(X)), exactly the forward's
+// operand), `W` the (cin, cin) matrix W diag(cB) W^T, `bias` the constant row, `Y` dX -- and after the dense k loop a second one runs over
+// the ctop channels with the A operand built from the group's (arg, V) pairs (V = cA * dPool * [pooled output > 0], gspn_pooltop_prep) and
+// the B operand W^T from LDS.  The epilogue takes the previous layer's BN reductions sum(dyh), sum(dyh*xhat_n) where the forward takes the
+// column statistics (same partial layout), reading the raw X tile that is still in LDS.  134 MB of Y (SA level 1) are not read.
+struct BwdPool {
+    const int* arg;       // (groups, ctop) row offset of each group's arg-max
+    const float* V;       // (groups, ctop)
+    const float* Wtop;    // (cin, ctop) the layer's weights
+    int ctop;
+    const float* mean;    // batch statistics of the previous layer (whose pre-BN output X is)
+    const float* var;
+    float eps;
+};
+template <int BN, int TRG, bool GATHER, bool BWDP = false>
 __global__ __launch_bounds__(256) void mlp_fwd_stream_kernel(int rows, int cin, int cout, const float* __restrict__ X, int ldx,
                                                              const float* __restrict__ in_scale, const float* __restrict__ in_shift,
                                                              const float* __restrict__ W, const float* __restrict__ bias,
                                                              float* __restrict__ Y, int ldy, float* __restrict__ stats, int nparts, PoolOut po,
-                                                             GatherSrc gs) {
+                                                             GatherSrc gs, BwdPool bp) {
     constexpr int NT = BN / 32, CG = 4 / TRG, NTW = NT / CG, TR = 32 * TRG;
     static_assert(NT % CG == 0 && NTW >= 1, "column groups tile the block");
     constexpr int JPMAX = 8;                              // 1-KiB pieces per wave per row tile (TR * QX / 64 / 4 <= 8 by the launcher's LDS check)
@@ -422,6 +439,10 @@ __global__ __launch_bounds__(256) void mlp_fwd_stream_kernel(int rows, int cin, 
     float* sSS = smem;                                    // [KP][2]  (scale, shift) of the input channels
     float* sW = sSS + KP * 2;                             // [QX][2][BN][2]  W[4j+2kh+e][n]
     float* sXb = sW + KP * BN;                            // 2 x [TR][QX quads], quads swizzled
+    // BWDP: W^T of the layer in the layout of sW (k = channel of the top layer), then 2 x TRG groups of (arg, V) pairs
+    const int CT4 = BWDP ? (bp.ctop + 3) / 4 * 4 : 0;
+    float* sWt = sXb + 2 * TR * KP;
+    int2* sPV = reinterpret_cast<int2*>(sWt + CT4 * BN);  // [2][TRG][CT4]
     __shared__ float sRed[2 * TRG * BN];
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int l31 = lane & 31, kh = lane >> 5;
@@ -438,6 +459,14 @@ __global__ __launch_bounds__(256) void mlp_fwd_stream_kernel(int rows, int cin, 
         const float w = (kw >= 0 && n0 + n < cout) ? W[(size_t)kw * cout + n0 + n] : 0.f;
         const int j = k >> 2, h = (k >> 1) & 1, e = k & 1;
         sW[(((j * 2 + h) * BN) + n) * 2 + e] = w;
+    }
+    if constexpr (BWDP) {
+        for (int f = t; f < CT4 * BN; f += 256) {
+            const int k = f / BN, n = f - k * BN;
+            const float w = (k < bp.ctop && n0 + n < cout) ? bp.Wtop[(size_t)(n0 + n) * bp.ctop + k] : 0.f;
+            const int j = k >> 2, h = (k >> 1) & 1, e = k & 1;
+            sWt[(((j * 2 + h) * BN) + n) * 2 + e] = w;
+        }
     }
     const int ntiles = (rows + TR - 1) / TR;
     const int npiece = TR * QX / 64;                       // whole pieces: TR is a multiple of 64 or QX is even (launcher)
@@ -474,12 +503,38 @@ __global__ __launch_bounds__(256) void mlp_fwd_stream_kernel(int rows, int cin, 
                 }
             }
     };
-    float bv[NTW], csum[NTW], csq[NTW];
+    // BWDP: the (arg, V) pairs of a tile's TRG pool groups, fetched a tile ahead into registers (<= 2 per thread: TRG * ctop <= 512, launcher)
+    // and handed to LDS right after the vmcnt(0) that opens the tile's iteration -- like g_nxt, never a wait of their own
+    int pv_a[BWDP ? 2 : 1];
+    float pv_v[BWDP ? 2 : 1];
+    auto pfetch = [&](int tile) {
+        if constexpr (BWDP) {
+            const long ngroups = rows >> 5;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int e = t + 256 * i;
+                const int gl = e / CT4, c = e - gl * CT4;
+                pv_a[i] = -1; pv_v[i] = 0.f;
+                if (gl < TRG && c < bp.ctop) {
+                    const long g = min((long)tile * TRG + gl, ngroups - 1);
+                    pv_a[i] = bp.arg[g * bp.ctop + c];
+                    pv_v[i] = bp.V[g * bp.ctop + c];
+                }
+            }
+        }
+    };
+    float bv[NTW], csum[NTW], csq[NTW], p_rs[NTW], p_mr[NTW];
 #pragma unroll
     for (int y = 0; y < NTW; ++y) {
         const int col = n0 + (cg * NTW + y) * 32 + l31;
         bv[y] = (bias && col < cout) ? bias[col] : 0.f;
         csum[y] = csq[y] = 0.f;
+        p_rs[y] = p_mr[y] = 0.f;
+        if constexpr (BWDP) {
+            const int cc = min(col, cout - 1);
+            p_rs[y] = (float)(1.0 / sqrt((double)bp.var[cc] + (double)bp.eps));
+            p_mr[y] = -bp.mean[cc] * p_rs[y];
+        }
     }
     const int arow = rg * 32 + l31;                         // this lane's row inside the tile (A operand)
     const int akey = fwd_swz_key(arow, QX);
@@ -516,6 +571,33 @@ __global__ __launch_bounds__(256) void mlp_fwd_stream_kernel(int rows, int cin, 
             }
         }
     };
+    // BWDP: dX = acc + constant row, stored; the previous layer's reductions from the finished tile and the raw X tile (still in LDS: called
+    // right after the tile's MFMAs, not a tile later like the forward's)
+    auto epilogue_b = [&](int tile, const f32x16 (&acc)[NTW], int buf) {
+        const int m0 = tile * TR + rg * 32;
+        const bool full = tile * TR + TR <= rows;
+        const float* xt = sXb + buf * (TR * KP);
+#pragma unroll
+        for (int y = 0; y < NTW; ++y) {
+            const int col = n0 + (cg * NTW + y) * 32 + l31;
+            if (col < cout) {
+                const float sc = sSS[2 * col], sh = sSS[2 * col + 1];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rl = rg * 32 + c_row(r, lane);
+                    const int row = tile * TR + rl;
+                    const float v = acc[y][r] + bv[y];
+                    const float xr = xt[rl * KP + ((((col >> 2) ^ fwd_swz_key(rl, QX)) << 2) | (col & 3))];
+                    const bool live = full || row < rows;
+                    if (live) Y[(size_t)row * ldy + col] = v;
+                    const float dyh = (live && xr * sc + sh > 0.f) ? v : 0.f;
+                    csum[y] += dyh;
+                    csq[y] = __builtin_fmaf(dyh, __builtin_fmaf(xr, p_rs[y], p_mr[y]), csq[y]);
+                }
+            }
+        }
+        (void)m0;
+    };
     f32x16 acc[NTW], pacc[NTW];
     int it = 0, ptile = -1;
     // tiles of this workgroup: strided over the grid, or (GATHER) a contiguous run placed so that the workgroups of one XCD (block % 8)
@@ -532,13 +614,22 @@ __global__ __launch_bounds__(256) void mlp_fwd_stream_kernel(int rows, int cin, 
         gfetch(tile0);
         issue(tile0, 0);
         if (tile0 + tstep < tend) gfetch(tile0 + tstep);
+        pfetch(tile0);
     }
     for (int tile = tile0; tile < tend; tile += tstep, ++it) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (BWDP) {                               // this tile's (arg, V) pairs: registers -> LDS half `it & 1` (last read two tiles ago)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int e = t + 256 * i;
+                if (e < TRG * CT4) sPV[(it & 1) * (TRG * CT4) + e] = make_int2(pv_a[i], __float_as_int(pv_v[i]));
+            }
+        }
         __syncthreads();                                    // tile `it` has landed (and W / constants are visible the first time)
         if (tile + tstep < tend) {
             issue(tile + tstep, (it + 1) & 1);
             if (tile + 2 * tstep < tend) gfetch(tile + 2 * tstep);
+            pfetch(tile + tstep);
         }
         // the previous tile's stores go out here, a whole compute phase before the next vmcnt(0): their latency is never waited on
         if (ptile >= 0) epilogue(ptile, pacc);
@@ -564,9 +655,32 @@ __global__ __launch_bounds__(256) void mlp_fwd_stream_kernel(int rows, int cin, 
         int j = 0;
         for (; j + 3 < QX; j += 4) { kstep(j); kstep(j + 1); kstep(j + 2); kstep(j + 3); }   // (hipcc will not partially unroll a loop of MFMAs itself)
         for (; j < QX; ++j) kstep(j);
+        if constexpr (BWDP) {
+            // the sparse term: k runs over the top layer's channels; lane (row i, k half) takes S[i][k] = (arg[k] == i) ? V[k] : 0
+            const int2* pv = sPV + (it & 1) * (TRG * CT4) + rg * CT4;
+            auto sstep = [&](int q) {
+                const int4 e2 = *reinterpret_cast<const int4*>(pv + 4 * q + 2 * kh);
+                float2 b2[NTW];
 #pragma unroll
-        for (int y = 0; y < NTW; ++y) pacc[y] = acc[y];
-        ptile = tile;
+                for (int y = 0; y < NTW; ++y)
+                    b2[y] = *reinterpret_cast<const float2*>(sWt + (((q * 2 + kh) * BN) + (cg * NTW + y) * 32 + l31) * 2);
+                const float a0 = e2.x == l31 ? __int_as_float(e2.y) : 0.f;
+                const float a1 = e2.z == l31 ? __int_as_float(e2.w) : 0.f;
+#pragma unroll
+                for (int y = 0; y < NTW; ++y) acc[y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b2[y].x, acc[y], 0, 0, 0);
+#pragma unroll
+                for (int y = 0; y < NTW; ++y) acc[y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b2[y].y, acc[y], 0, 0, 0);
+            };
+            const int QS = CT4 >> 2;
+            int q = 0;
+            for (; q + 3 < QS; q += 4) { sstep(q); sstep(q + 1); sstep(q + 2); sstep(q + 3); }
+            for (; q < QS; ++q) sstep(q);
+            epilogue_b(tile, acc, it & 1);
+        } else {
+#pragma unroll
+            for (int y = 0; y < NTW; ++y) pacc[y] = acc[y];
+            ptile = tile;
+        }
     }
     if (ptile >= 0) epilogue(ptile, pacc);
     if (stats) {
@@ -681,7 +795,7 @@ static int mlp_fwd_impl(long rows, int cin, int cout, const float* X, int ldx, c
                     attr_done = true;                                                                                                  \
                 }                                                                                                                      \
                 hipLaunchKernelGGL((mlp_fwd_stream_kernel<BN_, TRG_, G_>), dim3((unsigned)gx, yt), dim3(256), dyn, st, (int)rows, cin, cout, X, ldx, \
-                                   in_scale, in_shift, W, bias, Y, ldy, stats, (int)nparts, po, GS_);                                  \
+                                   in_scale, in_shift, W, bias, Y, ldy, stats, (int)nparts, po, GS_, BwdPool{});                                  \
                 return gspn_launch_status();                                                                                           \
             } while (0)
 #define FWDS_GO(BN_, TRG_)                                                                                                             \
@@ -2581,6 +2695,120 @@ extern "C" int gspn_mlp_bwd_data_dw2(long rows, int cin, int cout, const gspn_dy
         j.nblk2 = (int)dw_blocks((long)cin2 * cout, nslots2, 256);
     }
     return bwd_data_launch(rows, cin, cout, a, W, col0, ncols, dX, ldx, &j, (hipStream_t)stream);
+}
+// ---- pass B of a pooled top layer as a streaming GEMM on the layer's input (mlp_fwd_stream_kernel<.., BWDP>) ----
+// the small operands: workgroups [0, cin): row n of M = W diag(cB) W^T and cvec[n] = sum_c (b[c]*cB[c] + cC[c]) * W[n][c]; then the
+// dW reduction of the layer (dwj.nblk workgroups, its usual ride); the rest: V = cA * dPool * [pooled output > 0] over (groups, ctop)
+__global__ __launch_bounds__(256) void pooltop_prep_kernel(long groups, int cin, int ctop, const float* __restrict__ W, const float* __restrict__ bias,
+                                                           const float* __restrict__ cA, const float* __restrict__ cB, const float* __restrict__ cC,
+                                                           const float* __restrict__ dPool, const float* __restrict__ pooled, float* __restrict__ M,
+                                                           float* __restrict__ cvec, float* __restrict__ V, DwJob dwj) {
+    __shared__ __attribute__((aligned(16))) double prep_sh[2 * 16 * DW_OX + MAXCH / 2 + 8];
+    const int t = threadIdx.x;
+    int b = blockIdx.x;
+    if (b < cin) {
+        float* wrow = reinterpret_cast<float*>(prep_sh + 8);       // W[n][:] * cB[:]
+        const float* wn = W + (size_t)b * ctop;
+        double cv = 0.0;
+        for (int c = t; c < ctop; c += 256) {
+            wrow[c] = wn[c] * cB[c];
+            cv += ((double)(bias ? bias[c] : 0.f) * (double)cB[c] + (double)cC[c]) * (double)wn[c];
+        }
+        cv = wave_sum_f64(cv);
+        if ((t & 63) == 0) prep_sh[t >> 6] = cv;
+        __syncthreads();
+        if (t == 0) cvec[b] = (float)((prep_sh[0] + prep_sh[1]) + (prep_sh[2] + prep_sh[3]));
+        for (int m = t; m < cin; m += 256) {
+            const float* wm = W + (size_t)m * ctop;
+            double acc = 0.0;
+            for (int c = 0; c < ctop; ++c) acc += (double)wrow[c] * (double)wm[c];
+            M[(size_t)b * cin + m] = (float)acc;
+        }
+        return;
+    }
+    b -= cin;
+    if (b < dwj.nblk) { wgrad_dw_block<256>(dwj, (unsigned)b, prep_sh); return; }
+    b -= dwj.nblk;
+    const long total = groups * ctop;
+    const long nb = (long)gridDim.x - cin - dwj.nblk;
+    for (long i = (long)b * 256 + t; i < total; i += nb * 256) {
+        const int c = (int)(i % ctop);
+        V[i] = pooled[i] > 0.f ? cA[c] * dPool[i] : 0.f;
+    }
+}
+extern "C" long gspn_pooltop_scratch_floats(long rows, int cin, int ctop) {
+    if (rows <= 0 || cin <= 0 || ctop <= 0) return GSPN_ERR_ARG;
+    return (long)cin * cin + cin + (rows / 32 + 1) * (long)ctop + 16;
+}
+// Pass B of a pooled top layer (pool groups of 32 rows) without reading the layer's (rows, ctop) output -- see BwdPool.  a: the layer's
+// gspn_dy_args (dPool, pool_arg, ns = 32, cA/cB/cC; Y only for the dW job's plan); pooled: the (rows/32, ctop) pooled output of the
+// forward pass; scratch: gspn_pooltop_scratch_floats floats.  The dW reduction of the layer rides in the small-operand launch; the previous
+// layer's BN reductions come out of the GEMM's epilogue (part / nparts_out as for gspn_mlp_bwd_data_ex, both required).
+// GSPN_ERR_UNSUPPORTED outside cin <= 64 (multiple of 4), ctop <= 128 (multiple of 4), ns = 32, 16-byte aligned operands.
+extern "C" int gspn_mlp_bwd_data_pooltop(long rows, int cin, int ctop, const gspn_dy_args* a, const float* W, const float* bias, const float* pooled,
+                                         float* scratch, float* dX, int ldx,
+                                         const float* X, int ldx_in, const float* var, const float* gamma, float eps, int use_bn, int is_training,
+                                         const float* work, float* dW,
+                                         const float* Yp, int ldyp, const float* scale_p, const float* shift_p, const float* mean_p, const float* var_p,
+                                         float eps_p, float* part, int* nparts_out, void* stream) {
+    if (rows <= 0 || cin <= 0 || ctop <= 0 || !a || !a->dPool || !a->pool_arg || !a->cA || !a->cB || !a->cC || !W || !pooled || !scratch || !dX ||
+        ldx < cin || !work || !dW || !part || !Yp || ldyp < cin || !scale_p || !shift_p || !mean_p || !var_p || !nparts_out)
+        return GSPN_ERR_ARG;
+    if ((X && ldx_in < cin) || (use_bn && !var)) return GSPN_ERR_ARG;
+    if (a->ns != 32 || (rows & 31) || (cin & 3) || cin > 64 || (ctop & 3) || ctop > 128 || rows >= (1L << 31) || rows * (long)ldx >= (1L << 31) ||
+        rows * (long)ldyp >= (1L << 31) || !vec_ok(Yp, ldyp) || ((uintptr_t)a->dPool % 16) || ((uintptr_t)a->pool_arg % 16) || ((uintptr_t)scratch % 16))
+        return GSPN_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int BNs = cin <= 32 ? 32 : 64;
+    const int QX = cin / 4;
+    const long extra4 = 4L * ctop * BNs + 2L * 4 * ctop * 8, extra2 = 4L * ctop * BNs + 2L * 2 * ctop * 8;
+    const long lds4 = 16L * QX * (BNs + 64 * 4) + 32L * QX + extra4, lds2 = 16L * QX * (BNs + 64 * 2) + 32L * QX + extra2;
+    int trg = 0;
+    if (lds4 <= 53 * 1024 && 4 * ctop <= 512) trg = 4;
+    else if (BNs >= 64 && lds2 <= 80 * 1024 && 2 * ctop <= 512) trg = 2;
+    if (trg && (32 * trg * QX) % 64 != 0) trg = 0;
+    if (trg && 32 * trg * QX / 64 > 32) trg = 0;
+    if (!trg) return GSPN_ERR_UNSUPPORTED;
+    const long groups = rows / 32;
+    float* M = scratch;
+    float* cvec = M + (size_t)cin * cin;
+    float* V = cvec + (cin + 3) / 4 * 4;
+    bool use_stream;
+    const WgradPlan p = wgrad_choose(rows, cin, ctop, a, X, ldx_in, &use_stream);
+    const char* wb = reinterpret_cast<const char*>(work);
+    const DwJob j = dw_job(rows, cin, ctop, p.nslots, reinterpret_cast<const float*>(wb + ws_off_pp(p.nch, cin, ctop)), reinterpret_cast<const double*>(wb),
+                           reinterpret_cast<const float*>(wb + ws_off_g3(ctop)), var, gamma, eps, use_bn, is_training, dW);
+    long vb = (groups * ctop + 256 * 8 - 1) / (256 * 8);
+    if (vb > 1024) vb = 1024;
+    if (vb < 1) vb = 1;
+    hipLaunchKernelGGL(pooltop_prep_kernel, dim3((unsigned)(cin + j.nblk + vb)), dim3(256), 0, st, groups, cin, ctop, W, bias, a->cA, a->cB, a->cC, a->dPool,
+                       pooled, M, cvec, V, j);
+    const size_t dyn = (size_t)(trg == 4 ? lds4 : lds2);
+    const long ntiles = (rows + 32 * trg - 1) / (32 * trg);
+    long bpc = (160L * 1024) / (long)(dyn + 2 * trg * BNs * 4 + 512);
+    if (bpc > 4) bpc = 4;
+    if (bpc < 1) bpc = 1;
+    long gx = (long)GSPN_PLAN_CUS * bpc;
+    if (gx > ntiles) gx = ntiles;
+    const BwdPool bp{a->pool_arg, V, W, ctop, mean_p, var_p, eps_p};
+#define BWDP_GO(BN_, TRG_)                                                                                                             \
+    do {                                                                                                                               \
+        static bool attr_done = false;                                                                                                 \
+        if (!attr_done) {                                                                                                              \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_stream_kernel<BN_, TRG_, false, true>),          \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                                 \
+            if (e != hipSuccess) return (int)e;                                                                                        \
+            attr_done = true;                                                                                                          \
+        }                                                                                                                              \
+        hipLaunchKernelGGL((mlp_fwd_stream_kernel<BN_, TRG_, false, true>), dim3((unsigned)gx, 1), dim3(256), dyn, st, (int)rows, cin, cin, Yp, ldyp, \
+                           scale_p, shift_p, M, cvec, dX, ldx, part, (int)gx, PoolOut{nullptr, nullptr}, GatherSrc{}, bp);              \
+    } while (0)
+    if (BNs == 32 && trg == 4) BWDP_GO(32, 4);
+    else if (BNs == 64 && trg == 4) BWDP_GO(64, 4);
+    else BWDP_GO(64, 2);
+#undef BWDP_GO
+    *nparts_out = (int)gx;
+    return gspn_launch_status();
 }
 // Pass B with both options: the fused dW reduction of gspn_mlp_bwd_data_dw (work != NULL) and the previous layer's BN reductions in the
 // epilogue (part != NULL: Yp (rows, ldyp) = that layer's pre-BN output = this layer's input before activation; scale_p/shift_p its

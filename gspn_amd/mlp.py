@@ -31,6 +31,8 @@ EARLY_R = os.environ.get("GSPN_EARLY_R", "1") != "0"
 # source points, the grouped / interpolated rows are formed from the product.  Training-mode BN stacks with early coefficients only.
 PREAGG = os.environ.get("GSPN_PREAGG", "1") != "0"
 PREAGG_MIN_C = int(os.environ.get("GSPN_PREAGG_MIN_C", "16"))      # below this many feature columns the grouped GEMM is as cheap
+# pass B of a pooled top layer as a streaming GEMM on the layer's INPUT (gspn_mlp_bwd_data_pooltop): its (rows, cout) output is not read
+POOLTOP_STREAM = os.environ.get("GSPN_POOLTOP_STREAM", "1") != "0"
 # one launch for pass B + the dW reduction of the same layer (gspn_mlp_bwd_data_dw) instead of two
 FUSE_DW = os.environ.get("GSPN_FUSE_DW", "1") != "0"
 _side_streams = {}
@@ -193,6 +195,8 @@ class _MlpStack(torch.autograd.Function):
         ctx.versions = [(lp.weights._version, lp.gamma._version if lp.bn else 0) for lp in layers]
         ctx.arg = arg
         ctx.pool_yarg = pool[0] if pool is not None else None
+        if pool_ns:
+            ctx.save_for_backward(out)           # the pooled output: where it is 0 no gradient passes the ReLU (POOLTOP_STREAM)
         ctx.spec = spec
         ctx.rows = rows
         ctx.x_needs_grad = x.requires_grad
@@ -348,7 +352,22 @@ class _MlpStack(torch.autograd.Function):
                             part = torch.empty(int(lib.gspn_rsum_part_floats(rows, cin)), dtype=torch.float32, device=dev)
                             npart = ctypes.c_int(0)
                         bn_dw = 0 if ran_known else int(lp.bn)           # known coefficients: the partial tiles are dW's own (plain sum)
-                        L.check(lib.gspn_mlp_bwd_data_ex(rows, cin, cout, ctypes.byref(a), L.ptr(lp.weights), int(gc[0]), int(gc[1]), L.ptr(dx), dx.shape[1],
+                        top_done = False
+                        if (POOLTOP_STREAM and dz is None and pool_ns == 32 and want_rsum and fuse_dw and known is not None and cin <= 64
+                                and cin % 4 == 0 and cout <= 128 and cout % 4 == 0 and tuple(gc) == (0, cin)):
+                            scr = torch.empty(int(lib.gspn_pooltop_scratch_floats(rows, cin, cout)), dtype=torch.float32, device=dev)
+                            try:
+                                L.check(lib.gspn_mlp_bwd_data_pooltop(rows, cin, cout, ctypes.byref(a), L.ptr(lp.weights), L.ptr(lp.biases),
+                                                                      L.ptr(ctx.saved_tensors[0]), L.ptr(scr), L.ptr(dx), dx.shape[1],
+                                                                      L.ptr(xin), xld, L.ptr(var), L.ptr(lp.gamma if lp.bn else None), BN_EPS, bn_dw,
+                                                                      int(is_training), L.ptr(work), L.ptr(dW),
+                                                                      L.ptr(pY), cin, L.ptr(pscale), L.ptr(pshift), L.ptr(pmean), L.ptr(pvar), BN_EPS,
+                                                                      L.ptr(part), ctypes.byref(npart), st), "mlp_bwd_data_pooltop")
+                                top_done = True
+                            except NotImplementedError:
+                                top_done = False
+                        if not top_done:
+                          L.check(lib.gspn_mlp_bwd_data_ex(rows, cin, cout, ctypes.byref(a), L.ptr(lp.weights), int(gc[0]), int(gc[1]), L.ptr(dx), dx.shape[1],
                                                          L.ptr(xin), xld, L.ptr(var), L.ptr(lp.gamma if lp.bn else None), BN_EPS, bn_dw,
                                                          int(is_training), L.ptr(work) if fuse_dw else None, L.ptr(dW) if fuse_dw else None,
                                                          L.ptr(pY), cin, L.ptr(pscale), L.ptr(pshift), L.ptr(pmean), L.ptr(pvar), BN_EPS, L.ptr(part),

@@ -292,6 +292,19 @@ int gspn_mlp_bwd_data_dw(long rows, int cin, int cout, const gspn_dy_args* a, co
 int gspn_mlp_bwd_data_dw2(long rows, int cin, int cout, const gspn_dy_args* a, const float* W, int col0, int ncols, float* dX, int ldx,
                           const float* X, int ldx_in, const float* var, const float* gamma, float eps, int use_bn, int is_training,
                           const float* work, float* dW, const float* part2, int cin2, int nslots2, float* dW2, void* stream);
+/* Pass B of a POOLED TOP layer (pool groups of 32 rows) as a streaming GEMM on the layer's input: with dY = cA*dyh + cB*y + cC and
+ * y = xhat.W + b,   dX = xhat.(W diag(cB) W^T) + S.W^T + const,   S = cA*dyh (one non-zero per pool group and channel) -- the layer's own
+ * (rows, cout) output is not read.  a: the layer's gspn_dy_args (dPool, pool_arg, ns = 32, cA/cB/cC); pooled: the (rows/32, cout) pooled
+ * output of the forward pass; scratch: gspn_pooltop_scratch_floats(rows, cin, cout) floats.  The layer's dW reduction rides in the small
+ * launch that prepares the operands; the previous layer's BN reductions come out of the epilogue (as gspn_mlp_bwd_data_ex: both required).
+ * GSPN_ERR_UNSUPPORTED outside cin <= 64, cout <= 128 (multiples of 4), ns = 32, 16-byte aligned rows: call gspn_mlp_bwd_data_ex then. */
+long gspn_pooltop_scratch_floats(long rows, int cin, int cout);
+int gspn_mlp_bwd_data_pooltop(long rows, int cin, int cout, const gspn_dy_args* a, const float* W, const float* bias, const float* pooled,
+                              float* scratch, float* dX, int ldx,
+                              const float* X, int ldx_in, const float* var, const float* gamma, float eps, int use_bn, int is_training,
+                              const float* work, float* dW,
+                              const float* Yp, int ldyp, const float* scale_p, const float* shift_p, const float* mean_p, const float* var_p,
+                              float eps_p, float* part, int* nparts_out, void* stream);
 
 /* ---- early coefficients: pass A as ONE GEMM ------------------------------------------------------------------------------------
  * Training-mode BN's backward needs r0 = sum(dyh) and r1 = sum(dyh*xhat) over all rows before dY exists; gspn_mlp_bwd_wgrad side-steps

@@ -313,9 +313,12 @@ def test_dw_reduction_placements_agree():
         res.append([lp.weights.grad.clone() for lp in layers] + [x.grad.clone()])
     for a_, b_ in zip(res[0], res[1]):
         assert rel_err(b_, a_) < 1e-5
-    assert torch.equal(res[0][-1], res[2][-1])
+    if M.POOLTOP_STREAM:        # the fused placement then also takes the pooled top layer's dX from the layer's input: another order of additions
+        assert rel_err(res[2][-1], res[0][-1]) < 1e-5
+    else:
+        assert torch.equal(res[0][-1], res[2][-1])
     for a_, b_ in zip(res[0][:-1], res[2][:-1]):
-        assert rel_err(b_, a_) < 1e-6
+        assert rel_err(b_, a_) < (1e-5 if M.POOLTOP_STREAM else 1e-6)
 
 
 def test_fp_module_grad_cols_shortcut_is_exact():
