@@ -413,12 +413,14 @@ __device__ __forceinline__ int gather_w_row(const GatherSrc& g, int k) {        
 //     dX = dY.W^T = xhat.(W diag(cB) W^T) + S.W^T + 1.((b*cB + cC).W^T),      S = cA*dyh: ONE non-zero per (pool group, channel),
 // so the layer's own (rows, ctop) output is not needed: X is the previous layer's pre-BN output (xhat = relu(bn(X)), exactly the forward's
 // operand), `W` the (cin, cin) matrix W diag(cB) W^T, `bias` the constant row, `Y` dX -- and after the dense k loop a second one runs over
-// the ctop channels with the A operand built from the group's (arg, V) pairs (V = cA * dPool * [pooled output > 0], gspn_pooltop_prep) and
+// the ctop channels with the A operand built from the group's (arg, V) pairs (V = cA * dPool * [pooled output > 0]) and
 // the B operand W^T from LDS.  The epilogue takes the previous layer's BN reductions sum(dyh), sum(dyh*xhat_n) where the forward takes the
 // column statistics (same partial layout), reading the raw X tile that is still in LDS.  134 MB of Y (SA level 1) are not read.
 struct BwdPool {
     const int* arg;       // (groups, ctop) row offset of each group's arg-max
-    const float* V;       // (groups, ctop)
+    const float* dPool;   // (groups, ctop) upstream gradient of the pooled output
+    const float* pooled;  // (groups, ctop) the pooled output itself: where it is 0 the ReLU passes nothing
+    const float* cA;      // (ctop)        V = cA * dPool * [pooled > 0] is formed as the pairs are fetched
     const float* Wtop;    // (cin, ctop) the layer's weights
     int ctop;
     const float* mean;    // batch statistics of the previous layer (whose pre-BN output X is)
@@ -518,7 +520,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_stream_kernel(int rows, int cin, 
                 if (gl < TRG && c < bp.ctop) {
                     const long g = min((long)tile * TRG + gl, ngroups - 1);
                     pv_a[i] = bp.arg[g * bp.ctop + c];
-                    pv_v[i] = bp.V[g * bp.ctop + c];
+                    pv_v[i] = bp.pooled[g * bp.ctop + c] > 0.f ? bp.cA[c] * bp.dPool[g * bp.ctop + c] : 0.f;
                 }
             }
         }
@@ -2697,12 +2699,11 @@ extern "C" int gspn_mlp_bwd_data_dw2(long rows, int cin, int cout, const gspn_dy
     return bwd_data_launch(rows, cin, cout, a, W, col0, ncols, dX, ldx, &j, (hipStream_t)stream);
 }
 // ---- pass B of a pooled top layer as a streaming GEMM on the layer's input (mlp_fwd_stream_kernel<.., BWDP>) ----
-// the small operands: workgroups [0, cin): row n of M = W diag(cB) W^T and cvec[n] = sum_c (b[c]*cB[c] + cC[c]) * W[n][c]; then the
-// dW reduction of the layer (dwj.nblk workgroups, its usual ride); the rest: V = cA * dPool * [pooled output > 0] over (groups, ctop)
-__global__ __launch_bounds__(256) void pooltop_prep_kernel(long groups, int cin, int ctop, const float* __restrict__ W, const float* __restrict__ bias,
-                                                           const float* __restrict__ cA, const float* __restrict__ cB, const float* __restrict__ cC,
-                                                           const float* __restrict__ dPool, const float* __restrict__ pooled, float* __restrict__ M,
-                                                           float* __restrict__ cvec, float* __restrict__ V, DwJob dwj) {
+// the small operands: workgroups [0, cin): row n of M = W diag(cB) W^T and cvec[n] = sum_c (b[c]*cB[c] + cC[c]) * W[n][c]; the rest: the
+// dW reduction of the layer (dwj.nblk workgroups, its usual ride)
+__global__ __launch_bounds__(256) void pooltop_prep_kernel(int cin, int ctop, const float* __restrict__ W, const float* __restrict__ bias,
+                                                           const float* __restrict__ cB, const float* __restrict__ cC, float* __restrict__ M,
+                                                           float* __restrict__ cvec, DwJob dwj) {
     __shared__ __attribute__((aligned(16))) double prep_sh[2 * 16 * DW_OX + MAXCH / 2 + 8];
     const int t = threadIdx.x;
     int b = blockIdx.x;
@@ -2727,18 +2728,11 @@ __global__ __launch_bounds__(256) void pooltop_prep_kernel(long groups, int cin,
         return;
     }
     b -= cin;
-    if (b < dwj.nblk) { wgrad_dw_block<256>(dwj, (unsigned)b, prep_sh); return; }
-    b -= dwj.nblk;
-    const long total = groups * ctop;
-    const long nb = (long)gridDim.x - cin - dwj.nblk;
-    for (long i = (long)b * 256 + t; i < total; i += nb * 256) {
-        const int c = (int)(i % ctop);
-        V[i] = pooled[i] > 0.f ? cA[c] * dPool[i] : 0.f;
-    }
+    if (b < dwj.nblk) wgrad_dw_block<256>(dwj, (unsigned)b, prep_sh);
 }
 extern "C" long gspn_pooltop_scratch_floats(long rows, int cin, int ctop) {
     if (rows <= 0 || cin <= 0 || ctop <= 0) return GSPN_ERR_ARG;
-    return (long)cin * cin + cin + (rows / 32 + 1) * (long)ctop + 16;
+    return (long)cin * cin + cin + 16;
 }
 // Pass B of a pooled top layer (pool groups of 32 rows) without reading the layer's (rows, ctop) output -- see BwdPool.  a: the layer's
 // gspn_dy_args (dPool, pool_arg, ns = 32, cA/cB/cC; Y only for the dW job's plan); pooled: the (rows/32, ctop) pooled output of the
@@ -2756,7 +2750,7 @@ extern "C" int gspn_mlp_bwd_data_pooltop(long rows, int cin, int ctop, const gsp
         return GSPN_ERR_ARG;
     if ((X && ldx_in < cin) || (use_bn && !var)) return GSPN_ERR_ARG;
     if (a->ns != 32 || (rows & 31) || (cin & 3) || cin > 64 || (ctop & 3) || ctop > 128 || rows >= (1L << 31) || rows * (long)ldx >= (1L << 31) ||
-        rows * (long)ldyp >= (1L << 31) || !vec_ok(Yp, ldyp) || ((uintptr_t)a->dPool % 16) || ((uintptr_t)a->pool_arg % 16) || ((uintptr_t)scratch % 16))
+        rows * (long)ldyp >= (1L << 31) || !vec_ok(Yp, ldyp) || ((uintptr_t)scratch % 16))
         return GSPN_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     const int BNs = cin <= 32 ? 32 : 64;
@@ -2769,20 +2763,14 @@ extern "C" int gspn_mlp_bwd_data_pooltop(long rows, int cin, int ctop, const gsp
     if (trg && (32 * trg * QX) % 64 != 0) trg = 0;
     if (trg && 32 * trg * QX / 64 > 32) trg = 0;
     if (!trg) return GSPN_ERR_UNSUPPORTED;
-    const long groups = rows / 32;
     float* M = scratch;
     float* cvec = M + (size_t)cin * cin;
-    float* V = cvec + (cin + 3) / 4 * 4;
     bool use_stream;
     const WgradPlan p = wgrad_choose(rows, cin, ctop, a, X, ldx_in, &use_stream);
     const char* wb = reinterpret_cast<const char*>(work);
     const DwJob j = dw_job(rows, cin, ctop, p.nslots, reinterpret_cast<const float*>(wb + ws_off_pp(p.nch, cin, ctop)), reinterpret_cast<const double*>(wb),
                            reinterpret_cast<const float*>(wb + ws_off_g3(ctop)), var, gamma, eps, use_bn, is_training, dW);
-    long vb = (groups * ctop + 256 * 8 - 1) / (256 * 8);
-    if (vb > 1024) vb = 1024;
-    if (vb < 1) vb = 1;
-    hipLaunchKernelGGL(pooltop_prep_kernel, dim3((unsigned)(cin + j.nblk + vb)), dim3(256), 0, st, groups, cin, ctop, W, bias, a->cA, a->cB, a->cC, a->dPool,
-                       pooled, M, cvec, V, j);
+    hipLaunchKernelGGL(pooltop_prep_kernel, dim3((unsigned)(cin + j.nblk)), dim3(256), 0, st, cin, ctop, W, bias, a->cB, a->cC, M, cvec, j);
     const size_t dyn = (size_t)(trg == 4 ? lds4 : lds2);
     const long ntiles = (rows + 32 * trg - 1) / (32 * trg);
     long bpc = (160L * 1024) / (long)(dyn + 2 * trg * BNs * 4 + 512);
@@ -2790,7 +2778,7 @@ extern "C" int gspn_mlp_bwd_data_pooltop(long rows, int cin, int ctop, const gsp
     if (bpc < 1) bpc = 1;
     long gx = (long)GSPN_PLAN_CUS * bpc;
     if (gx > ntiles) gx = ntiles;
-    const BwdPool bp{a->pool_arg, V, W, ctop, mean_p, var_p, eps_p};
+    const BwdPool bp{a->pool_arg, a->dPool, pooled, a->cA, W, ctop, mean_p, var_p, eps_p};
 #define BWDP_GO(BN_, TRG_)                                                                                                             \
     do {                                                                                                                               \
         static bool attr_done = false;                                                                                                 \
