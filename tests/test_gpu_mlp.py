@@ -48,13 +48,15 @@ def to_layers(ps):
     return layers
 
 
-def check_stack(rows, ld, cin, chans, ns, training, ref_device="cpu"):
+def check_stack(rows, ld, cin, chans, ns, training, ref_device="cpu", neg_gamma=False):
     """mlp_stack forward + backward against oracle/mlp_ref.py evaluated in float64 on `ref_device`"""
     from gspn_amd.mlp import mlp_stack
     g = torch.Generator().manual_seed(rows + cin)
     x64 = torch.randn(rows, ld, generator=g, dtype=torch.float64)
     x64[:, cin:] = 0
     ps = make_params(chans, cin, seed=cin)
+    if neg_gamma:
+        ps[-1]["gamma"][::3] *= -1.0             # every third channel of the last layer: negative BN scale (the pool then takes the group minimum of y)
     if not training:
         for p in ps:
             p["moving_mean"] = torch.randn(p["w"].shape[1], generator=g, dtype=torch.float64) * 0.1
@@ -252,6 +254,17 @@ def test_early_coefficients_equal_the_two_product_pass(rows, cin, chans, ns, mon
     for a_, b_ in zip(res[0], res[1]):
         scale = float(b_.abs().max())
         assert float((a_ - b_).abs().max()) <= 2e-5 * max(scale, 1e-3)
+
+
+@pytest.mark.parametrize("stream", [True, False])
+@pytest.mark.parametrize("rows,cin,chans", [(4096, 32, [32, 64]), (2048 + 64, 6, [32, 32, 64]), (8192, 20, [24, 64, 128]), (1024, 64, [64, 128])])
+def test_pooled_top_layer_backward_from_its_input(rows, cin, chans, stream, monkeypatch):
+    """mlp.POOLTOP_STREAM: the pooled top layer's pass B as a streaming GEMM on the layer's input (its own output is not read), against
+    the float64 restatement -- with negative BN scales on the pooled layer (arg = the group minimum there), partial last tiles, and the
+    shapes outside the kernel's LDS budget that fall back to the register-staged pass B"""
+    from gspn_amd import mlp as M
+    monkeypatch.setattr(M, "POOLTOP_STREAM", stream)
+    check_stack(rows, (cin + 3) // 4 * 4, cin, chans, 32, True, neg_gamma=True)
 
 
 @pytest.mark.parametrize("T,rows,nsrc,cout,side_n,per_scene", [(1, 5000, 700, 64, 3, 0), (3, 4096, 300, 32, 4, 2), (3, 999, 128, 128, 0, 1), (1, 64, 9, 8, 1, 0)])
