@@ -252,3 +252,56 @@ def test_fused_sa_front_end_equals_the_materialised_path(kind, b, n, c, npoint, 
             assert rel_err(res[mode][2][k], res["rows"][2][k]) < 1e-5, (mode, k)
     rnew, ref, ridx, leaves = ref_sa(res["preagg"][3], 'sa', xyz, pts, npoint, radius, ns, mlp, None, False, 'max', False, True, 0.5)
     assert rel_err(res["preagg"][0], ref) < 1e-5
+
+
+def test_preaggregated_first_layer_random_shapes(monkeypatch):
+    """seeded sweep over batch, cloud size, centres, nsample, feature width and layer widths: the pre-aggregated first layer (SA modules
+    with xyz first and features first, FP modules with 0..4 gradient-free skip columns) against the path that materialises the rows"""
+    from gspn_amd import mlp as M
+    from gspn_amd import pointnet_util as PU
+    from gspn_amd.geometry import fp_geometry, sa_geometry
+    rng = np.random.default_rng(77)
+    taken = 0
+    for trial in range(16):
+        b = int(rng.integers(1, 4))
+        n = int(rng.integers(300, 3000))
+        c = int(rng.choice([16, 20, 32, 48, 64, 100]))
+        widths = [int(rng.choice([32, 64, 128])), int(rng.choice([16, 32, 48, 64]))] + ([int(rng.choice([32, 64]))] if trial % 3 == 0 else [])
+        xyz = D.batch("UDS"[trial % 3], b, n, trial)
+        pts = rng.standard_normal((b, n, c)).astype(np.float32)
+        res = {}
+        if trial % 2 == 0:          # SA module
+            npoint = int(rng.integers(16, max(17, n // 4)))
+            ns = int(rng.choice([8, 16, 32, 64]))
+            radius = float(rng.choice([0.15, 0.3, 0.6]))
+            for pre in (True, False):
+                monkeypatch.setattr(M, "PREAGG", pre)
+                store = fresh_store(trial)
+                tp = dev(pts).requires_grad_(True)
+                _, out, _ = PU.pointnet_sa_module(dev(xyz), tp, npoint, radius, ns, widths, None, False, True, 0.5, 'sa')
+                g = torch.from_numpy(np.random.default_rng(trial).standard_normal(tuple(out.shape)).astype(np.float32)).cuda()
+                out.backward(g)
+                res[pre] = (out.detach(), tp.grad.clone(), {k: v.grad.clone() for k, v in store.named_parameters()})
+            monkeypatch.setattr(M, "PREAGG", True)
+            taken += int(M.preagg_ok(PU._mlp_layers(widths, 3 + c, 'probe%d' % trial, True), True, c))
+        else:                       # FP module: dense cloud = xyz, sparse = an FPS sample, 0..4 skip columns without a gradient
+            m = int(rng.integers(8, max(9, n // 5)))
+            c1 = int(rng.integers(0, 5))
+            xyz2 = O.gather_point(xyz, O.farthest_point_sample(m, xyz))
+            p1 = rng.standard_normal((b, n, c1)).astype(np.float32) if c1 else None
+            p2 = rng.standard_normal((b, m, c)).astype(np.float32)
+            for pre in (True, False):
+                monkeypatch.setattr(PU, "FUSE_FP_FRONT", pre)
+                store = fresh_store(trial)
+                t2 = dev(p2).requires_grad_(True)
+                out = PU.pointnet_fp_module(dev(xyz), dev(xyz2), dev(p1) if c1 else None, t2, widths, True, 0.5, 'fa')
+                g = torch.from_numpy(np.random.default_rng(trial).standard_normal(tuple(out.shape)).astype(np.float32)).cuda()
+                out.backward(g)
+                res[pre] = (out.detach(), t2.grad.clone(), {k: v.grad.clone() for k, v in store.named_parameters()})
+            taken += 1
+        what = "trial %d" % trial
+        assert rel_err(res[True][0], res[False][0]) < 5e-6, what
+        assert rel_err(res[True][1], res[False][1]) < 2e-5, what
+        for k in res[True][2]:
+            assert rel_err(res[True][2][k], res[False][2][k]) < 2e-5, (what, k)
+    assert taken >= 12
