@@ -277,11 +277,12 @@ def test_preaggregated_first_layer_random_shapes(monkeypatch):
             for pre in (True, False):
                 monkeypatch.setattr(M, "PREAGG", pre)
                 store = fresh_store(trial)
-                tp = dev(pts).requires_grad_(True)
+                wants = trial % 4 != 2            # every other SA trial: features without a gradient (no inverse lists, no d(feat) launch to ride in)
+                tp = dev(pts).requires_grad_(wants)
                 _, out, _ = PU.pointnet_sa_module(dev(xyz), tp, npoint, radius, ns, widths, None, False, True, 0.5, 'sa')
                 g = torch.from_numpy(np.random.default_rng(trial).standard_normal(tuple(out.shape)).astype(np.float32)).cuda()
                 out.backward(g)
-                res[pre] = (out.detach(), tp.grad.clone(), {k: v.grad.clone() for k, v in store.named_parameters()})
+                res[pre] = (out.detach(), tp.grad.clone() if wants else torch.zeros(1), {k: v.grad.clone() for k, v in store.named_parameters()})
             monkeypatch.setattr(M, "PREAGG", True)
             taken += int(M.preagg_ok(PU._mlp_layers(widths, 3 + c, 'probe%d' % trial, True), True, c))
         else:                       # FP module: dense cloud = xyz, sparse = an FPS sample, 0..4 skip columns without a gradient
