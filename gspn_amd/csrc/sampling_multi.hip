@@ -467,12 +467,15 @@ static int launch_fps_multi(int b, int n, int m, int csz, int G, const float* sx
 }
 
 // G workgroups per scene.  A workgroup holds at most 32768 points (2048 per wave: x, y, min-distance in 96 VGPRs, z in LDS), but the
-// 1024-point-per-wave instance keeps everything in registers with room to spare, so the default is ceil(n / 16384) while that is
-// <= 32 and the fewest that hold the scene beyond.  The caller may ask for more (finer cells, shorter updates), never for fewer.
+// 1024-point-per-wave instance keeps everything in registers with room to spare and the 1536-point one (z in LDS) nearly so.  Every
+// workgroup more makes a round's exchange longer, so the default is ceil(n / 16384) while that is <= 10, then ceil(n / 24576) while
+// that is <= 32, and the fewest that hold the scene beyond (measured on MI355X, ms for m = 30000: n = 150000: G 7..10 26.1-26.6, 16: 36;
+// n = 250000: 11: 31.2, 16: 35.7; n = 400000: 17: 42.6, 25: 60.9).  The caller may ask for more (finer cells), never for fewer.
 static int fps_multi_pick_g(int n, int G) {
     const int gmin = (n + 32767) / 32768;
     if (G <= 0) {
         G = (n + 16383) / 16384;
+        if (G > 10) G = (n + 24575) / 24576;
         if (G > FPSM_GMAX) G = gmin;
     }
     if (G < gmin) G = gmin;
