@@ -58,8 +58,9 @@ int gspn_fps_cells_sample(int b, int n, int m, const float* inp, const void* ws,
 
 /* Scenes that do not fit one CU (n > 32768; tf_sampling_g.cu:137-141 is the reference's any-n path, data_prep.py:64-83 its caller
  * at n ~ 1e5, m = 30000): the same cell scheme on G workgroups (CUs) per scene, 16*G cells, candidates exchanged between the CUs
- * once per round (gspn_amd/csrc/sampling_multi.hip).  Output identical to gspn_farthestpointsampling.  G = 0 picks the fewest
- * workgroups that hold the scene (ceil(n/32768)); a larger G (<= 32) means smaller cells and shorter rounds.  Works for any
+ * once per round (gspn_amd/csrc/sampling_multi.hip).  Output identical to gspn_farthestpointsampling.  G = 0 picks the
+ * workgroup count measured fastest for the scene size (ceil(n/16384) up to 10, ceil(n/24576) up to 32, ceil(n/32768) beyond); the caller
+ * may ask for more (<= 32: smaller cells, but every workgroup lengthens a round's exchange), never for fewer than hold the scene.  Works for any
  * n >= 1 (also below 32768, e.g. one large scene spread over several CUs).  ws: gspn_fps_multi_ws_bytes(b,n) bytes.
  * prepass + sample = the combined call, as for the single-CU cell kernel.  gspn_fps_multi_status synchronises the stream and returns
  * 0, or 1 if a bounded inter-workgroup wait expired (the workgroups of a scene were not co-resident; output invalid). */
