@@ -476,7 +476,9 @@ def mlp_roofline(mlp_mod, eager_step, state, reps=3):
             "kernels": "mlp_fwd_* / wgrad_* (+ finalize) / mlp_bwd_data_* of the 16 layers of pn2_fea_extractor",
             "flops_per_step": flops, "gemm_ms_per_step": total_ms, "ms_by_pass": by,
             "algorithmic_bytes_per_step": nbytes, "algorithmic_TBps": nbytes / (total_ms * 1e-3) / 1e12,
-            "note": "eager launches bracketed one by one (includes ~1-2 us of event overhead per launch); profiles/ holds the rocprofv3 per-kernel table of the captured step"}
+            "note": "flops = SURVEY 8(d)'s algorithmic count of the 16 layers (the pre-aggregated first layers of SA2 / SA3 / the last FP level execute "
+                    "fewer: their feature part runs on the source points); eager launches bracketed one by one (includes ~1-2 us of event overhead per "
+                    "launch); profiles/ holds the rocprofv3 per-kernel table of the captured step"}
 
 
 def _time_steps(fn, warm, reps):
