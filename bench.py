@@ -260,7 +260,9 @@ def main():
             # Geometry of step i+DEPTH, to run under the layers of steps i+1 .. i+DEPTH.  In graph mode it refills the persistent buffers
             # of slot (i+DEPTH) % NB = (i-1) % NB, which the layers of step i-1 read: the HOST waits for that step (step i is already
             # queued behind it, so the GPU never idles) instead of making the side stream wait on the layers' stream.
-            done[i] = torch.cuda.current_stream().record_event()
+            # (only the step whose completion the host will wait for gets an event: the last of each group)
+            if not PAIRED or i % GROUP == GROUP - 1:
+                done[i] = torch.cuda.current_stream().record_event()
             if PAIRED:
                 # every GROUP-th step submits the geometry of steps i+GROUP .. i+2*GROUP-1 at once (their slots were last read by steps
                 # i-GROUP .. i-1: the host waits for step i-1)
