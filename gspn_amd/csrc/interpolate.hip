@@ -3,6 +3,7 @@
 // :187,222,262), so every FP module round-trips through the host.  These kernels keep the data
 // on the device and reproduce the host arithmetic: unfused fp32, left to right.
 #include <math.h>
+#include <stdlib.h>
 #include <stdint.h>
 
 #include "common.h"
@@ -22,11 +23,12 @@
 #define NN_Q 1
 #define NN_B 8             // candidates tested per branch: the rejection values of a batch are independent (ILP), one compare decides
 __global__ __launch_bounds__(NN_BLOCK) void three_nn_kernel(int b, int n, int m, const float* __restrict__ xyz1, const float* __restrict__ xyz2,
-                                                            float* __restrict__ dist, int* __restrict__ idx, const int* __restrict__ order) {
+                                                            float* __restrict__ dist, int* __restrict__ idx, const int* __restrict__ order, unsigned nblocks) {
     __shared__ float4 tile[NN_TILE + NN_B];
     __shared__ float tile_pm[NN_BLOCK / 64];
-    const int scene = blockIdx.x % b;               // scene <-> XCD affinity for the sparse cloud
-    const int j0 = (blockIdx.x / b) * (NN_BLOCK * NN_Q) + threadIdx.x;      // queries j0 + u*NN_BLOCK
+    for (unsigned blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {      // (a capped grid walks the query tiles: GSPN_NN_GRID)
+    const int scene = blk % b;                      // scene <-> XCD affinity for the sparse cloud
+    const int j0 = (blk / b) * (NN_BLOCK * NN_Q) + threadIdx.x;      // queries j0 + u*NN_BLOCK
     float x1[NN_Q], y1[NN_Q], z1[NN_Q];
 #pragma unroll
     for (int u = 0; u < NN_Q; ++u) {
@@ -124,13 +126,18 @@ __global__ __launch_bounds__(NN_BLOCK) void three_nn_kernel(int b, int n, int m,
             oi[0] = i1[u]; oi[1] = i2[u]; oi[2] = i3[u];
         }
     }
+    }
+}
+static unsigned nn_grid(long long blocks) {
+    static const long long cap = [] { const char* e = getenv("GSPN_NN_GRID"); const long long v = e ? atoll(e) : 0; return v > 0 ? v : (1ll << 31); }();
+    return (unsigned)(blocks < cap ? blocks : cap);
 }
 extern "C" int gspn_threenn(int b, int n, int m, const float* xyz1, const float* xyz2, float* dist, int* idx, void* stream) {
     if (b < 0 || n < 0 || m < 0) return GSPN_ERR_ARG;
     if (b == 0 || n == 0) return 0;
     const long long blocks = (long long)b * ((n + NN_BLOCK * NN_Q - 1) / (NN_BLOCK * NN_Q));
     if (blocks > 0x7FFFFFFFll) return GSPN_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(three_nn_kernel, dim3((unsigned)blocks), dim3(NN_BLOCK), 0, (hipStream_t)stream, b, n, m, xyz1, xyz2, dist, idx, (const int*)nullptr);
+    hipLaunchKernelGGL(three_nn_kernel, dim3(nn_grid(blocks)), dim3(NN_BLOCK), 0, (hipStream_t)stream, b, n, m, xyz1, xyz2, dist, idx, (const int*)nullptr, (unsigned)blocks);
     return gspn_launch_status();
 }
 extern "C" int gspn_threenn_ordered(int b, int n, int m, const float* xyz1, const float* xyz2, const int* order, float* dist, int* idx, void* stream) {
@@ -138,7 +145,7 @@ extern "C" int gspn_threenn_ordered(int b, int n, int m, const float* xyz1, cons
     if (b == 0 || n == 0) return 0;
     const long long blocks = (long long)b * ((n + NN_BLOCK * NN_Q - 1) / (NN_BLOCK * NN_Q));
     if (blocks > 0x7FFFFFFFll) return GSPN_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(three_nn_kernel, dim3((unsigned)blocks), dim3(NN_BLOCK), 0, (hipStream_t)stream, b, n, m, xyz1, xyz2, dist, idx, order);
+    hipLaunchKernelGGL(three_nn_kernel, dim3(nn_grid(blocks)), dim3(NN_BLOCK), 0, (hipStream_t)stream, b, n, m, xyz1, xyz2, dist, idx, order, (unsigned)blocks);
     return gspn_launch_status();
 }
 
