@@ -518,8 +518,7 @@ __global__ void csr_fill_kernel(long total, int L, int n, const int* __restrict_
 }
 // count + scan + fill of ONE scene in one workgroup, the histogram and the cursors in LDS (n <= CSR_LDS_MAX_N): no global atomics, one
 // launch instead of a memset and three kernels (the default; GSPN_CSR_GLOBAL=1 selects the kernels above for comparison).  Beside the
-// captured layers both forms cost the same, 0.2 ms per step for the five lists of a batch, whatever the grid size: most of it is the
-// fixed price of ANY activity on a second hardware queue, not what these kernels do.
+// captured layers both forms cost about the same (0.07 ms per step for the five lists of a batch, whatever the grid size).
 #define CSR_LDS_MAX_N 32768
 __global__ __launch_bounds__(1024) void csr_build_lds_kernel(int L, int n, const int* __restrict__ idx, int* __restrict__ offsets, int* __restrict__ tmp) {
     extern __shared__ int csr_cnt[];                 // [n]
