@@ -52,6 +52,10 @@ def main():
     ap.add_argument("--sync-bn", action="store_true", help="optional SyncBN (global-batch statistics, SURVEY 8e): unfused layers + two small "
                     "all-reduces per layer, no hipGraph; NOT the headline configuration")
     ap.add_argument("--no-extra", action="store_true", help="skip the post-run legs (per-kernel rooflines of the layers / ball query, other_configs)")
+    ap.add_argument("--force-collective", action="store_true", help="issue the gradient all-reduce through RCCL even at world size 1 (one-rank "
+                    "communicator, identity result): the collective path of the N>1 runs, executed on a single GPU; the line then carries `collective`")
+    ap.add_argument("--collective-in-graph", action="store_true", help="capture the all-reduce as the last node of the captured step instead of "
+                    "issuing it after the replay (diagnostic: the default placement is after the graph)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -74,7 +78,9 @@ def main():
     if args.sync_bn:
         mlp_mod.SYNC_BN = True
         args.no_graph = True                      # collectives inside the layers: not captured
-    rank, local, world = parallel.init_from_env()
+    rank, local, world = parallel.init_from_env(force=args.force_collective)
+    FORCE_COLL = bool(args.force_collective)
+    COLL_IN_GRAPH = bool(args.collective_in_graph) and (world > 1 or FORCE_COLL)
     if world != args.gpus:
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d): the line would report n_gpus != --gpus" % (world, args.gpus))
     dev = torch.device("cuda", local)
@@ -138,8 +144,9 @@ def main():
         state["bucket"].flatten()
         return loss.detach()          # (a live loss would keep the autograd graph -- and its AccumulateGrad nodes -- alive across captures)
 
-    def finish():
-        state["bucket"].all_reduce(average=False)    # one flat RCCL all-reduce (SUM; no-op at world 1)
+    def finish(in_graph=False):
+        if not in_graph:
+            state["bucket"].all_reduce(average=False, force=FORCE_COLL)    # one flat RCCL all-reduce (SUM; no-op at world 1 unless --force-collective)
         state["opt"].step(grad_scale=1.0 / world)    # the division by the world size rides in the Adam kernel
 
     graphs = None
@@ -151,7 +158,10 @@ def main():
         graphs = []
         def captured(k):
             state["opt"].zero_grad(set_to_none=True)          # host-side only: the captured backward ASSIGNS fresh gradients, flatten() re-points them
-            return fwd_bwd(k, G[k])
+            r = fwd_bwd(k, G[k])
+            if COLL_IN_GRAPH:
+                state["bucket"].all_reduce(average=False, force=FORCE_COLL)      # the collective as the captured step's last node (--collective-in-graph)
+            return r
         for k in range(NB):
             graphs.append(CapturedStep(lambda k=k: captured(k), pool=graphs[0].pool() if graphs else None))
 
@@ -255,7 +265,7 @@ def main():
             if state["opt"] is not None:
                 state["opt"].zero_grad(set_to_none=True)      # backward assigns fresh grads; the bucket re-points them at its slices
             fwd_bwd(k, g)
-        finish()
+        finish(in_graph=use_graph and COLL_IN_GRAPH)
         if geo is not None and not LAYERS_ONLY:
             # Geometry of step i+DEPTH, to run under the layers of steps i+1 .. i+DEPTH.  In graph mode it refills the persistent buffers
             # of slot (i+DEPTH) % NB = (i-1) % NB, which the layers of step i-1 read: the HOST waits for that step (step i is already
@@ -359,6 +369,10 @@ def main():
         except Exception:
             traffic = None
 
+    coll = None
+    if world > 1 or FORCE_COLL:         # every rank enters (a collective is entered by all ranks or by none); after the timed region
+        coll = collective_leg(state["bucket"], world, FORCE_COLL, "last node of the captured step" if (use_graph and COLL_IN_GRAPH) else
+                              "after the graph replay, before the Adam kernel (same stream)")
     if rank == 0:
         global_batch = SCENES_PER_GPU * world
         res = {
@@ -391,6 +405,8 @@ def main():
             "host_wait_ms_per_step": state["t_wait"] / args.steps * 1e3,
             "host_replay_ms_per_step": state.get("t_replay", 0.0) / (args.steps + args.warmup) * 1e3,
         }
+        if coll is not None:
+            res["collective"] = coll
         if world == 1 and not LAYERS_ONLY and not args.no_extra:
             torch.cuda.synchronize()
             try:
@@ -408,9 +424,31 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(xyz_np0, col_np0)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+
+
+def collective_leg(bucket, world, forced, placement, reps=50):
+    """the gradient all-reduce alone: `reps` back-to-back calls on an otherwise idle stream, HIP events around the lot (rank 0's view; the
+    other ranks run the same calls -- a collective is entered by everyone or by no one)"""
+    flat = bucket.flat
+    keep = flat.clone()
+    for _ in range(3):
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(reps):
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    e1.record()
+    t_host = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    flat.copy_(keep)
+    return {"backend": dist.get_backend(), "world": world, "forced_at_world_1": bool(forced and world == 1), "placement": placement,
+            "bucket_bytes": flat.numel() * 4, "allreduce_ms_standalone": e0.elapsed_time(e1) / reps, "host_enqueue_ms_per_call": t_host / reps * 1e3,
+            "note": "per-step cost inside the step = ms_per_step of this run minus that of the same command without the collective (DESIGN 6)"}
 
 
 def ball_query_roofline(bq_prof, batches, G):

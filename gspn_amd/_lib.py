@@ -73,6 +73,7 @@ SIGNATURES = {
     "gspn_mlp_fwd_pool32": [_L, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P],
     "gspn_pool32_select": [_L, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P],
     "gspn_sa_rel": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
+    "gspn_sa_rel_shift": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     "gspn_mlp_gather_cin": [_c.POINTER(GatherArgs)],
     "gspn_mlp_fwd_gather": [_L, _c.POINTER(GatherArgs), _I, _P, _P, _P, _I, _P, _P],
     "gspn_mlp_bwd_wgrad_gather": [_L, _c.POINTER(GatherArgs), _I, _c.POINTER(DyArgs), _P, _P, _P, _F, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
@@ -85,6 +86,9 @@ SIGNATURES = {
     "gspn_bn_finalize_parts": [_L, _I, _P, _I, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P],
     "gspn_bnrelu_maxpool": [_L, _I, _I, _P, _I, _P, _P, _P, _P, _P],
     "gspn_bnrelu_apply": [_L, _I, _P, _I, _P, _P, _P, _I, _P],
+    "gspn_bn_colsum": [_L, _I, _P, _I, _P, _I, _P, _P, _F, _P, _c.POINTER(_I), _P],
+    "gspn_bn_apply": [_L, _I, _P, _I, _P, _P, _I, _P, _I, _P],
+    "gspn_bn_backward_apply": [_L, _I, _P, _I, _P, _I, _P, _P, _P, _P, _I, _P],
     "gspn_mlp_bwd_data_pooltop": [_L, _I, _I, _c.POINTER(DyArgs), _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _F, _I, _I, _P, _P,
                                   _P, _I, _P, _P, _P, _P, _F, _P, _c.POINTER(_I), _P],
     "gspn_mlp_bwd_wgrad": [_L, _I, _I, _c.POINTER(DyArgs), _P, _I, _P, _P, _P, _P, _P, _F, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
@@ -107,12 +111,16 @@ SPECIAL = {
     "gspn_mlp_fwd_stats_bytes": ([_L, _I], _L),
     "gspn_fps_cells_ws_bytes": ([_I, _I], _L),
     "gspn_fps_multi_ws_bytes": ([_I, _I], _L),
+    "gspn_fps_multi_status_offset": ([_I, _I], _L),
     "gspn_rsum_part_floats": ([_L, _I], _L),
+    "gspn_bn_colsum_part_floats": ([_L, _I], _L),
     "gspn_preagg_part_floats": ([_I, _I], _L),
     "gspn_preagg_fwd_parts": ([_L, _I], _L),
     "gspn_pooltop_scratch_floats": ([_L, _I, _I], _L),
     "gspn_inverse_lists_work_ints": ([_I, _I, _I], _L),
 }
+
+ABI_VERSION = 3         # == GSPN_ABI_VERSION of include/gspn_hip.h this binding was written against
 
 _lib = None
 
@@ -137,6 +145,10 @@ def lib():
             fn = getattr(h, name)
             fn.argtypes = args
             fn.restype = res
+        got = int(h.gspn_abi_version())
+        if got != ABI_VERSION:
+            raise GspnHipError("libgspn_hip.so at %s has ABI version %d, this binding needs %d: rebuild it (`python -m gspn_amd.build --force`)"
+                               % (LIB_PATH, got, ABI_VERSION))
         _lib = h
     return _lib
 
@@ -149,6 +161,34 @@ def check(rc, what):
     if rc == -2:
         raise NotImplementedError("%s: input outside the supported range of this build" % what)
     raise GspnHipError("%s: HIP error %d" % (what, rc))
+
+
+# Device-side status words that cannot be read where the kernel is launched without a synchronisation (the multi-CU FPS: a bounded
+# inter-workgroup wait that expired).  The launcher copies the word to pinned host memory behind the kernel and registers it here;
+# check_async() raises for every registered word whose copy has completed with a non-zero value.  It is called by the op wrappers
+# before their next launch and by PendingGeometry.get() after its wait -- the next natural synchronisation points.
+_async_status = []
+
+
+def register_async_status(host_word, event, what):
+    _async_status.append((host_word, event, what))
+
+
+def check_async(block=False):
+    """raise GspnHipError if a kernel launched earlier reported a failure through its status word (block=True: wait for all of them)"""
+    keep, bad = [], None
+    for host_word, event, what in _async_status:
+        if block:
+            event.synchronize()
+        if event.query():
+            if int(host_word.item()) != 0 and bad is None:
+                bad = what
+        else:
+            keep.append((host_word, event, what))
+    _async_status[:] = keep
+    if bad is not None:
+        raise GspnHipError("%s: a bounded inter-workgroup wait expired (the workgroups of a scene were not co-resident -- another kernel held "
+                           "the CUs); the output of that call is invalid (all indices 0 past the failure)" % bad)
 
 
 def stream():

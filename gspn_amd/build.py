@@ -36,19 +36,34 @@ def _newer(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+# translation units whose arithmetic depends on GSPN_DIST_POLICY (common.h: dist2_cuda); a policy-variant library holds only these
+POLICY_SOURCES = ("sampling.hip", "sampling_multi.hip", "grouping.hip", "nndistance.hip")
+
+
+def policy_lib_path(policy):
+    return os.path.join(LIBDIR, "libgspn_hip_p%d.so" % policy)
+
+
 def build(force=False, verbose=False, policy=None):
-    os.makedirs(OBJ, exist_ok=True)
+    """policy=None: the product library (GSPN_DIST_POLICY 2, common.h).  policy=0/1/2: a VARIANT library
+    lib/libgspn_hip_p<policy>.so holding only the policy-dependent translation units (FPS, ball query / grouping, nn_distance), built
+    with -DGSPN_DIST_POLICY=<policy> into its own object directory -- test infrastructure for tests/test_gpu_policy.py; the product
+    library is never touched by it."""
     os.makedirs(LIBDIR, exist_ok=True)
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     hdrs = sorted(glob.glob(os.path.join(CSRC, "*.h"))) + sorted(glob.glob(os.path.join(HERE, "..", "include", "*.h")))
     flags = list(FLAGS) + os.environ.get("GSPN_EXTRA_HIPCC_FLAGS", "").split()
+    obj_dir, lib_path = OBJ, LIB
     if policy is not None:
         flags.append("-DGSPN_DIST_POLICY=%d" % policy)
+        obj_dir, lib_path = os.path.join(OBJ, "p%d" % policy), policy_lib_path(policy)
+        srcs = [s for s in srcs if os.path.basename(s) in POLICY_SOURCES]
+    os.makedirs(obj_dir, exist_ok=True)
     hipcc = _hipcc()
     jobs = []
     objs = []
     for s in srcs:
-        o = os.path.join(OBJ, os.path.basename(s)[:-4] + ".o")
+        o = os.path.join(obj_dir, os.path.basename(s)[:-4] + ".o")
         objs.append(o)
         if force or _newer(o, [s] + hdrs):
             jobs.append([hipcc] + flags + ["-c", s, "-o", o])
@@ -64,9 +79,9 @@ def build(force=False, verbose=False, policy=None):
 
     with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
-    if force or jobs or _newer(LIB, objs):
-        run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs)
-    return LIB
+    if force or jobs or _newer(lib_path, objs):
+        run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib_path] + objs)
+    return lib_path
 
 
 if __name__ == "__main__":

@@ -9,6 +9,23 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 #define NEG_ONE_BITS ((int)0xBF800000)
 
+// dist2_cuda (common.h) on two points at once: the same contraction policy, spelled with element-wise fused multiply-adds
+// (v_pk_fma_f32 / v_pk_mul_f32).  EVERY squared distance of the FPS kernels goes through this or through dist2_cuda, so
+// -DGSPN_DIST_POLICY=0/1/2 is the whole change (tests/test_gpu_policy.py builds all three and compares with the oracle built alike).
+__device__ __forceinline__ v2f dist2_cuda_v2(v2f a, v2f b, v2f c) {
+#if GSPN_DIST_POLICY == 2
+    v2f d = b * b;
+    d = __builtin_elementwise_fma(a, a, d);
+    return __builtin_elementwise_fma(c, c, d);
+#elif GSPN_DIST_POLICY == 1
+    v2f d = a * a;
+    d = __builtin_elementwise_fma(b, b, d);
+    return __builtin_elementwise_fma(c, c, d);
+#else
+    return (a * a + b * b) + c * c;
+#endif
+}
+
 template <int P>
 struct FpsGroup {
     static constexpr int G = (P >= 8) ? 8 : P;   // points per resolve group

@@ -32,6 +32,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ int c_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
+// THE ReLU mask of a batch-normalised element, the forward's own expression: relu(y*scale + shift) is open iff the two-rounding value
+// round(round(y*scale) + shift) is positive (-ffp-contract=off: no fused form).  Every backward kernel forms its mask with this, so the
+// BN reductions (r0, r1), the coefficients and dY are built from the same set of live elements as the forward's activations.
+// (round(t + shift) > 0  <=>  t > -shift exactly: a multiply and a compare, the cost of the fused form.)
+__device__ __forceinline__ bool relu_open(float y, float sc, float sh) { return y * sc > -sh; }
 __device__ __forceinline__ float act1(float v, bool act, float sc, float sh) {
     if (act) { v = v * sc + sh; v = v > 0.f ? v : 0.f; }     // relu(x*scale+shift): two roundings, like tf.nn.batch_normalization
     return v;
@@ -745,6 +750,7 @@ static inline int pick_bn(long rows, int cols, const char* env) {
 // number of row-blocks (= partial-statistics rows) the forward launch of a (rows, cout) layer uses
 // (workgroups per CU = what the kernel's LDS footprint lets reside at once: a persistent grid larger than that runs a second wave)
 static inline int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+static inline int bwd_bpc_narrow() { static const int v = env_int("GSPN_BWD_BPC", 4); return v < 1 ? 1 : v; }
 static inline unsigned fwd_blocks(long rows, int cout) { return row_grid(rows, cout <= 64 ? 1 : (cout + 127) / 128, cout <= 64 ? 4 : env_int("GSPN_FWD_WIDE_BPC", 3)); }
 extern "C" long gspn_mlp_fwd_stats_bytes(long rows, int cout) {
     if (rows < 0 || cout <= 0) return GSPN_ERR_ARG;
@@ -1454,7 +1460,7 @@ __global__ __launch_bounds__(256, ((WgradSplit<MT, NTT>::AM * WgradSplit<MT, NTT
                             if (gl == gl_rt) dz = p_arg[y][gl] == off_cur + r - gl * gs ? p_dp[y][gl] : 0.f;
                     }
                     if (TAIL) dz = r < live ? dz : 0.f;
-                    dyh[y] = __builtin_fmaf(yv, bsc[y], bsh[y]) > 0.f ? dz : 0.f;
+                    dyh[y] = relu_open(yv, bsc[y], bsh[y]) ? dz : 0.f;
                     xh[y] = __builtin_fmaf(yv, brs[y], bmr[y]);              // (y - mean) * rstd   [KNOWN: cB*y + cC]
                     if constexpr (KNOWN) {
                         dyh[y] = __builtin_fmaf(kca[y], dyh[y], xh[y]);      // dY (rows past the end are killed through av = 0)
@@ -2038,7 +2044,7 @@ __global__ __launch_bounds__(256) void pool_rsum_kernel(long groups, int ns, int
         for (long g = g0 + sub; g < g1; g += nsub) {
             const float dp = dPool[g * c + col];
             const float yv = ldy ? Y[(g * ns + arg[g * c + col]) * ldy + col] : Y[g * c + col];     // ldy == 0: Y is (groups, c), y at the arg row
-            const float dyh = __builtin_fmaf(yv, sc, sh) > 0.f ? dp : 0.f;
+            const float dyh = relu_open(yv, sc, sh) ? dp : 0.f;
             r0 += dyh;
             r1 = __builtin_fmaf(dyh, __builtin_fmaf(yv, rs, mr), r1);
         }
@@ -2055,7 +2061,10 @@ __global__ __launch_bounds__(256) void pool_rsum_kernel(long groups, int ns, int
 // floats of a partial-sum buffer [nparts][2][c] large enough for gspn_pool_rsum and for pass B's epilogue (one row per workgroup)
 extern "C" long gspn_rsum_part_floats(long rows, int c) {
     if (c <= 0) return GSPN_ERR_ARG;
-    long n = row_grid(rows > 0 ? rows : 1, 1, 4);
+    // pass B writes one partial row per workgroup of row_grid(rows, yt, bpc), bpc = bwd_bpc_narrow() (or 2 for 128-column tiles): size the
+    // buffer from the same value, so the GSPN_BWD_BPC tuning hook cannot push the epilogue past it
+    const int bpc = bwd_bpc_narrow() > 4 ? bwd_bpc_narrow() : 4;
+    long n = row_grid(rows > 0 ? rows : 1, 1, bpc);
     if (n < RSUM_POOL_BLOCKS) n = RSUM_POOL_BLOCKS;
     return n * 2 * c;
 }
@@ -2128,25 +2137,34 @@ extern "C" int gspn_mlp_bwd_wgrad_known(long rows, int cin, int cout, const gspn
 // from the (b, n, c) feature tensor through the LDS-DMA's per-lane addresses (GatherSrc).
 // ============================================================================================
 __global__ void sa_rel_kernel(long total, int n, int m, int ns, const float* __restrict__ xyz, const float* __restrict__ new_xyz,
-                              const int* __restrict__ idx, float* __restrict__ rel, int* __restrict__ gidx) {
+                              const float* __restrict__ shift, const int* __restrict__ idx, float* __restrict__ rel, int* __restrict__ gidx) {
     for (long r = blockIdx.x * (long)blockDim.x + threadIdx.x; r < total; r += (long)gridDim.x * blockDim.x) {
         const long q = r / ns;                       // (scene, query)
         const int scene = (int)(q / m);
         const int src = scene * n + idx[r];
         const float* p = xyz + (size_t)src * 3;
         const float* c = new_xyz + (size_t)q * 3;
-        *reinterpret_cast<float4*>(rel + r * 4) = make_float4(p[0] - c[0], p[1] - c[1], p[2] - c[2], 0.f);     // :41-42
+        float dx = p[0] - c[0], dy = p[1] - c[1], dz = p[2] - c[2];                                          // :41-42
+        if (shift) {                                 // model_rpointnet.py:56-57: grouped_xyz -= tile(shift_pred) -- a second fp32 subtraction
+            const float* s = shift + (size_t)q * 3;
+            dx -= s[0]; dy -= s[1]; dz -= s[2];
+        }
+        *reinterpret_cast<float4*>(rel + r * 4) = make_float4(dx, dy, dz, 0.f);
         gidx[r] = src;
     }
 }
-extern "C" int gspn_sa_rel(int b, int n, int m, int ns, const float* xyz, const float* new_xyz, const int* idx, float* rel, int* gidx, void* stream) {
+extern "C" int gspn_sa_rel_shift(int b, int n, int m, int ns, const float* xyz, const float* new_xyz, const float* shift, const int* idx,
+                                 float* rel, int* gidx, void* stream) {
     if (b < 0 || n <= 0 || m < 0 || ns <= 0) return GSPN_ERR_ARG;
     const long total = (long)b * m * ns;
     if (total == 0) return 0;
     if (!xyz || !new_xyz || !idx || !rel || !gidx || ((uintptr_t)rel % 16)) return GSPN_ERR_ARG;
     if ((long)b * n >= (1L << 31)) return GSPN_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(sa_rel_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, total, n, m, ns, xyz, new_xyz, idx, rel, gidx);
+    hipLaunchKernelGGL(sa_rel_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, total, n, m, ns, xyz, new_xyz, shift, idx, rel, gidx);
     return gspn_launch_status();
+}
+extern "C" int gspn_sa_rel(int b, int n, int m, int ns, const float* xyz, const float* new_xyz, const int* idx, float* rel, int* gidx, void* stream) {
+    return gspn_sa_rel_shift(b, n, m, ns, xyz, new_xyz, nullptr, idx, rel, gidx, stream);
 }
 static int gather_src(const gspn_gather_args* g, GatherSrc* out) {
     if (!g || !g->feat || !g->gidx || !g->rel || g->c <= 0 || g->ldf < g->c || (g->ldf & 3)) return GSPN_ERR_ARG;
@@ -2557,7 +2575,7 @@ void mlp_bwd_data_kernel(long rows, int cin, int cout, gspn_dy_args a, const flo
 #pragma unroll
                             for (int r = 0; r < 16; ++r) {
                                 const bool live = full || (m0 + wave * 32 + c_row(r, lane)) < rows;
-                                const float dyh = (live && __builtin_fmaf(yv[r], p_sc[nt], p_sh[nt]) > 0.f) ? acc[nt][r] : 0.f;
+                                const float dyh = (live && relu_open(yv[r], p_sc[nt], p_sh[nt])) ? acc[nt][r] : 0.f;
                                 r0s[nt] += dyh;
                                 r1s[nt] = __builtin_fmaf(dyh, __builtin_fmaf(yv[r], p_rs[nt], p_mr[nt]), r1s[nt]);
                             }
@@ -2624,7 +2642,7 @@ static int bwd_data_launch(long rows, int cin, int cout, const gspn_dy_args* a, 
     // workgroups per CU the grid is sized for.  3 reside (waves per SIMD: the amdgpu_waves_per_eu attribute of the kernel keeps the 32- and
     // 64-column tiles under 168 VGPRs; 2 for 128), yet 4 measures best (pass B of the bench step: 648 / 596 / 581 us at 2 / 3 / 4):
     // the fourth quarter of the workgroups fills the slots the first finishers free.  GSPN_BWD_BPC overrides (tuning hook).
-    static const int bpc_narrow = env_int("GSPN_BWD_BPC", 4);
+    const int bpc_narrow = bwd_bpc_narrow();
 #define BD_GO(BN_, V_, P_, YT_)                                                                                                       \
     do {                                                                                                                               \
         const unsigned rg = row_grid(rows, YT_, BN_ >= 128 ? 2 : bpc_narrow);                                                          \

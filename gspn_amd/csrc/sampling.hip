@@ -110,9 +110,7 @@ __global__ __launch_bounds__(FPS_T) void fps_resident_kernel(int n, int m, const
                     zz = z[pp];
                 }
                 const v2f dx = x[pp] - cx, dy = y[pp] - cy, dz = zz - cz;
-                v2f d = dy * dy;                                   // dist2_cuda, GSPN_DIST_POLICY 2, :142
-                d = __builtin_elementwise_fma(dx, dx, d);
-                d = __builtin_elementwise_fma(dz, dz, d);
+                const v2f d = dist2_cuda_v2(dx, dy, dz);                                   // contraction policy: fps_common.h, :142
                 td[pp][0] = vmin_f32(d[0], td[pp][0]);             // :143
                 td[pp][1] = vmin_f32(d[1], td[pp][1]);
                 gm = vmax3_i32(gm, __float_as_int(td[pp][0]), __float_as_int(td[pp][1]));
@@ -350,9 +348,7 @@ __global__ __launch_bounds__(FPS_T) void fps_cell_kernel(int n, int m, int csz, 
                         const int pp = qd * 2 + h;
                         const v2f zz = h == 0 ? zq.xy : zq.zw;
                         const v2f dx = x[pp] - cx, dy = y[pp] - cy, dz = zz - cz;
-                        v2f d = dy * dy;                                   // dist2_cuda, GSPN_DIST_POLICY 2
-                        d = __builtin_elementwise_fma(dx, dx, d);
-                        d = __builtin_elementwise_fma(dz, dz, d);
+                        const v2f d = dist2_cuda_v2(dx, dy, dz);                                   // contraction policy: fps_common.h
                         td[pp][0] = vmin_f32(d[0], td[pp][0]);
                         td[pp][1] = vmin_f32(d[1], td[pp][1]);
                     }
@@ -363,9 +359,7 @@ __global__ __launch_bounds__(FPS_T) void fps_cell_kernel(int n, int m, int csz, 
 #pragma unroll
                 for (int pp = 0; pp < P / 2; ++pp) {
                     const v2f dx = x[pp] - cx, dy = y[pp] - cy, dz = z[pp] - cz;
-                    v2f d = dy * dy;                                       // dist2_cuda, GSPN_DIST_POLICY 2
-                    d = __builtin_elementwise_fma(dx, dx, d);
-                    d = __builtin_elementwise_fma(dz, dz, d);
+                    const v2f d = dist2_cuda_v2(dx, dy, dz);                                       // contraction policy: fps_common.h
                     td[pp][0] = vmin_f32(d[0], td[pp][0]);
                     td[pp][1] = vmin_f32(d[1], td[pp][1]);
                 }
@@ -1066,7 +1060,7 @@ extern "C" int gspn_probsample(int b, int n, int m, const float* inp_p, const fl
 }
 
 extern "C" int gspn_dist_policy(void) { return GSPN_DIST_POLICY; }
-extern "C" int gspn_abi_version(void) { return 1; }
+extern "C" int gspn_abi_version(void) { return GSPN_ABI_VERSION; }
 extern "C" int gspn_fill_zero(void* ptr, long bytes, void* stream) {
     if (bytes < 0) return GSPN_ERR_ARG;
     if (bytes == 0) return 0;

@@ -171,9 +171,7 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(int b, int n, int m, i
                         const int pp = qd * 2 + h;
                         const v2f zz = h == 0 ? zq.xy : zq.zw;
                         const v2f dx = x[pp] - cx, dy = y[pp] - cy, dz = zz - cz;
-                        v2f d = dy * dy;                                   // dist2_cuda, GSPN_DIST_POLICY 2 (tf_sampling_g.cu:142)
-                        d = __builtin_elementwise_fma(dx, dx, d);
-                        d = __builtin_elementwise_fma(dz, dz, d);
+                        const v2f d = dist2_cuda_v2(dx, dy, dz);                                   // contraction policy: fps_common.h (tf_sampling_g.cu:142)
                         td[pp][0] = vmin_f32(d[0], td[pp][0]);             // :143
                         td[pp][1] = vmin_f32(d[1], td[pp][1]);
                     }
@@ -184,9 +182,7 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(int b, int n, int m, i
 #pragma unroll
                 for (int pp = 0; pp < P / 2; ++pp) {
                     const v2f dx = x[pp] - cx, dy = y[pp] - cy, dz = z[pp] - cz;
-                    v2f d = dy * dy;
-                    d = __builtin_elementwise_fma(dx, dx, d);
-                    d = __builtin_elementwise_fma(dz, dz, d);
+                    const v2f d = dist2_cuda_v2(dx, dy, dz);
                     td[pp][0] = vmin_f32(d[0], td[pp][0]);
                     td[pp][1] = vmin_f32(d[1], td[pp][1]);
                 }
@@ -453,9 +449,12 @@ static int launch_fps_multi(int b, int n, int m, int csz, int G, const float* sx
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     const int A = min(FPSM_AMAX, FPSM_RMAX / G);
-    // scene groups: at most FPS_MULTI_MAX_WG co-resident workgroups per launch, whole multiples of 8 scenes (one per XCD)
-    int per = (FPS_MULTI_MAX_WG / G) & ~7;
-    if (per < 8) per = 8;
+    // scene groups: at most FPS_MULTI_MAX_WG co-resident workgroups per launch; whole multiples of 8 scenes (one per XCD) while that
+    // fits, fewer than 8 scenes per launch beyond G = 16 (the blocks of the absent scenes' residue classes exit at once, so
+    // bs * G <= FPS_MULTI_MAX_WG workgroups stay resident -- never 8 * G = up to every CU of the chip)
+    int per = FPS_MULTI_MAX_WG / G;
+    if (per >= 8) per &= ~7;
+    if (per < 1) per = 1;
     for (int s0 = 0; s0 < b; s0 += per) {
         const int bs = min(per, b - s0);
         const int grid = ((bs + 7) / 8) * G * 8;
@@ -519,6 +518,10 @@ extern "C" int gspn_fps_multi_sample(int b, int n, int m, int G, const float* in
     // every polled word is zeroed before every launch (tags of an earlier call must not look like this call's epochs)
     hipError_t e = hipMemsetAsync(xch, 0, (size_t)b * FPSM_XCH_GRANULES * 8 + 64, st);
     if (e != hipSuccess) return (int)e;
+    // a bounded wait that expires leaves the status word at 1 and `out` partly written: zero it first, so that even then every entry
+    // is a VALID index (point 0) and a caller that gathers before looking at the status word cannot read out of bounds
+    e = hipMemsetAsync(out, 0, (size_t)b * m * sizeof(int), st);
+    if (e != hipSuccess) return (int)e;
     const int ncell = G * FPS_W;
     const int csz = (n + ncell - 1) / ncell;
     if (csz <= 64 * 2) return launch_fps_multi<2, false>(b, n, m, csz, G, sxyz, perm, inp, n * 3, out, xch, status, st);
@@ -534,6 +537,13 @@ extern "C" int gspn_farthestpointsampling_multi(int b, int n, int m, int G, cons
     const int rc = gspn_fps_multi_prepass(b, n, G, inp, ws, stream);
     if (rc) return rc;
     return gspn_fps_multi_sample(b, n, m, G, inp, ws, out, stream);
+}
+
+// device address of the status word inside a workspace (for a caller that copies it asynchronously and checks it at its own next
+// synchronisation point: gspn_amd/tf_sampling.py)
+extern "C" long gspn_fps_multi_status_offset(int b, int n) {
+    if (b <= 0 || n <= 0) return GSPN_ERR_ARG;
+    return (long)b * n * 16 + (long)b * FPSM_XCH_GRANULES * 8;
 }
 
 // status word of a workspace the sampling kernel has finished with: 0 = ok, 1 = a bounded wait expired (output invalid).

@@ -65,15 +65,21 @@ class FPGeometry:
         return [t for t in (self.idx, self.weight, self.order, self.offsets) if t is not None]
 
 
-def sa_front(xyz, new_xyz, idx):
+def sa_front(xyz, new_xyz, idx, shift=None):
     """pointnet_util.py:41-42 reduced to what depends on coordinates only: rel[r] = (xyz[idx[r]] - centre, 0) and the source row
-    gidx[r] of every grouped row r -- the inputs of the fused front end (gspn_mlp_fwd_gather), 20 bytes per grouped row."""
+    gidx[r] of every grouped row r -- the inputs of the fused front end (gspn_mlp_fwd_gather), 20 bytes per grouped row.
+    shift (b, npoint, 3), optional: multi_encoding_net's per-seed shift (model_rpointnet.py:56-57), subtracted after the centre."""
     b, n, _ = xyz.shape
     _, m, ns = idx.shape
     rel = torch.empty((b * m * ns, 4), dtype=torch.float32, device=xyz.device)
     gidx = torch.empty((b * m * ns,), dtype=torch.int32, device=xyz.device)
+    if shift is not None:
+        shift = L.need(shift.detach(), torch.float32, 3, "shift_pred")
+        if tuple(shift.shape) != (b, m, 3):
+            raise ValueError("shift_pred must be (batch, npoint, 3)")
     with torch.cuda.device(xyz.device):
-        L.check(L.lib().gspn_sa_rel(b, n, m, ns, L.ptr(xyz), L.ptr(new_xyz), L.ptr(idx), L.ptr(rel), L.ptr(gidx), L.stream()), "sa_rel")
+        L.check(L.lib().gspn_sa_rel_shift(b, n, m, ns, L.ptr(xyz), L.ptr(new_xyz), L.ptr(shift), L.ptr(idx), L.ptr(rel), L.ptr(gidx), L.stream()),
+                "sa_rel")
     return rel, gidx
 
 
@@ -123,6 +129,8 @@ class PendingGeometry:
                 cur.wait_event(self._event)
             for t in _tensors_of(self._value):
                 t.record_stream(cur)
+            if host_wait:
+                L.check_async()                  # the geometry is complete: so is the status word of a multi-CU FPS launch inside it
         return self._value
 
 

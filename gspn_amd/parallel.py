@@ -9,16 +9,26 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None):
-    """One process per GPU, launched by torch.distributed.run: RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* from the env."""
+def init_from_env(backend=None, force=False):
+    """One process per GPU, launched by torch.distributed.run: RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* from the env.
+    force=True initialises the process group even at world size 1 (a one-rank RCCL communicator: the collective path -- communicator
+    set-up, the all-reduce launch, its ordering against the captured step and the side streams -- then runs on a single GPU)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if torch.cuda.is_available():
         torch.cuda.set_device(local)
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend=backend or ("nccl" if torch.cuda.is_available() else "gloo"), rank=rank, world_size=world)
+        if "MASTER_PORT" not in os.environ:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        kw = {}
+        if torch.cuda.is_available() and (backend or "nccl") == "nccl":
+            kw["device_id"] = torch.device("cuda", local)      # bind the communicator to this rank's GPU at init (no lazy device guess)
+        dist.init_process_group(backend=backend or ("nccl" if torch.cuda.is_available() else "gloo"), rank=rank, world_size=world, **kw)
     return rank, local, world
 
 
@@ -117,12 +127,14 @@ class FlatGradBucket:
             p.grad = v
         return self.flat
 
-    def all_reduce(self, average=True):
+    def all_reduce(self, average=True, force=False):
         """SUM all-reduce of the bucket over the ranks; average=False leaves the sum (FlatAdam.step(grad_scale=1/world) folds the division
-        into the update)."""
-        if dist.is_initialized() and dist.get_world_size() > 1:
+        into the update).  At world size 1 there is nothing to reduce and no collective is issued -- unless force=True (and a process
+        group exists): the call then really goes through RCCL on the one-rank communicator (identity result, bit for bit), which is
+        how the collective path is exercised on a single GPU (tests/test_gpu_collective.py, bench.py --force-collective)."""
+        if dist.is_initialized() and (dist.get_world_size() > 1 or force):
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-            if average:
+            if average and dist.get_world_size() > 1:
                 self.flat.div_(dist.get_world_size())
         return self.flat
 

@@ -30,20 +30,27 @@ def multi_encoding_net(xyz, points, npoint, radius_list, nsample_list, mlp_list,
             radius, nsample = radius_list[i], nsample_list[i]
             idx, pts_cnt = query_ball_point(radius, nsample, xyz, new_xyz)      # :53
             pooled = None
-            if shift_pred is None and (points is None or use_xyz) and not xyz.requires_grad:
+            # a shift without a gradient (the reference's own call, :377: shift_pred=tf.stop_gradient(shift_pred_seed)) is a constant of
+            # the grouping like the centres; one that carries a gradient takes the reference's composition below
+            shift_const = shift_pred is None or not shift_pred.requires_grad
+            if shift_const and (points is None or use_xyz) and not xyz.requires_grad and (shift_pred is None or points is not None):
                 c = 0 if points is None else points.shape[2]
                 cin = c + 3
                 if PU.FUSE_SA_FRONT and points is not None and len(mlp_list[i]) >= 2:
                     # fused front end (features FIRST here, :61): the grouped tensor is never written, the first conv gathers its rows
-                    rel, gidx = sa_front(xyz.detach(), new_xyz.detach(), idx)
+                    rel, gidx = sa_front(xyz.detach(), new_xyz.detach(), idx, shift_pred)
                     geo = SAGeometry(new_xyz, idx, pts_cnt, npoint, nsample, None, None, rel, gidx)
                     layers = _mlp_layers(mlp_list[i], cin, 'conv_prev_%d_' % i, bn)
                     pooled = PU._sa_stack_gathered(points, geo, False, cin, layers, is_training, bn_decay, nsample)
-                if pooled is None:
+                if pooled is None and shift_pred is None:
                     # fused: concat([points[idx], xyz[idx] - new_xyz]) written straight into the MLP's input matrix (:54-63)
                     rows = group_concat(xyz, new_xyz, points, idx, xyz_first=False)
                     gcols = (0, c) if c > 0 else None                           # the xyz columns carry no gradient
+                elif pooled is None:
+                    rows = None                                                 # (a shape the gathering kernels do not take: composition below)
             else:
+                rows = None
+            if pooled is None and rows is None:
                 grouped_xyz = group_point(xyz, idx) - new_xyz.unsqueeze(2)      # :54-55
                 if shift_pred is not None:
                     grouped_xyz = grouped_xyz - shift_pred.unsqueeze(2)         # :56-57 (keeps the gradient to shift_pred)

@@ -21,6 +21,9 @@ FPS_CELLS_MIN_N = int(os.environ.get("GSPN_FPS_CELLS_MIN_N", "8192"))
 # workgroups (CUs) per scene for n > 32768 (0 = the library's choice); any n goes multi-CU when FPS_MULTI_FORCE is set (tests)
 FPS_MULTI_G = int(os.environ.get("GSPN_FPS_MULTI_G", "0"))
 FPS_MULTI_FORCE = False
+# check the multi-CU kernel's status word synchronously after every launch (costs a stream synchronisation; default: asynchronously,
+# at the next op call / PendingGeometry.get / L.check_async())
+FPS_MULTI_SYNC_CHECK = os.environ.get("GSPN_FPS_MULTI_SYNC_CHECK", "0") == "1"
 
 
 def _spread10(v):
@@ -58,6 +61,7 @@ def farthest_point_sample(npoint, inp, return_order=False):
     npoint = int(npoint)
     if npoint <= 0:
         raise ValueError("FarthestPointSample expects positive npoint")               # tf_sampling.cpp:99
+    L.check_async()                                      # a multi-CU launch of an earlier call that reported a failure raises here
     inp = L.need(inp.detach(), torch.float32, 3, "inp")
     if inp.shape[2] != 3:
         raise ValueError("FarthestPointSample expects (batch_size,num_points,3) inp shape")   # tf_sampling.cpp:105
@@ -83,6 +87,18 @@ def farthest_point_sample(npoint, inp, return_order=False):
             tic()
             L.check(lib.gspn_fps_multi_sample(b, n, npoint, FPS_MULTI_G, L.ptr(inp), L.ptr(ws), L.ptr(out), L.stream()),
                     "farthest_point_sample(multi)")
+            # the kernel's status word (1 = a bounded inter-workgroup wait expired, `out` zero-filled past the failure): copied behind
+            # the kernel into pinned memory and checked at the next synchronisation point (L.check_async) -- or right here when the
+            # caller asked for it.  Not under stream capture (a captured copy would need a persistent host word; FPS is never captured:
+            # it runs on the geometry streams).
+            if not torch.cuda.is_current_stream_capturing():
+                word = ws.view(torch.int32)[int(lib.gspn_fps_multi_status_offset(b, n)) // 4:][:1]
+                host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+                host.copy_(word, non_blocking=True)
+                ev = torch.cuda.current_stream().record_event()
+                L.register_async_status(host, ev, "farthest_point_sample(multi-CU, b=%d, n=%d, m=%d)" % (b, n, npoint))
+                if FPS_MULTI_SYNC_CHECK:
+                    L.check_async(block=True)
         elif FPS_MODE == "cells" and FPS_CELLS_MIN_N <= n:
             ws = torch.empty(int(lib.gspn_fps_cells_ws_bytes(b, n)) // 4, dtype=torch.float32, device=inp.device)
             L.check(lib.gspn_fps_cells_prepass(b, n, L.ptr(inp), L.ptr(ws), L.stream()), "farthest_point_sample(cells pre-pass)")

@@ -186,23 +186,87 @@ def _apply_layer(x2d, cin, lp, activation_fn, is_training, bn_decay):
     raise NotImplementedError("activation_fn must be relu, or None without batch-norm (the cases the set-abstraction path and its heads use)")
 
 
-def batch_norm_for_conv2d(inputs, is_training, bn_decay, scope, data_format='NHWC'):
-    """tf_util.py:568-580 (stand-alone BN over N,H,W): torch ops; the fused path is inside conv2d."""
+class _BatchNormRows(torch.autograd.Function):
+    """tf.contrib.layers.batch_norm(center=True, scale=True, decay, updates_collections=None) over the rows of a (rows, c) matrix
+    (tf_util.py:529-534) on the HIP kernels of csrc/batchnorm.hip + the finalize / coefficient kernels of the shared-MLP path:
+    statistics from per-workgroup partial sums added in double, biased variance, eps 1e-3, y = x*inv + (beta - mean*inv),
+    moving = moving*decay + batch*(1-decay) updated in place."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, mm, mv, is_training, decay):
+        import ctypes
+        from .mlp import BN_EPS
+        lib = L.lib()
+        rows, c = x.shape
+        dev = x.device
+        mean, var, scale, shift = (torch.empty(c, dtype=torch.float32, device=dev) for _ in range(4))
+        out = torch.empty_like(x)
+        with torch.cuda.device(dev):
+            st = L.stream()
+            part, npart = None, ctypes.c_int(0)
+            if is_training:
+                part = torch.empty(int(lib.gspn_bn_colsum_part_floats(rows, c)), dtype=torch.float32, device=dev)
+                L.check(lib.gspn_bn_colsum(rows, c, L.ptr(x), c, None, 0, None, None, BN_EPS, L.ptr(part), ctypes.byref(npart), st), "bn_colsum")
+            L.check(lib.gspn_bn_finalize_parts(rows, c, L.ptr(part), npart.value, L.ptr(gamma), L.ptr(beta), BN_EPS, float(decay), int(is_training),
+                                               L.ptr(mm), L.ptr(mv), L.ptr(mean), L.ptr(var), L.ptr(scale), L.ptr(shift), st), "bn_finalize")
+            L.check(lib.gspn_bn_apply(rows, c, L.ptr(x), c, L.ptr(scale), L.ptr(shift), 0, L.ptr(out), c, st), "bn_apply")
+        ctx.save_for_backward(x, gamma, mean, var, scale)
+        ctx.is_training = bool(is_training)
+        return out
+
+    @staticmethod
+    def backward(ctx, dz):
+        import ctypes
+        from .mlp import BN_EPS
+        lib = L.lib()
+        x, gamma, mean, var, scale = ctx.saved_tensors
+        rows, c = x.shape
+        dev = x.device
+        dz = dz.contiguous()
+        cA, cB, cC, dgamma, dbeta, dbias = (torch.empty(c, dtype=torch.float32, device=dev) for _ in range(6))
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        with torch.cuda.device(dev):
+            st = L.stream()
+            part = torch.empty(int(lib.gspn_bn_colsum_part_floats(rows, c)), dtype=torch.float32, device=dev)
+            npart = ctypes.c_int(0)
+            L.check(lib.gspn_bn_colsum(rows, c, L.ptr(x), c, L.ptr(dz), c, L.ptr(mean), L.ptr(var), BN_EPS, L.ptr(part), ctypes.byref(npart), st), "bn_colsum")
+            # (sum dz, sum dz*xhat) -> dbeta, dgamma and, in training mode, the three coefficients of dx = cA*dz + cB*x + cC
+            L.check(lib.gspn_mlp_bwd_coef(rows, c, npart.value, L.ptr(part), L.ptr(mean), L.ptr(var), L.ptr(gamma), BN_EPS,
+                                          L.ptr(cA), L.ptr(cB), L.ptr(cC), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dbias), st), "bn_coef")
+            if dx is not None:
+                if not ctx.is_training:                  # moving statistics are constants: dx = dz * inv
+                    cA, cB, cC = scale, torch.zeros_like(scale), torch.zeros_like(scale)
+                L.check(lib.gspn_bn_backward_apply(rows, c, L.ptr(dz), c, L.ptr(x), c, L.ptr(cA), L.ptr(cB), L.ptr(cC), L.ptr(dx), c, st), "bn_backward_apply")
+        return dx, dgamma, dbeta, None, None, None, None
+
+
+def batch_norm_template(inputs, is_training, scope, moments_dims_unused, bn_decay, data_format='NHWC'):
+    """tf_util.py:515-534: batch normalisation over every axis but the last (BC, BLC, BHWC ...), variables beta / gamma /
+    moving_mean / moving_variance under `scope`, decay 0.9 when bn_decay is None.  Runs on the HIP kernels (_BatchNormRows)."""
+    if data_format != 'NHWC':
+        raise NotImplementedError("gspn_amd.tf_util batch norm: NHWC (channels last) only, like every call on the set-abstraction path")
+    inputs = L.need(inputs, torch.float32, None, "inputs")
     c = inputs.shape[-1]
     with variable_scope(scope):
         beta, gamma, mm, mv = _bn_variables(c)
     decay = 0.9 if bn_decay is None else float(bn_decay)
-    x = inputs.reshape(-1, c)
-    if is_training:
-        mean = x.mean(0)
-        var = x.var(0, unbiased=False)
-        with torch.no_grad():
-            mm.mul_(decay).add_(mean.detach() * (1 - decay))
-            mv.mul_(decay).add_(var.detach() * (1 - decay))
-    else:
-        mean, var = mm, mv
-    inv = torch.rsqrt(var + 1e-3) * gamma
-    return (x * inv + (beta - mean * inv)).view_as(inputs)
+    out = _BatchNormRows.apply(inputs.reshape(-1, c), gamma, beta, mm, mv, bool(is_training), decay)
+    return out.view(inputs.shape)
+
+
+def batch_norm_for_fc(inputs, is_training, bn_decay, scope):
+    """tf_util.py:537-548"""
+    return batch_norm_template(inputs, is_training, scope, [0, ], bn_decay)
+
+
+def batch_norm_for_conv1d(inputs, is_training, bn_decay, scope, data_format='NHWC'):
+    """tf_util.py:551-563"""
+    return batch_norm_template(inputs, is_training, scope, [0, 1], bn_decay, data_format)
+
+
+def batch_norm_for_conv2d(inputs, is_training, bn_decay, scope, data_format='NHWC'):
+    """tf_util.py:568-580 (stand-alone BN over N,H,W; inside conv2d the same arithmetic rides in the MLP kernels)."""
+    return batch_norm_template(inputs, is_training, scope, [0, 1, 2], bn_decay, data_format)
 
 
 def max_pool2d(inputs, kernel_size, scope, stride=[2, 2], padding='VALID'):

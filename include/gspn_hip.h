@@ -28,7 +28,12 @@ extern "C" {
 #define GSPN_ERR_ARG (-1)
 #define GSPN_ERR_UNSUPPORTED (-2)
 
-/* Build facts: squared-distance contraction policy (see oracle/gspn_oracle.c header) and ABI rev. */
+/* Build facts: squared-distance contraction policy (see oracle/gspn_oracle.c header) and ABI rev.
+ * GSPN_ABI_VERSION is bumped whenever an entry point is added, removed or changes its argument list or workspace layout; a binder
+ * compares it with gspn_abi_version() of the library it loaded (gspn_amd/_lib.py raises on a mismatch: a stale .so fails loudly).
+ *   1: round 1.   2: round 2 (gspn_fps_background removed, ~30 entry points added, finalize / workspace layouts changed).
+ *   3: round 3 (gspn_sa_rel_shift, gspn_bn_apply, gspn_mlp_gemm_*, gspn_small_geometry, status word of the multi-CU FPS checked). */
+#define GSPN_ABI_VERSION 3
 int gspn_dist_policy(void);
 int gspn_abi_version(void);
 
@@ -69,6 +74,12 @@ int gspn_fps_multi_prepass(int b, int n, int G, const float* inp, void* ws, void
 int gspn_fps_multi_sample(int b, int n, int m, int G, const float* inp, void* ws, int* out, void* stream);
 int gspn_farthestpointsampling_multi(int b, int n, int m, int G, const float* inp, void* ws, int* out, void* stream);
 int gspn_fps_multi_status(const void* ws, int b, int n, void* stream);
+/* A launch is capped at 128 co-resident workgroups (fewer than 8 scenes per launch beyond G = 16).  The sampling call zeroes `out`
+ * before it launches, so after an expired wait every entry is still a valid index (0); the status word -- one int32 at byte offset
+ * gspn_fps_multi_status_offset(b, n) of ws -- is then 1.  A caller MUST look at it before trusting `out`: synchronously with
+ * gspn_fps_multi_status, or by copying the word asynchronously and checking it at its next synchronisation point (what
+ * gspn_amd/tf_sampling.py does: a non-zero word raises GspnHipError there). */
+long gspn_fps_multi_status_offset(int b, int n);
 
 /* gatherpointLauncher(b,n,m,inp,idx,out)  tf_sampling.cpp:125, tf_sampling_g.cu:206-208 */
 int gspn_gatherpoint(int b, int n, int m, const float* inp, const int* idx, float* out, void* stream);
@@ -235,6 +246,21 @@ int gspn_bnrelu_maxpool(long groups, int ns, int c, const float* Y, int ldy, con
 /* out = relu(Y*scale+shift) materialised (last layer of an FP module) */
 int gspn_bnrelu_apply(long rows, int c, const float* Y, int ldy, const float* scale, const float* shift, float* out, int ldo, void* stream);
 
+/* ---- stand-alone batch normalisation over the rows of a (rows, c) matrix (gspn_amd/csrc/batchnorm.hip): the device side of
+ * tf_util.batch_norm_for_fc / _conv1d / _conv2d (utils/tf_util.py:515-580: tf.contrib.layers.batch_norm over all leading axes).
+ *   forward : gspn_bn_colsum(dZ = NULL) -> gspn_bn_finalize_parts -> gspn_bn_apply(relu = 0)
+ *   backward: gspn_bn_colsum(dZ)        -> gspn_mlp_bwd_coef      -> gspn_bn_backward_apply
+ * gspn_bn_colsum leaves *nparts_out partial rows [2][c] in part (gspn_bn_colsum_part_floats(rows, c) floats): column sums of
+ * (x, x^2) when dZ is NULL, of (dz, dz * xhat) with xhat = (x - mean) * rsqrt(var + eps) otherwise. */
+long gspn_bn_colsum_part_floats(long rows, int c);
+int gspn_bn_colsum(long rows, int c, const float* X, int ldx, const float* dZ, int ldz, const float* mean, const float* var, float eps,
+                   float* part, int* nparts_out, void* stream);
+/* out = x*scale + shift (two roundings: tf.nn.batch_normalization, tf_util.py:511), through a ReLU when relu != 0 */
+int gspn_bn_apply(long rows, int c, const float* X, int ldx, const float* scale, const float* shift, int relu, float* out, int ldo, void* stream);
+/* dX = cA*dZ + cB*X + cC per column (training mode: the coefficients of gspn_mlp_bwd_coef; inference: cA = scale, cB = cC = 0) */
+int gspn_bn_backward_apply(long rows, int c, const float* dZ, int ldz, const float* X, int ldx, const float* cA, const float* cB, const float* cC,
+                           float* dX, int lddx, void* stream);
+
 /* ---- backward of one layer -------------------------------------------------------------
  * With z = relu(s*y+t) and upstream gradient dz (dense, or the scatter of a pooled gradient to its
  * arg-max rows), the gradient w.r.t. the pre-BN output is
@@ -371,6 +397,10 @@ typedef struct gspn_gather_args {
     int xyz_first;
 } gspn_gather_args;
 int gspn_sa_rel(int b, int n, int m, int ns, const float* xyz, const float* new_xyz, const int* idx, float* rel, int* gidx, void* stream);
+/* the same with the per-seed shift of multi_encoding_net (model_rpointnet.py:56-57, called with a stop_gradient shift at :377):
+ * rel[r] = ((xyz[i, idx[r]] - new_xyz[i, j]) - shift[i, j], 0); shift (b, m, 3) or NULL (= gspn_sa_rel) */
+int gspn_sa_rel_shift(int b, int n, int m, int ns, const float* xyz, const float* new_xyz, const float* shift, const int* idx,
+                      float* rel, int* gidx, void* stream);
 int gspn_mlp_gather_cin(const gspn_gather_args* g);
 int gspn_mlp_fwd_gather(long rows, const gspn_gather_args* g, int cout, const float* W, const float* bias, float* Y, int ldy,
                         float* stats, void* stream);

@@ -36,6 +36,32 @@ def lib():
     return _LIB
 
 
+class use_policy:
+    """context manager: the oracle built with GSPN_DIST_POLICY = policy (0 unfused, 1 fma(c,c,fma(b,b,a*a)), 2 = the default)
+    behind every function of this module -- tests/test_gpu_policy.py"""
+
+    def __init__(self, policy):
+        self.policy = int(policy)
+
+    def __enter__(self):
+        global _LIB
+        self.prev = _LIB
+        if self.policy != 2:
+            so = os.path.join(_HERE, "libgspn_oracle_p%d.so" % self.policy)
+            if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(os.path.join(_HERE, "gspn_oracle.c")):
+                subprocess.check_call(["make", "-C", _HERE, "policies"], stdout=subprocess.DEVNULL)
+            _LIB = ctypes.CDLL(so)
+        else:
+            _LIB = None
+            lib()
+        assert _LIB.oracle_dist_policy() == self.policy
+        return self
+
+    def __exit__(self, *a):
+        global _LIB
+        _LIB = self.prev
+
+
 def ref_lib():
     """oracle/_ref/libinterp_ref.so, compiled from the reference's interpolate.cpp (or None)."""
     global _REF

@@ -19,7 +19,6 @@ def cloud_d(n, seed, frac=0.1):
 def cloud_s(n, seed):
     """points on the faces of an 8x6x3 m room plus 20 random boxes"""
     rng = np.random.default_rng(seed)
-    pts = np.empty((n, 3), np.float32)
     ext = np.array([8.0, 6.0, 3.0], np.float32)
     boxes = [(np.zeros(3, np.float32), ext)]
     for _ in range(20):
@@ -29,12 +28,12 @@ def cloud_s(n, seed):
     which = rng.integers(0, len(boxes), size=n)
     face = rng.integers(0, 6, size=n)
     uv = rng.random((n, 3), dtype=np.float32)
-    for i in range(n):
-        lo, sz = boxes[which[i]]
-        p = lo + uv[i] * sz
-        ax = face[i] // 2
-        p[ax] = lo[ax] + (sz[ax] if face[i] % 2 else 0.0)
-        pts[i] = p
+    los = np.stack([bx[0] for bx in boxes])[which]          # (n, 3) float32
+    szs = np.stack([bx[1] for bx in boxes])[which]
+    pts = (los + uv * szs).astype(np.float32)
+    ax = face // 2
+    rows = np.arange(n)
+    pts[rows, ax] = los[rows, ax] + np.where(face % 2 == 1, szs[rows, ax], np.float32(0.0)).astype(np.float32)
     return pts
 
 

@@ -118,3 +118,35 @@ def test_gloo_world4_unequal_shards_and_sync_bn():
     mp.spawn(_worker4, args=(world, _free_port(), out), nprocs=world, join=True)
     assert all(out[r][0] for r in range(world)), dict(out)
     assert [(out[r][1], out[r][2]) for r in range(world)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
+
+
+def _worker_forced(rank, world, port, out):
+    """world 1 with force=True: the process group exists and the bucket's all-reduce really calls the backend (identity result)"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    from gspn_amd import parallel
+    r, local, w = parallel.init_from_env(backend="gloo", force=True)
+    calls = []
+    real = dist.all_reduce
+
+    def spy(t, *a, **k):
+        calls.append(1)
+        return real(t, *a, **k)
+    dist.all_reduce = spy
+    p = torch.nn.Parameter(torch.zeros(7))
+    p.grad = torch.arange(7.)
+    bk = parallel.FlatGradBucket([p])
+    bk.flatten()
+    bk.all_reduce(average=False)
+    n_unforced = len(calls)
+    bk.all_reduce(average=False, force=True)
+    bk.all_reduce(average=True, force=True)
+    out[0] = (dist.is_initialized(), w, n_unforced, len(calls), bool(torch.equal(bk.flat, torch.arange(7.))))
+    dist.all_reduce = real
+    dist.destroy_process_group()
+
+
+def test_forced_collective_at_world_1():
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_forced, args=(1, _free_port(), out), nprocs=1, join=True)
+    assert out[0] == (True, 1, 0, 2, True)

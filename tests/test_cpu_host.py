@@ -30,7 +30,8 @@ def test_library_exports_every_declared_symbol():
     bound = set(_lib.SIGNATURES) | set(_lib.SPECIAL)
     assert bound == set(syms), "binding table and header disagree: %s" % (bound ^ set(syms))
     lib = _lib.lib()
-    assert lib.gspn_abi_version() == 1
+    hdr = int(re.search(r"#define GSPN_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "gspn_hip.h")).read()).group(1))
+    assert lib.gspn_abi_version() == hdr == _lib.ABI_VERSION
     assert lib.gspn_dist_policy() == 2        # same contraction policy as the oracle
 
 
@@ -143,3 +144,34 @@ def test_preagg_host_side_rules():
     assert not mlp.preagg_ok([layer(64, bn=False), layer(64)], True, 64)
     assert not mlp.preagg_ok([layer(48), layer(64)], True, 64)
     assert not mlp.preagg_ok([layer(64), layer(64)], True, 3)              # SA level 1: three colour channels, the gathered GEMM is as cheap
+
+
+def test_async_status_words_raise_at_the_next_check():
+    """_lib.check_async: a registered status word whose copy has completed with a non-zero value raises GspnHipError (the multi-CU
+    FPS's expired-wait flag); pending ones are kept, zero ones dropped"""
+    import torch
+    from gspn_amd import _lib
+
+    class Ev:
+        def __init__(self, done):
+            self.done = done
+
+        def query(self):
+            return self.done
+
+        def synchronize(self):
+            self.done = True
+
+    _lib._async_status[:] = []
+    ok, pend, bad = torch.zeros(1, dtype=torch.int32), torch.ones(1, dtype=torch.int32), torch.ones(1, dtype=torch.int32)
+    _lib.register_async_status(ok, Ev(True), "ok")
+    _lib.register_async_status(pend, Ev(False), "pending")
+    _lib.check_async()                                   # nothing completed-and-bad yet
+    assert len(_lib._async_status) == 1
+    _lib.register_async_status(bad, Ev(True), "farthest_point_sample(multi-CU, test)")
+    with pytest.raises(_lib.GspnHipError, match="multi-CU, test"):
+        _lib.check_async()
+    assert len(_lib._async_status) == 1                  # the pending one is still watched
+    with pytest.raises(_lib.GspnHipError, match="pending"):
+        _lib.check_async(block=True)
+    assert _lib._async_status == []

@@ -48,7 +48,31 @@ def to_layers(ps):
     return layers
 
 
-def check_stack(rows, ld, cin, chans, ns, training, ref_device="cpu", neg_gamma=False):
+def fragile_entries(zs, ns):
+    """zs: the float64 pre-activations (BN output before the ReLU) of every layer of a stack, (rows, c_l) each; ns: pool size or None.
+    Returns (fragile, frag_rows): the entries of the stack's OUTPUT gradient that a float32 evaluation may route differently -- (rows,)
+    bool for a dense output, (groups, c_last) bool for a pooled one -- and the (rows,) rows holding a fragile hidden element.
+    See check_stack for the rule."""
+    rows = zs[0].shape[0]
+    dev = zs[0].device
+    frag_rows = torch.zeros(rows, dtype=torch.bool, device=dev)
+    for li, z in enumerate(zs):
+        if ns and li == len(zs) - 1:
+            continue                                 # the last layer's mask matters only on the row that wins the pool
+        frag_rows |= (z.abs() < 2e-5).any(dim=1)
+    if not ns:
+        return frag_rows, frag_rows
+    groups = rows // ns
+    zl = zs[-1].view(groups, ns, -1)
+    top2 = torch.relu(zl).topk(2, dim=1)
+    vals, win = top2.values, top2.indices[:, 0]                                                   # (groups, 2, c), (groups, c)
+    near = ((vals[:, 0] - vals[:, 1]) < 1e-5 * (vals[:, 0].abs() + 1e-3)) & (vals[:, 0] > 0)
+    win_row = win + torch.arange(groups, device=dev)[:, None] * ns
+    win_small = zl.gather(1, win[:, None, :]).squeeze(1).abs() < 2e-5
+    return near | frag_rows[win_row] | win_small, frag_rows
+
+
+def check_stack(rows, ld, cin, chans, ns, training, ref_device="cpu", neg_gamma=False, max_fragile=0.05):
     """mlp_stack forward + backward against oracle/mlp_ref.py evaluated in float64 on `ref_device`"""
     from gspn_amd.mlp import mlp_stack
     g = torch.Generator().manual_seed(rows + cin)
@@ -75,26 +99,34 @@ def check_stack(rows, ld, cin, chans, ns, training, ref_device="cpu", neg_gamma=
     # float64 restatement, layer by layer (oracle/mlp_ref.py), keeping the pre-activations.  An element whose BN output lies within
     # fp32 rounding of the ReLU kink -- or a pool group whose two largest activations agree to fp32 rounding -- may fall on the other
     # side in float32.  One such flip moves dW by a single row's contribution, which at 1e5 rows is already 1e-3 of |dW| (the sum over
-    # rows of a random-sign gradient grows like sqrt(rows), not rows).  So the upstream gradient is set to ZERO on the rows (groups)
-    # that hold a fragile element: their masks then matter to no weight gradient in either precision.  Their own dX rows still see the
-    # flip through the batch-norm mean terms (a 1/sqrt(rows) effect, measured 2e-4 of max|dX| at 131072 rows: tools/mlp_bigcheck.py),
-    # so those rows -- and only those -- are left out of the dX comparison.  The forward comparison covers all rows.
-    h, moving = xr, []
-    fragile = torch.zeros(rows, dtype=torch.bool, device=ref_device)
-    for p in ps:
+    # rows of a random-sign gradient grows like sqrt(rows), not rows).  So the upstream gradient is set to ZERO exactly where a fragile
+    # decision would carry it:
+    #   * dense output (no pool): on the rows that hold a fragile element in any layer;
+    #   * pooled output: per (group, channel) ELEMENT -- where the two largest activations of the group nearly tie, where the winning
+    #     activation itself is within rounding of 0, or where the winning ROW holds a fragile element in a hidden layer.  A row of a
+    #     pooled stack receives gradient only through the channels it wins, so this removes every fragile row from the weight
+    #     gradients without silencing its whole group (at nsample = 256 / 512 nearly every group holds SOME fragile element; the
+    #     group-level rule of round 2 would zero the whole test there).
+    # Rows with a fragile hidden element still see the flip through the batch-norm mean terms of their own dX row (a 1/sqrt(rows)
+    # effect, measured 2e-4 of max|dX| at 131072 rows: tools/mlp_bigcheck.py), so those rows -- and only those -- are left out of the
+    # dX comparison.  The forward comparison covers all rows.  The fraction of silenced gradient entries is printed and capped.
+    h, moving, zs = xr, [], []
+    for li, p in enumerate(ps):
         z, mm, mv = R.layer(h, p["w"], p["b"], p.get("gamma"), p.get("beta"), p.get("moving_mean"), p.get("moving_var"), training, 0.7,
                             p.get("bn", True), relu=False)
-        fragile |= (z.detach().abs() < 2e-5).any(dim=1)
+        zs.append(z.detach())
         h = torch.relu(z)
         moving.append((mm, mv))
     ref = h
+    fragile, frag_rows = fragile_entries(zs, ns)
+    del zs
     if ns:
-        full = ref.view(rows // ns, ns, -1)
-        top2 = full.detach().topk(2, dim=1).values
-        near = ((top2[:, 0] - top2[:, 1]) < 1e-5 * (top2[:, 0].abs() + 1e-3)) & (top2[:, 0] > 0)
-        fragile = fragile.view(rows // ns, ns).any(dim=1) | near.any(dim=1)
-        ref = full.max(dim=1).values
-    assert int(fragile.sum()) <= max(4, fragile.numel() // 4), "too many fragile rows/groups: %d of %d" % (int(fragile.sum()), fragile.numel())
+        ref = ref.view(rows // ns, ns, -1).max(dim=1).values
+    frac = float(fragile.float().mean())
+    print("check_stack rows=%d cin=%d chans=%s ns=%s: fragile (silenced) gradient entries %.3f %% of %d; rows left out of the dX comparison %.3f %%"
+          % (rows, cin, chans, ns, 100 * frac, fragile.numel(), 100 * float(frag_rows.float().mean())))
+    # measured on MI355X at every shape of this file: <= 1.2 % (printed above); the cap is that + margin
+    assert frac <= max_fragile or int(fragile.sum()) <= 4, "too many fragile gradient entries: %.3f %% (cap %.1f %%)" % (100 * frac, 100 * max_fragile)
     assert out.shape == ref.shape
     assert rel_err(out, ref) < 1e-5
     if training:
@@ -106,7 +138,7 @@ def check_stack(rows, ld, cin, chans, ns, training, ref_device="cpu", neg_gamma=
     ref.backward(go)
     out.backward(go.float().cuda())
     tol = 1e-4
-    keep = ~(fragile.repeat_interleave(ns) if ns else fragile)
+    keep = ~frag_rows
     assert rel_err(x.grad[:, :cin][keep.to(x.device)], xr.grad[keep]) < tol
     for lp, p in zip(layers, ps):
         assert rel_err(lp.weights.grad, p["w"].grad) < tol
@@ -146,6 +178,15 @@ def test_mlp_stack_at_bench_sizes(rows, ld, cin, chans, ns):
     """the row counts, pitches and channel widths bench.py runs (other template instances, multi-chunk partial-tile reduction,
     persistent grids than the small cases select), against the float64 restatement evaluated on the device"""
     check_stack(rows, ld, cin, chans, ns, True, ref_device="cuda")
+
+
+@pytest.mark.parametrize("rows,ns", [(524288, 256), (1048576, 512)])
+def test_mlp_stack_at_config3_shard_sizes(rows, ns):
+    """the context encoder's stacks at BASELINE configs[3]'s per-GPU shard (model_rpointnet.py:377: 8 scenes x 256 seeds x nsample
+    256 / 512 grouped rows, [colour, xyz] -> 64 -> 128 -> 256, max-pool over nsample): the kernel instances that carry that leg --
+    mlp_fwd_kernel<128,.>, mlp_bwd_data_kernel<128,.,true,.>, wgrad_stream_kernel<1,4,16,...> at 0.5 M / 1 M rows and bnrelu_maxpool
+    with nsample != 32 -- forward AND backward against the float64 restatement evaluated on the device"""
+    check_stack(rows, 8, 6, [64, 128, 256], ns, True, ref_device="cuda")
 
 
 def test_mlp_stack_no_bn():

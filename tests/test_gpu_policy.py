@@ -1,0 +1,137 @@
+"""The one bit-level assumption nothing in this container can verify is how nvcc contracted (x2-x1)^2+(y2-y1)^2+(z2-z1)^2 in the
+reference's CUDA kernels (oracle/gspn_oracle.c header).  It is ONE compile-time switch, GSPN_DIST_POLICY, shared by
+the HIP kernels (csrc/common.h dist2_cuda, csrc/fps_common.h dist2_cuda_v2) and the oracle.  This test proves the claim "flip one
+switch if a real CUDA run ever disagrees": variant libraries built with policy 0 (unfused) and 1 (fma(c,c,fma(b,b,a*a))) -- by
+gspn_amd.build.build(policy=...) and `make -C oracle policies`, prebuilt by __graft_entry__.build() -- stay INDEX- AND BIT-EXACT against
+the oracle built with the same policy on FPS (plain on-chip, 4-wave, cell and multi-CU kernels), ball query and nn_distance, and the
+three policies really produce different bits (so the test cannot pass vacuously)."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from tests import data as D
+
+pytestmark = pytest.mark.gpu
+
+P = ctypes.c_void_p
+I = ctypes.c_int
+F = ctypes.c_float
+
+
+def _variant(policy):
+    from gspn_amd import _lib, build
+    if policy == 2:
+        return _lib.lib()
+    path = build.policy_lib_path(policy)
+    if not os.path.exists(path):
+        build.build(policy=policy)                      # (normally prebuilt by __graft_entry__.build(): it travels with the snapshot)
+    h = ctypes.CDLL(path)
+    for name in ("gspn_farthestpointsampling", "gspn_farthestpointsampling_multi", "gspn_queryballpoint", "gspn_nmdistance", "gspn_gatherpoint"):
+        fn = getattr(h, name)
+        fn.argtypes = _lib.SIGNATURES[name]
+        fn.restype = I
+    h.gspn_fps_multi_ws_bytes.argtypes = [I, I]
+    h.gspn_fps_multi_ws_bytes.restype = ctypes.c_long
+    h.gspn_ball_threshold.argtypes = [F]
+    h.gspn_ball_threshold.restype = F
+    assert h.gspn_dist_policy() == policy
+    return h
+
+
+def _ptr(t):
+    return P(t.data_ptr()) if t is not None else P(0)
+
+
+def _st():
+    return P(torch.cuda.current_stream().cuda_stream)
+
+
+def _fps(h, xyz, m, temp=True):
+    b, n, _ = xyz.shape
+    out = torch.empty((b, m), dtype=torch.int32, device="cuda")
+    scratch = torch.empty((32, n), dtype=torch.float32, device="cuda") if temp else None      # the reference's own scratch (tf_sampling.cpp:111-115)
+    assert h.gspn_farthestpointsampling(b, n, m, _ptr(xyz), _ptr(scratch), _ptr(out), _st()) == 0
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+def _fps_multi(h, xyz, m, G):
+    b, n, _ = xyz.shape
+    out = torch.empty((b, m), dtype=torch.int32, device="cuda")
+    ws = torch.empty((int(h.gspn_fps_multi_ws_bytes(b, n)) + 3) // 4, dtype=torch.float32, device="cuda")
+    assert h.gspn_farthestpointsampling_multi(b, n, m, G, _ptr(xyz), _ptr(ws), _ptr(out), _st()) == 0
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+@pytest.mark.parametrize("policy", [0, 1, 2])
+def test_geometry_is_index_exact_under_every_contraction_policy(policy):
+    h = _variant(policy)
+    with O.use_policy(policy):
+        assert O.dist_policy() == policy
+        # FPS: lattice-free uniform clouds AND a duplicate-heavy cloud (ties decide), every kernel family
+        for kind, b, n, m, temp in (("U", 2, 1500, 300, False),     # 4-wave kernel (n <= 2048)
+                                    ("D", 2, 4096, 512, False),     # plain on-chip kernel
+                                    ("U", 2, 32768, 512, False),    # plain on-chip kernel, z in LDS
+                                    ("U", 2, 32768, 1024, True),    # cell kernel (spatial pre-pass, culling, batched picks)
+                                    ("D", 2, 16384, 512, True)):    # cell kernel on duplicates
+            xyz = D.batch(kind, b, n, 40 + policy)
+            got = _fps(h, torch.from_numpy(xyz).cuda(), m, temp)
+            np.testing.assert_array_equal(got, O.farthest_point_sample(m, xyz, mt=True), err_msg="FPS %s n=%d policy %d" % (kind, n, policy))
+        xyz = D.batch("U", 2, 65536, 77)
+        got = _fps_multi(h, torch.from_numpy(xyz).cuda(), 512, 4)
+        np.testing.assert_array_equal(got, O.farthest_point_sample(512, xyz, mt=True), err_msg="multi-CU FPS policy %d" % policy)
+        # ball query: radius chosen so that many candidates sit within rounding of the boundary
+        xyz = D.batch("U", 2, 8192, 5)
+        t = torch.from_numpy(xyz).cuda()
+        ctr = np.ascontiguousarray(xyz[:, ::16])                                   # 512 centres that ARE data points
+        tc = torch.from_numpy(ctr).cuda()
+        for radius, ns in ((0.1, 32), (0.05, 64)):
+            idx = torch.zeros((2, 512, ns), dtype=torch.int32, device="cuda")
+            cnt = torch.zeros((2, 512), dtype=torch.int32, device="cuda")
+            assert h.gspn_queryballpoint(2, 8192, 512, F(radius), ns, _ptr(t), _ptr(tc), _ptr(idx), _ptr(cnt), _st()) == 0
+            torch.cuda.synchronize()
+            ridx, rcnt = O.query_ball_point(radius, ns, xyz, ctr, mt=True)
+            np.testing.assert_array_equal(idx.cpu().numpy(), ridx)
+            np.testing.assert_array_equal(cnt.cpu().numpy(), rcnt)
+        # nn_distance: indices AND distances bit for bit
+        rng = np.random.default_rng(3)
+        a = rng.standard_normal((64, 512, 3)).astype(np.float32)
+        c = rng.standard_normal((64, 384, 3)).astype(np.float32)
+        ta, tcc = torch.from_numpy(a).cuda(), torch.from_numpy(c).cuda()
+        d1 = torch.empty((64, 512), device="cuda"); i1 = torch.empty((64, 512), dtype=torch.int32, device="cuda")
+        d2 = torch.empty((64, 384), device="cuda"); i2 = torch.empty((64, 384), dtype=torch.int32, device="cuda")
+        assert h.gspn_nmdistance(64, 512, _ptr(ta), 384, _ptr(tcc), _ptr(d1), _ptr(i1), _ptr(d2), _ptr(i2), _st()) == 0
+        torch.cuda.synchronize()
+        r1, ri1, r2, ri2 = O.nn_distance(a, c)
+        np.testing.assert_array_equal(i1.cpu().numpy(), ri1)
+        np.testing.assert_array_equal(i2.cpu().numpy(), ri2)
+        np.testing.assert_array_equal(d1.cpu().numpy(), r1)
+        np.testing.assert_array_equal(d2.cpu().numpy(), r2)
+
+
+def test_the_policies_really_differ():
+    """the three contraction forms give different bits on the same inputs, on the device as in the oracle -- the sweep above is not vacuous"""
+    rng = np.random.default_rng(4)
+    a = rng.standard_normal((32, 512, 3)).astype(np.float32)
+    c = rng.standard_normal((32, 512, 3)).astype(np.float32)
+    ta, tc = torch.from_numpy(a).cuda(), torch.from_numpy(c).cuda()
+    dev, ora = [], []
+    for policy in (0, 1, 2):
+        h = _variant(policy)
+        d1 = torch.empty((32, 512), device="cuda"); i1 = torch.empty((32, 512), dtype=torch.int32, device="cuda")
+        d2 = torch.empty((32, 512), device="cuda"); i2 = torch.empty((32, 512), dtype=torch.int32, device="cuda")
+        assert h.gspn_nmdistance(32, 512, _ptr(ta), 512, _ptr(tc), _ptr(d1), _ptr(i1), _ptr(d2), _ptr(i2), _st()) == 0
+        torch.cuda.synchronize()
+        dev.append(d1.cpu().numpy())
+        with O.use_policy(policy):
+            ora.append(O.nn_distance(a, c)[0])
+    for p in range(3):
+        np.testing.assert_array_equal(dev[p], ora[p])
+    for p, q in ((0, 1), (0, 2), (1, 2)):
+        assert (dev[p] != dev[q]).any(), "policies %d and %d give identical bits" % (p, q)
+        assert np.abs(dev[p] - dev[q]).max() <= 1e-6 * np.abs(dev[p]).max()          # ... and differ in the last place only
