@@ -23,6 +23,11 @@ import os
 import sys
 import time
 
+# The layers' stream, the two geometry streams and the communication library's stream must each own a hardware queue; HIP's default of
+# four leaves no slack once RCCL and the capture streams have taken their round-robin slots (gspn_amd/geometry.py: GeometryStream tests
+# its queue, this only gives the test room to succeed).  Read by the HIP runtime at initialisation, so it is set before torch loads.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -126,7 +131,17 @@ def main():
 
     store = tf_util.set_variable_store(tf_util.VariableStore(device=dev, seed=1234))   # same weights on every rank
     state = {"bucket": None, "opt": None, "i": 0, "pend": None, "t_wait": 0.0}
-    geo = None if args.no_overlap else [GeometryStream(dev, priority=GEO_PRIO) for _ in range(DEPTH)]     # (default priority: a high-priority geometry queue starves the layers, 3.7 -> 8.1 ms per step)
+    geo = None
+    if not args.no_overlap:
+        # every geometry stream is TESTED to run beside the layers' stream, beside the other geometry streams and -- when a process
+        # group exists -- not to hold up a collective issued on the layers' stream (GeometryStream: hardware-queue round-robin)
+        probes = []
+        if dist.is_initialized():
+            dummy = torch.zeros(1024, device=dev)
+            probes.append(lambda: dist.all_reduce(dummy))
+        geo = []
+        for _ in range(DEPTH):          # (default priority: a high-priority geometry queue starves the layers, 3.7 -> 8.1 ms per step)
+            geo.append(GeometryStream(dev, priority=GEO_PRIO, beside=[torch.cuda.current_stream()] + [g_.stream for g_ in geo], probes=probes))
     use_graph = geo is not None and not args.no_graph
     pend = {}                   # step index -> PendingGeometry
     done = {}                   # step index -> event after its layers + optimiser step
@@ -401,6 +416,8 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
                          "achieved_is": "effective rate = algorithmic bytes / time (the kernel is on-chip resident; see traffic)",
                          "avg_launch_ms": fps_avg_ms, "us_per_pick": fps_avg_ms * 1e3 / m, "launches_timed": len(fps_ms)},
+            "geometry_streams": None if geo is None else {"hw_queues_env": os.environ.get("GPU_MAX_HW_QUEUES"), "streams_tried": [g_.tried for g_ in geo],
+                                                         "shares_a_queue": [g_.shares_queue for g_ in geo]},
             "host_enqueue_ms_per_step": t_host / args.steps * 1e3,
             "host_wait_ms_per_step": state["t_wait"] / args.steps * 1e3,
             "host_replay_ms_per_step": state.get("t_replay", 0.0) / (args.steps + args.warmup) * 1e3,
@@ -421,6 +438,15 @@ def main():
                 res["other_configs"] = other_configs(batches[0][0], batches[0][1], dev)
             except Exception as e:
                 res["other_configs"] = {"error": repr(e)}
+            try:
+                res["roofline_ops"] = ops_roofline(batches[0][0], G[0] if use_graph else pn2_geometry(batches[0][0]), dev)
+            except Exception as e:
+                res["roofline_ops"] = {"error": repr(e)}
+            if not args.no_cpu_baseline:
+                try:
+                    res["reference_harness"] = reference_harness(dev)
+                except Exception as e:
+                    res["reference_harness"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(xyz_np0, col_np0)
         print(json.dumps(res), flush=True)
@@ -500,8 +526,10 @@ def mlp_roofline(mlp_mod, eager_step, state, reps=3):
     by = {"fwd": 0.0, "wgrad": 0.0, "bwd": 0.0}
     flops = 0.0
     nbytes = 0.0
-    for kind, rows, cin, cout, e0, e1 in prof:
+    executed = 0.0
+    for kind, rows, cin, cout, e0, e1, ex in prof:
         by[kind] += e0.elapsed_time(e1)
+        executed += ex
         if kind == "fwd":
             flops += 3 * 2.0 * rows * cin * cout
             # one read of X and one write of Y forward; X, Y, dZ read by pass A; Y, dZ read + dX written by pass B
@@ -510,15 +538,236 @@ def mlp_roofline(mlp_mod, eager_step, state, reps=3):
         by[k] /= reps
     flops /= reps
     nbytes /= reps
+    executed /= reps
     total_ms = sum(by.values())
     tf = flops / (total_ms * 1e-3) / 1e12
+    hbm_floor_ms = nbytes / (HBM_PEAK_GBS * 1e9) * 1e3
     return {"bound": "mfma_f32", "unit": "TFLOP/s", "peak": MFMA_F32_PEAK_TFLOPS, "achieved": tf, "frac": tf / MFMA_F32_PEAK_TFLOPS,
             "kernels": "mlp_fwd_* / wgrad_* (+ finalize) / mlp_bwd_data_* of the 16 layers of pn2_fea_extractor",
-            "flops_per_step": flops, "gemm_ms_per_step": total_ms, "ms_by_pass": by,
+            "flops_per_step": flops, "executed_flops_per_step": executed, "executed_TFLOPs": executed / (total_ms * 1e-3) / 1e12,
+            "gemm_ms_per_step": total_ms, "ms_by_pass": by,
             "algorithmic_bytes_per_step": nbytes, "algorithmic_TBps": nbytes / (total_ms * 1e-3) / 1e12,
+            # at 12 flop/B the stack sits left of the fp32 ridge (157.3 TF / 8 TB/s = 19.7 flop/B): its true roof is HBM
+            "hbm_roof": {"floor_ms_at_peak": hbm_floor_ms, "frac": hbm_floor_ms / total_ms, "flop_per_byte": flops / nbytes},
             "note": "flops = SURVEY 8(d)'s algorithmic count of the 16 layers (the pre-aggregated first layers of SA2 / SA3 / the last FP level execute "
                     "fewer: their feature part runs on the source points); eager launches bracketed one by one (includes ~1-2 us of event overhead per "
                     "launch); profiles/ holds the rocprofv3 per-kernel table of the captured step"}
+
+
+def _ev_time(fn, warm=3, reps=20):
+    """average milliseconds of fn() on the GPU: `reps` calls captured into one hipGraph and replayed between two HIP events, so that the
+    figure is kernel time and not the host's time to enqueue a 10-microsecond launch from Python (eager fallback if capture fails)"""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    try:
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(reps):
+                fn()
+        g.replay()
+        torch.cuda.synchronize()
+        e0.record()
+        g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        del g
+        return ms
+    except Exception:
+        torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def _pmc_ops():
+    """memory-side bytes per launch of the stand-alone ops (tools/pmc_ops.sh -> profiles/r03_ops_pmc.json: separate --pmc FETCH_SIZE /
+    WRITE_SIZE passes over tools/ops_only.py, FETCH_SIZE doubled per MI355X_MICROARCH.md), keyed like the entries below"""
+    q = os.path.join(ROOT, "profiles", "r03_ops_pmc.json")
+    try:
+        return json.load(open(q)).get("ops", {}) if os.path.exists(q) else {}
+    except Exception:
+        return {}
+
+
+def ops_roofline(xyz, geo, dev, timer=None):
+    """SURVEY 8(d)'s remaining per-op rooflines at the bench shapes (BASELINE configs[2] levels; nn_distance at configs[3]'s 2048 x (512,512)
+    clouds): three_nn, three_interpolate(+grad) and the fused FP input (fp_concat + its inverse-list gradient), group_point(+grad),
+    gather_point, nn_distance(+grad).  `achieved` = 8(d)'s algorithmic bytes / HIP-event time of the stand-alone launch (20 back-to-back
+    calls replayed from a hipGraph on an idle chip) -- an EFFECTIVE rate: these working sets (<= 134 MB, mostly <= 4 MB) live in L2 / Infinity Cache, so the
+    fraction of the 8 TB/s HBM peak can exceed what HBM could deliver; `traffic` is the PMC memory-side byte count per launch and
+    `bound_by` names what actually limits the kernel."""
+    from gspn_amd.pointnet_util import fp_concat
+    from gspn_amd.tf_grouping import group_point
+    from gspn_amd.tf_interpolate import three_interpolate, three_nn
+    from gspn_amd.tf_nndistance import nn_distance
+    from gspn_amd.tf_sampling import gather_point
+    pmc = _pmc_ops()
+    gen = torch.Generator(device=dev).manual_seed(21)
+    b = xyz.shape[0]
+    out = []
+
+    if timer is None:
+        timer = lambda key, fn: _ev_time(fn)       # (tools/ops_only.py passes one that brackets a single launch with marker kernels for the PMC passes)
+
+    def add(name, shape, alg_bytes, fn, bound_by, key=None):
+        ms = timer(key or name, fn)
+        ach = alg_bytes / (ms * 1e-3) / 1e9
+        out.append({"op": name, "shape": shape, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": ms, "achieved": ach,
+                    "frac": ach / HBM_PEAK_GBS, "traffic": pmc.get(key or name), "bound_by": bound_by})
+
+    lv = [xyz, geo["sa"][0].new_xyz, geo["sa"][1].new_xyz, geo["sa"][2].new_xyz]
+    # three_nn (tf_interpolate.cpp:60-103): 12*b*n*m + 36*b*n
+    for d, s_ in ((0, 1), (1, 2), (2, 3)):
+        n, m = lv[d].shape[1], lv[s_].shape[1]
+        order = geo["sa"][d].scan_order if d < 3 else None
+        add("three_nn", "%dx%d<-%d%s" % (b, n, m, " (queries in the FPS pre-pass order)" if order is not None else ""), 12.0 * b * n * m + 36.0 * b * n, lambda: three_nn(lv[d], lv[s_], order=order),
+            "VALU issue + LDS broadcast: 4 instructions per (query, candidate) pair, exact re-evaluation of the survivors; the known cloud (<= 24 KB per "
+            "scene) sits in LDS" if n >= 2048 else "launch latency (a few microseconds of work)", "three_nn_%d" % n)
+    # three_interpolate (+grad) (tf_interpolate.cpp:107-153): b*n*(24 + 16*c), and the fused FP input used by the bench graph
+    for (d, s_, c2, c1, k) in ((0, 1, 128, 3, 2), (1, 2, 256, 64, 1), (2, 3, 256, 128, 0)):
+        n, m = lv[d].shape[1], lv[s_].shape[1]
+        fpg = geo["fp"][k]
+        p2 = torch.randn(b, m, c2, device=dev, generator=gen).requires_grad_(True)
+        p1 = torch.randn(b, n, c1, device=dev, generator=gen)
+        go = torch.randn(b, n, c2, device=dev, generator=gen)
+        add("three_interpolate", "%dx%d<-%d, c=%d" % (b, n, m, c2), 1.0 * b * n * (24 + 16 * c2), lambda: three_interpolate(p2.detach(), fpg.idx, fpg.weight),
+            "memory: one coalesced (n, c) write, three L2-resident row reads per point", "three_interpolate_%d" % n)
+        o = three_interpolate(p2, fpg.idx, fpg.weight)
+        add("three_interpolate_grad", "%dx%d->%d, c=%d (scatter-add, hardware fp32 atomics)" % (b, n, m, c2), 1.0 * b * n * (24 + 16 * c2), lambda: torch.autograd.grad(o, p2, go, retain_graph=True),
+            "L2 atomic throughput: 3*c atomic adds per dense point onto m*c addresses", "three_interpolate_grad_%d" % n)
+        o2 = fp_concat(p2, fpg.idx, fpg.weight, p1, fpg.order, fpg.offsets)
+        g2 = torch.randn_like(o2)
+        add("fp_concat (interpolate + concat, fused)", "%dx%d<-%d, c2=%d c1=%d" % (b, n, m, c2, c1), 1.0 * b * n * (24 + 16 * c2 + 8 * c1), lambda: fp_concat(p2.detach(), fpg.idx, fpg.weight, p1, fpg.order, fpg.offsets),
+            "memory: one write of the (n, c2+c1) input matrix", "fp_concat_%d" % n)
+        add("fp_concat_grad (gather over inverse lists, no atomics)", "%dx%d->%d, c2=%d" % (b, n, m, c2), 1.0 * b * n * (24 + 16 * c2), lambda: torch.autograd.grad(o2, p2, g2, retain_graph=True),
+            "dependent-load latency of the inverse-list walk (one wave per sparse point x 64 channels)", "fp_concat_grad_%d" % n)
+        del o, o2
+    # group_point (+grad) (tf_grouping_g.cu:43-83): b*m*ns*(4 + 8*c); gather_point (tf_sampling_g.cu:172-192)
+    feats = [3, 64, 128]
+    for lvl in range(3):
+        sa = geo["sa"][lvl]
+        n, m, ns, c = lv[lvl].shape[1], sa.idx.shape[1], sa.idx.shape[2], feats[lvl]
+        pts = torch.randn(b, n, c, device=dev, generator=gen).requires_grad_(True)
+        add("group_point", "%dx%d -> (%d,%d), c=%d" % (b, n, m, ns, c), 1.0 * b * m * ns * (4 + 8 * c), lambda: group_point(pts.detach(), sa.idx),
+            "memory: the (m, ns, c) write; gathered rows are L2 hits" if c >= 64 else "write coalescing: 12-byte rows", "group_point_%d" % n)
+        o = group_point(pts, sa.idx)
+        go = torch.randn_like(o)
+        add("group_point_grad", "(%d,%d) -> %dx%d, c=%d (scatter-add, hardware fp32 atomics)" % (m, ns, b, n, c), 1.0 * b * m * ns * (4 + 8 * c), lambda: torch.autograd.grad(o, pts, go, retain_graph=True),
+            "L2 atomic throughput", "group_point_grad_%d" % n)
+        del o
+    fidx = geo["sa"][0].idx[:, :, 0].contiguous()
+    add("gather_point", "%dx%d -> %d" % (b, xyz.shape[1], fidx.shape[1]), 1.0 * b * fidx.shape[1] * (4 + 24), lambda: gather_point(xyz, fidx), "launch latency (590 KB moved)", "gather_point")
+    # nn_distance (+grad) (tf_nndistance_g.cu:5-151): 12*b*(2*n*m) + 8*b*(n+m); grad b*(n+m)*56
+    for (nb, n, m) in ((256 * b, 512, 512), (32, 16384, 1024)):
+        a = torch.randn(nb, n, 3, device=dev, generator=gen).requires_grad_(True)
+        c_ = torch.randn(nb, m, 3, device=dev, generator=gen).requires_grad_(True)
+        add("nn_distance", "%d clouds x (%d, %d)" % (nb, n, m), 12.0 * nb * 2 * n * m + 8.0 * nb * (n + m), lambda: nn_distance(a.detach(), c_.detach()),
+            "VALU issue: 7 instructions per point pair from LDS tiles (the clouds are on-chip; 38 MB of input for 2048 clouds)", "nn_distance_%d" % n)
+        d1, _, d2, _ = nn_distance(a, c_)
+        g1, g2 = torch.randn_like(d1), torch.randn_like(d2)
+        add("nn_distance_grad", "%d clouds x (%d, %d) (scatter-add, hardware fp32 atomics)" % (nb, n, m), 56.0 * nb * (n + m), lambda: torch.autograd.grad([d1, d2], [a, c_], [g1, g2], retain_graph=True),
+            "L2 atomic throughput + two memsets", "nn_distance_grad_%d" % n)
+        del d1, d2
+    return {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+            "achieved_is": "effective rate = SURVEY 8(d) algorithmic bytes / stand-alone launch time (HIP events, 20 calls, idle chip); traffic = PMC "
+                           "memory-side bytes per launch (profiles/r03_ops_pmc.json) or null",
+            "ops": out}
+
+
+def reference_harness(dev):
+    """The only performance harnesses the reference ships, at their own shapes, HIP kernel beside CPU code:
+      * tf_ops/3d_interpolation/interpolate.cpp:134,153-167 (b=32, n=512, m=128, c=64) / tf_interpolate.py:40-54: three_nn,
+        three_interpolate, three_interpolate_grad.  CPU = the REFERENCE'S OWN compiled loops for interpolate / interpolate_grad
+        (oracle/_ref/libinterp_ref.so, built from that very file) -- kind "reference"; its threenn_cpu ignores the query point
+        (interpolate.cpp:34), so the 3-NN CPU time is the oracle's restatement of tf_interpolate.cpp:60-103 -- kind "port".
+      * tf_ops/nn_distance/tf_nndistance.py:48-66 ((32,16384,3) x (32,1024,3), forward + gradient): CPU = the oracle's twin of the
+        reference's own CPU kernel nnsearch (tf_nndistance.cpp:21-43,126-163) -- kind "port", one thread like the reference.
+      * the reference's operating point (models/config.py:14-19: batch 2 x 18000 points): one fwd+bwd of pn2_fea_extractor."""
+    from oracle import oracle as O
+    from gspn_amd import tf_util
+    from gspn_amd.fea_extractor import pn2_fea_extractor
+    from gspn_amd.tf_interpolate import three_interpolate, three_nn
+    from gspn_amd.tf_nndistance import nn_distance
+    res = {}
+
+    def best(fn, reps=3):
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return min(ts) * 1e3
+
+    # ---- interpolate.cpp / tf_interpolate.py ----
+    rng = np.random.RandomState(100)                       # np.random.seed(100), tf_interpolate.py:39
+    pts = rng.random_sample((32, 128, 64)).astype(np.float32)
+    x1 = rng.random_sample((32, 512, 3)).astype(np.float32)
+    x2 = rng.random_sample((32, 128, 3)).astype(np.float32)
+    tp, t1, t2 = (torch.from_numpy(a).to(dev) for a in (pts, x1, x2))
+    dist, idx = three_nn(t1, t2)
+    w = torch.full_like(dist, 1.0 / 3.0)                   # tf_interpolate.py:48
+    tpg = tp.clone().requires_grad_(True)
+    o = three_interpolate(tpg, idx, w)
+    go = torch.randn_like(o)
+    idx_np, w_np, go_np = idx.cpu().numpy(), w.cpu().numpy(), go.cpu().numpy()
+    have_ref = O.ref_lib() is not None
+    ref_out = O.ref_three_interpolate(pts, idx_np, w_np) if have_ref else None
+    leg = {"shape": "b=32, n=512, m=128, c=64 (interpolate.cpp:134; tf_interpolate.py:40-47)",
+           "hip_ms": {"three_nn": _ev_time(lambda: three_nn(t1, t2), 3, 50), "three_interpolate": _ev_time(lambda: three_interpolate(tp, idx, w), 3, 50),
+                      "three_interpolate_grad": _ev_time(lambda: torch.autograd.grad(o, tpg, go, retain_graph=True), 3, 50)},
+           "cpu_ms": {"three_nn": best(lambda: O.three_nn(x1, x2)),
+                      "three_interpolate": best(lambda: (O.ref_three_interpolate if have_ref else O.three_interpolate)(pts, idx_np, w_np)),
+                      "three_interpolate_grad": best(lambda: (O.ref_three_interpolate_grad if have_ref else O.three_interpolate_grad)(pts, idx_np, w_np, go_np))},
+           "cpu_kind": {"three_nn": "port (oracle restatement of tf_interpolate.cpp:60-103; the harness's own threenn_cpu is not the op's formula)",
+                        "three_interpolate": "reference (oracle/_ref: interpolate.cpp compiled as is)" if have_ref else "port",
+                        "three_interpolate_grad": "reference (oracle/_ref)" if have_ref else "port"},
+           "cores": 1,
+           "hip_equals_reference_bits": bool(have_ref and np.array_equal(o.detach().cpu().numpy(), ref_out))}
+    leg["tf_interpolate.py loop (100 x three_interpolate)"] = {"hip_ms": 100 * leg["hip_ms"]["three_interpolate"], "cpu_ms": 100 * leg["cpu_ms"]["three_interpolate"]}
+    res["3d_interpolation"] = leg
+    # ---- tf_nndistance.py ----
+    rng = np.random.RandomState(100)
+    a = rng.randn(32, 16384, 3).astype(np.float32)
+    c = rng.randn(32, 1024, 3).astype(np.float32)
+    ta = torch.from_numpy(a).to(dev).requires_grad_(True)
+    tc = torch.from_numpy(c).to(dev)
+
+    def hip_step():
+        d1, _, d2, _ = nn_distance(ta, tc)
+        (d1.sum() + d2.sum()).backward()                   # loss = reduce_sum(reta) + reduce_sum(retc), tf_nndistance.py:59
+        ta.grad = None
+
+    def cpu_step():
+        d1, i1, d2, i2 = O.nn_distance(a, c, cpu_twin=True)
+        O.nn_distance_grad(a, c, np.ones_like(d1), i1, np.ones_like(d2), i2)
+    res["nn_distance"] = {"shape": "(32,16384,3) x (32,1024,3), forward + gradient (tf_nndistance.py:48-66)",
+                          "hip_ms_per_step": _ev_time(hip_step, 3, 20), "cpu_ms_per_step": best(cpu_step, 2), "cores": 1,
+                          "cpu_kind": "port (oracle twin of the reference's CPU kernel nnsearch, tf_nndistance.cpp:21-43, + its gradient loop)"}
+    # ---- the reference's operating point ----
+    keep = tf_util.get_variable_store()
+    try:
+        tf_util.set_variable_store(tf_util.VariableStore(device=dev, seed=6))
+        nb, npt = 2, 18000
+        xyz = torch.from_numpy(np.stack([np.random.default_rng(900 + i).random((npt, 3), dtype=np.float32) for i in range(nb)])).to(dev)
+        col = torch.rand(nb, npt, 3, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+
+        def op_step():
+            for p_ in tf_util.get_variable_store().parameters():
+                p_.grad = None
+            pn2_fea_extractor(xyz, col, 'op', True, 0.5).square().mean().backward()
+        t = _time_steps(op_step, 3, 10)
+        res["operating_point"] = {"workload": "models/config.py:14-19: batch 2 x 18000 points, pn2_fea_extractor 3 x SA + 3 x FP fwd+bwd, eager, geometry inline",
+                                  "ms_per_step": t * 1e3, "scenes_per_s": nb / t}
+    finally:
+        tf_util.set_variable_store(keep)
+        torch.cuda.empty_cache()
+    return res
 
 
 def _time_steps(fn, warm, reps):

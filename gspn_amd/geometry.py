@@ -146,18 +146,63 @@ def _tensors_of(v):
     return []
 
 
+_parked = []          # streams that turned out to share a hardware queue with the layers: kept alive so that their queue slot stays taken
+
+
+def runs_beside(busy, other, work=None, cycles=1500000):
+    """True if work enqueued on `other` (default: one trivial kernel) completes while a long spin kernel is still running on `busy`, i.e.
+    the two streams sit on different hardware queues.  (HIP multiplexes streams onto GPU_MAX_HW_QUEUES -- by default four -- hardware
+    queues round-robin in creation order; kernels of two streams on one queue are serialised.)  Costs about a millisecond; call at set-up."""
+    dev = busy.device
+    torch.cuda.synchronize(dev)
+    tiny = torch.zeros(64, device=dev)
+    with torch.cuda.stream(busy):
+        torch.cuda._sleep(int(cycles))
+        spun = busy.record_event()
+    with torch.cuda.stream(other):
+        if work is None:
+            tiny.fill_(1.0)
+        else:
+            work()
+        done = other.record_event()
+    done.synchronize()
+    beside = not spun.query()
+    torch.cuda.synchronize(dev)
+    return beside
+
+
 class GeometryStream:
     """A side HIP stream for coordinate-only work.  submit(fn, *tensors) runs fn on it after the tensors'
     producer (the caller's current stream) and returns a PendingGeometry."""
 
-    def __init__(self, device=None, priority=0):
-        self.stream = torch.cuda.Stream(device=device, priority=priority)
-        # Bind the stream to a hardware queue NOW.  HIP hands out its (by default four) hardware queues to streams round-robin on FIRST
-        # USE, so a side stream first used after, say, four graph-capture streams lands on the queue of the caller's own stream and its
-        # kernels are serialised with the layers instead of running beside them (measured: +1.0 ms per 2.8 ms step, rocprofv3 shows the
-        # geometry kernels on the layers' queue).  One trivial launch right after creation gives the stream the next free queue.
-        with torch.cuda.stream(self.stream):
-            torch.zeros(1, device=self.stream.device)
+    def __init__(self, device=None, priority=0, beside=None, probes=(), attempts=12):
+        """beside: streams this one must run CONCURRENTLY with (default: the caller's current stream, i.e. the one the layers run on);
+        probes: callables that enqueue work on the caller's current stream which must not queue up behind this stream either (e.g. a
+        collective that the communication library runs on a stream of its own).
+        HIP hands its hardware queues to streams round-robin in creation order, so which queue a new stream lands on depends on every
+        stream anybody created before -- torch's capture streams, and RCCL's: with a process group initialised, the geometry stream of
+        round 2 landed on the LAYERS' queue and every step paid +1.1 ms (r03, rocprofv3 queue ids).  So the stream is not trusted, it
+        is tested: a spin kernel on each stream of `beside` must not delay a trivial launch here (and a spin here must not delay the
+        probes); a stream that fails is parked and the next one tried."""
+        cur = torch.cuda.current_stream(device)
+        beside = [cur] if beside is None else list(beside)
+        self.stream = None
+        self.tried = 0
+        for _ in range(max(1, attempts)):
+            st = torch.cuda.Stream(device=device, priority=priority)
+            with torch.cuda.stream(st):
+                torch.zeros(1, device=st.device)        # first use binds the stream to its hardware queue
+            self.tried += 1
+            ok = all(runs_beside(b, st) for b in beside) and all(runs_beside(st, cur, work=p) for p in probes)
+            if ok:
+                self.stream = st
+                break
+            _parked.append(st)
+        if self.stream is None:                          # fewer free hardware queues than streams that must run side by side
+            self.stream = _parked.pop()
+            self.shares_queue = True
+        else:
+            self.shares_queue = False
 
     def submit(self, fn, *args, after="current", **kwargs):
         """after = "current" (default): fn starts once everything enqueued so far on the caller's current stream is done (its inputs may

@@ -56,11 +56,14 @@ def _tic():
     return e
 
 
-def _toc(e0, kind, rows, cin, cout):
+def _toc(e0, kind, rows, cin, cout, executed=None):
+    """executed: multiply-add flops the launches between the two events really issue when that differs from the algorithmic
+    2*rows*cin*cout of the layer (pre-aggregated first layers run their feature part on the source rows; the two-product pass A
+    runs two GEMMs; pass B of a first layer may cover only the columns that carry a gradient)"""
     if e0 is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        PROFILE.append((kind, rows, cin, cout, e0, e1))
+        PROFILE.append((kind, rows, cin, cout, e0, e1, 2.0 * rows * cin * cout if executed is None else float(executed)))
 
 
 def _side_stream(dev):
@@ -152,7 +155,8 @@ class _MlpStack(torch.autograd.Function):
                 else:
                     L.check(lib.gspn_mlp_fwd(rows, cin, cout, L.ptr(cur), cur_ld, L.ptr(in_scale), L.ptr(in_shift),
                                              L.ptr(lp.weights), L.ptr(lp.biases), L.ptr(y), cout, L.ptr(stats), st), "mlp_fwd")
-                _toc(ev, "fwd", rows, cin, cout)
+                _toc(ev, "fwd", rows, cin, cout,
+                     2.0 * cout * (x.shape[0] * pre["c"] + rows * pre["side_n"]) if (li == 0 and pre is not None) else None)
                 mean = torch.empty(cout, dtype=torch.float32, device=dev)
                 var = torch.empty(cout, dtype=torch.float32, device=dev)
                 scale = torch.empty(cout, dtype=torch.float32, device=dev)
@@ -263,7 +267,8 @@ class _MlpStack(torch.autograd.Function):
                         raise RuntimeError("mlp_stack(preagg=): the first layer's BN coefficients must be known before its backward (EARLY_R)")
                     ev = _tic()
                     dW, dx0 = _preagg_backward(lib, ctx.pre, ctx.pre_x, lp, a, rows, cout, ctx.x_needs_grad, dev, st)
-                    _toc(ev, "bwd", rows, cin, cout)          # (the whole backward of the layer, both "passes")
+                    # (the whole backward of the layer, both "passes": dW_feat and d(feat) on the source rows, dW_side on the output rows)
+                    _toc(ev, "bwd", rows, cin, cout, 2.0 * cout * (ctx.pre_x.shape[0] * ctx.pre["c"] * (2 if ctx.x_needs_grad else 1) + rows * ctx.pre["side_n"]))
                     g = [dW, dbias]
                     if lp.bn:
                         g += [dbeta, dgamma]
@@ -297,7 +302,7 @@ class _MlpStack(torch.autograd.Function):
                                                        L.ptr(mean), L.ptr(var), L.ptr(lp.gamma if lp.bn else None), BN_EPS, int(lp.bn), int(is_training),
                                                        L.ptr(work), L.ptr(cA), L.ptr(cB), L.ptr(cC), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dbias),
                                                        None if (DEFER_DW or fuse_dw) else L.ptr(dW), st), "mlp_bwd_wgrad")
-                _toc(ev, "wgrad", rows, cin, cout)
+                _toc(ev, "wgrad", rows, cin, cout, None if ran_known else 2 * 2.0 * rows * cin * cout)      # the two-product form: G1 and Gx
                 if DEFER_DW and gather0 is None:
                     if side is None:
                         side = _side_stream(dev)
@@ -322,7 +327,7 @@ class _MlpStack(torch.autograd.Function):
                     ev = _tic()
                     L.check(lib.gspn_mlp_bwd_data_cols(rows, cin, cout, ctypes.byref(a), L.ptr(lp.weights), 3 if xf else 0, gc, L.ptr(dxg), ldp, st),
                             "mlp_bwd_data_cols")
-                    _toc(ev, "bwd", rows, cin, cout)
+                    _toc(ev, "bwd", rows, cin, cout, 2.0 * rows * gc * cout)
                     gp = torch.empty((gb, gn, gc), dtype=torch.float32, device=dev)
                     if gather0.get("order") is not None:
                         L.check(lib.gspn_sa_group_concat_grad_csr(gb, gn, gc, gm, gns, L.ptr(gather0["order"]), L.ptr(gather0["offsets"]), xf, ldp,
@@ -377,7 +382,7 @@ class _MlpStack(torch.autograd.Function):
                     else:
                         L.check(lib.gspn_mlp_bwd_data_cols(rows, cin, cout, ctypes.byref(a), L.ptr(lp.weights), int(gc[0]), int(gc[1]), L.ptr(dx),
                                                            dx.shape[1], st), "mlp_bwd_data_cols")
-                    _toc(ev, "bwd", rows, cin, cout)
+                    _toc(ev, "bwd", rows, cin, cout, 2.0 * rows * int(gc[1]) * cout)
                     if li == 0:
                         dx0 = dx
                     dz, ldz = dx, dx.shape[1]

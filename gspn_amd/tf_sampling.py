@@ -95,8 +95,7 @@ def farthest_point_sample(npoint, inp, return_order=False):
                 word = ws.view(torch.int32)[int(lib.gspn_fps_multi_status_offset(b, n)) // 4:][:1]
                 host = torch.empty(1, dtype=torch.int32, pin_memory=True)
                 host.copy_(word, non_blocking=True)
-                ev = torch.cuda.current_stream().record_event()
-                L.register_async_status(host, ev, "farthest_point_sample(multi-CU, b=%d, n=%d, m=%d)" % (b, n, npoint))
+                L.register_async_status(host, torch.cuda.current_stream().record_event(), "farthest_point_sample(multi-CU, b=%d, n=%d, m=%d)" % (b, n, npoint))
                 if FPS_MULTI_SYNC_CHECK:
                     L.check_async(block=True)
         elif FPS_MODE == "cells" and FPS_CELLS_MIN_N <= n:

@@ -72,7 +72,7 @@ def fragile_entries(zs, ns):
     return near | frag_rows[win_row] | win_small, frag_rows
 
 
-def check_stack(rows, ld, cin, chans, ns, training, ref_device="cpu", neg_gamma=False, max_fragile=0.05):
+def check_stack(rows, ld, cin, chans, ns, training, ref_device="cpu", neg_gamma=False, max_fragile=0.02):
     """mlp_stack forward + backward against oracle/mlp_ref.py evaluated in float64 on `ref_device`"""
     from gspn_amd.mlp import mlp_stack
     g = torch.Generator().manual_seed(rows + cin)
@@ -125,7 +125,7 @@ def check_stack(rows, ld, cin, chans, ns, training, ref_device="cpu", neg_gamma=
     frac = float(fragile.float().mean())
     print("check_stack rows=%d cin=%d chans=%s ns=%s: fragile (silenced) gradient entries %.3f %% of %d; rows left out of the dX comparison %.3f %%"
           % (rows, cin, chans, ns, 100 * frac, fragile.numel(), 100 * float(frag_rows.float().mean())))
-    # measured on MI355X at every shape of this file: <= 1.2 % (printed above); the cap is that + margin
+    # measured on MI355X at every shape of this file: <= 0.8 % (printed above; round 2's group-level rule: up to 20 %); the cap is that + margin
     assert frac <= max_fragile or int(fragile.sum()) <= 4, "too many fragile gradient entries: %.3f %% (cap %.1f %%)" % (100 * frac, 100 * max_fragile)
     assert out.shape == ref.shape
     assert rel_err(out, ref) < 1e-5
