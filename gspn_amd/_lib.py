@@ -9,7 +9,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgspn_hip.so")
+# GSPN_HIP_LIB: load another build of the same ABI instead (tools/: kernel ablation / variant libraries built by gspn_amd.build.build(variant=...))
+LIB_PATH = os.environ.get("GSPN_HIP_LIB") or os.path.join(_HERE, "lib", "libgspn_hip.so")
 
 _c = ctypes
 _P = _c.c_void_p

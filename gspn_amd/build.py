@@ -44,7 +44,7 @@ def policy_lib_path(policy):
     return os.path.join(LIBDIR, "libgspn_hip_p%d.so" % policy)
 
 
-def build(force=False, verbose=False, policy=None):
+def build(force=False, verbose=False, policy=None, variant=None, extra_flags=()):
     """policy=None: the product library (GSPN_DIST_POLICY 2, common.h).  policy=0/1/2: a VARIANT library
     lib/libgspn_hip_p<policy>.so holding only the policy-dependent translation units (FPS, ball query / grouping, nn_distance), built
     with -DGSPN_DIST_POLICY=<policy> into its own object directory -- test infrastructure for tests/test_gpu_policy.py; the product
@@ -58,6 +58,9 @@ def build(force=False, verbose=False, policy=None):
         flags.append("-DGSPN_DIST_POLICY=%d" % policy)
         obj_dir, lib_path = os.path.join(OBJ, "p%d" % policy), policy_lib_path(policy)
         srcs = [s for s in srcs if os.path.basename(s) in POLICY_SOURCES]
+    if variant is not None:                      # tools/: a complete library built with extra -D switches (kernel ablations), own object directory
+        flags += list(extra_flags)
+        obj_dir, lib_path = os.path.join(OBJ, "v_" + variant), os.path.join(LIBDIR, "libgspn_hip_%s.so" % variant)
     os.makedirs(obj_dir, exist_ok=True)
     hipcc = _hipcc()
     jobs = []

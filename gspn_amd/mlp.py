@@ -20,7 +20,7 @@ BN_EPS = 1e-3      # tf.contrib.layers.batch_norm default epsilon (tf_util.py:52
 # optimiser and cannot fill the chip (latency-bound); DEFER_DW = True puts it on a side stream where it overlaps the next layer's
 # kernels.  Off by default: inside a captured step the fork becomes a multi-branch hipGraph, and ROCm 7.2 replays those far slower
 # than a linear graph (measured on MI355X: 3.9 -> 6.6 ms per step), which costs more than the ~0.2 ms of overlap gains.
-DEFER_DW = False
+DEFER_DW = os.environ.get("GSPN_DEFER_DW", "0") == "1"
 # max-pool over nsample = 32 rows taken from the last layer's accumulators (gspn_mlp_fwd_pool32 + gspn_pool32_select) instead of a pass
 # over the (rows, c) output
 FUSE_POOL32 = os.environ.get("GSPN_FUSE_POOL32", "1") != "0"
