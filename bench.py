@@ -57,12 +57,16 @@ def main():
     ap.add_argument("--sync-bn", action="store_true", help="optional SyncBN (global-batch statistics, SURVEY 8e): unfused layers + two small "
                     "all-reduces per layer, no hipGraph; NOT the headline configuration")
     ap.add_argument("--no-extra", action="store_true", help="skip the post-run legs (per-kernel rooflines of the layers / ball query, other_configs)")
+    ap.add_argument("--legs-only", action="store_true", help="(internal) run the post-run legs alone and print their JSON: roofline_mlp, other_configs, "
+                    "roofline_ops, reference_harness -- bench.py runs itself with this flag in a child process")
     ap.add_argument("--force-collective", action="store_true", help="issue the gradient all-reduce through RCCL even at world size 1 (one-rank "
                     "communicator, identity result): the collective path of the N>1 runs, executed on a single GPU; the line then carries `collective`")
     ap.add_argument("--collective-in-graph", action="store_true", help="capture the all-reduce as the last node of the captured step instead of "
                     "issuing it after the replay (diagnostic: the default placement is after the graph)")
     args = ap.parse_args()
 
+    if args.legs_only:
+        return legs_main(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: re-run under torch.distributed.run, one rank per GPU (the driver's own form)
         import socket
@@ -430,29 +434,63 @@ def main():
                 res["roofline_ball_query"] = ball_query_roofline(bq_prof, batches, G if use_graph else None)
             except Exception as e:                                  # the extra legs never take the headline line down with them
                 res["roofline_ball_query"] = {"error": repr(e)}
-            try:
-                res["roofline_mlp"] = mlp_roofline(mlp_mod, lambda: fwd_bwd(0, G[0] if use_graph else pn2_geometry(batches[0][0])), state)
-            except Exception as e:
-                res["roofline_mlp"] = {"error": repr(e)}
-            try:
-                res["other_configs"] = other_configs(batches[0][0], batches[0][1], dev)
-            except Exception as e:
-                res["other_configs"] = {"error": repr(e)}
-            try:
-                res["roofline_ops"] = ops_roofline(batches[0][0], G[0] if use_graph else pn2_geometry(batches[0][0]), dev)
-            except Exception as e:
-                res["roofline_ops"] = {"error": repr(e)}
-            if not args.no_cpu_baseline:
-                try:
-                    res["reference_harness"] = reference_harness(dev)
-                except Exception as e:
-                    res["reference_harness"] = {"error": repr(e)}
+            # The remaining legs (per-kernel rooflines of the layers and of the stand-alone ops, the other configs, the reference's own
+            # harness shapes) run in a CHILD process: whatever happens there -- an exception, a crash, a hang -- the headline line above
+            # is printed.  (r03: a graph capture inside one of these legs segfaulted and the run printed nothing at all.)
+            res.update(run_legs_in_child(args))
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(xyz_np0, col_np0)
         print(json.dumps(res), flush=True)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+
+
+def run_legs_in_child(args, timeout=900):
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--legs-only"] + (["--no-cpu-baseline"] if args.no_cpu_baseline else [])
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"extra_legs": {"error": "child exited with code %d" % r.returncode, "stderr_tail": r.stderr[-600:]}}
+        return json.loads(lines[-1])
+    except subprocess.TimeoutExpired:
+        return {"extra_legs": {"error": "child timed out after %d s" % timeout}}
+    except Exception as e:
+        return {"extra_legs": {"error": repr(e)}}
+
+
+def legs_main(args):
+    """the post-run legs on a fresh process and device context (one GPU): each leg in its own try block, ONE JSON object on stdout"""
+    from gspn_amd import mlp as mlp_mod
+    from gspn_amd import parallel, tf_util
+    from gspn_amd.fea_extractor import pn2_fea_extractor, pn2_geometry
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(dev)
+    xyz_np, col_np = synth(SCENES_PER_GPU, NPOINTS, seed0=0)
+    xyz, col = torch.from_numpy(xyz_np).to(dev), torch.from_numpy(col_np).to(dev)
+    gout = torch.from_numpy(np.random.default_rng(777).standard_normal((SCENES_PER_GPU, NPOINTS, 64)).astype(np.float32)).to(dev) / (SCENES_PER_GPU * NPOINTS * 64)
+    store = tf_util.set_variable_store(tf_util.VariableStore(device=dev, seed=1234))
+    G0 = pn2_geometry(xyz)
+    state = {"opt": None}
+
+    def eager_step():
+        for p_ in store.parameters():
+            p_.grad = None
+        (pn2_fea_extractor(xyz, col, 'fea', True, 0.5, geometry=G0) * gout).sum().backward()
+    out = {}
+    for key, fn in (("roofline_mlp", lambda: mlp_roofline(mlp_mod, eager_step, state)),
+                    ("other_configs", lambda: other_configs(xyz, col, dev)),
+                    ("roofline_ops", lambda: ops_roofline(xyz, G0, dev))) + \
+                   (() if args.no_cpu_baseline else (("reference_harness", lambda: reference_harness(dev)),)):
+        try:
+            out[key] = fn()
+        except Exception as e:
+            out[key] = {"error": repr(e)}
+        torch.cuda.synchronize()
+    print(json.dumps(out), flush=True)
+    return 0
 
 
 def collective_leg(bucket, world, forced, placement, reps=50):
@@ -511,7 +549,8 @@ def mlp_roofline(mlp_mod, eager_step, state, reps=3):
     """The shared-MLP GEMM kernels of one fwd+bwd step (16 layers: forward, weight-gradient pass A, data-gradient pass B), each launch
     bracketed by HIP events on its stream in `reps` eager (un-captured) steps run after the timed region.  flops = SURVEY 8(d):
     2*rows*cin*cout per GEMM, x3 for fwd+bwd."""
-    eager_step()                                       # warm
+    for _ in range(5):                                 # warm: variables, per-kernel attributes, the caching allocator's pool (this runs in a fresh process)
+        eager_step()
     torch.cuda.synchronize()
     mlp_mod.PROFILE = []
     try:
@@ -607,6 +646,8 @@ def ops_roofline(xyz, geo, dev, timer=None):
     from gspn_amd.tf_interpolate import three_interpolate, three_nn
     from gspn_amd.tf_nndistance import nn_distance
     from gspn_amd.tf_sampling import gather_point
+    from gspn_amd import _lib as L
+    lib = L.lib()
     pmc = _pmc_ops()
     gen = torch.Generator(device=dev).manual_seed(21)
     b = xyz.shape[0]
@@ -621,6 +662,7 @@ def ops_roofline(xyz, geo, dev, timer=None):
         out.append({"op": name, "shape": shape, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": ms, "achieved": ach,
                     "frac": ach / HBM_PEAK_GBS, "traffic": pmc.get(key or name), "bound_by": bound_by})
 
+    torch.set_grad_enabled(False)            # forward launches and direct C-ABI gradient launches only: nothing here records an autograd graph
     lv = [xyz, geo["sa"][0].new_xyz, geo["sa"][1].new_xyz, geo["sa"][2].new_xyz]
     # three_nn (tf_interpolate.cpp:60-103): 12*b*n*m + 36*b*n
     for d, s_ in ((0, 1), (1, 2), (2, 3)):
@@ -633,47 +675,53 @@ def ops_roofline(xyz, geo, dev, timer=None):
     for (d, s_, c2, c1, k) in ((0, 1, 128, 3, 2), (1, 2, 256, 64, 1), (2, 3, 256, 128, 0)):
         n, m = lv[d].shape[1], lv[s_].shape[1]
         fpg = geo["fp"][k]
-        p2 = torch.randn(b, m, c2, device=dev, generator=gen).requires_grad_(True)
+        p2 = torch.randn(b, m, c2, device=dev, generator=gen)
         p1 = torch.randn(b, n, c1, device=dev, generator=gen)
         go = torch.randn(b, n, c2, device=dev, generator=gen)
-        add("three_interpolate", "%dx%d<-%d, c=%d" % (b, n, m, c2), 1.0 * b * n * (24 + 16 * c2), lambda: three_interpolate(p2.detach(), fpg.idx, fpg.weight),
+        add("three_interpolate", "%dx%d<-%d, c=%d" % (b, n, m, c2), 1.0 * b * n * (24 + 16 * c2), lambda: three_interpolate(p2, fpg.idx, fpg.weight),
             "memory: one coalesced (n, c) write, three L2-resident row reads per point", "three_interpolate_%d" % n)
-        o = three_interpolate(p2, fpg.idx, fpg.weight)
-        add("three_interpolate_grad", "%dx%d->%d, c=%d (scatter-add, hardware fp32 atomics)" % (b, n, m, c2), 1.0 * b * n * (24 + 16 * c2), lambda: torch.autograd.grad(o, p2, go, retain_graph=True),
+        gp2 = torch.empty_like(p2)
+        add("three_interpolate_grad", "%dx%d->%d, c=%d (scatter-add, hardware fp32 atomics)" % (b, n, m, c2), 1.0 * b * n * (24 + 16 * c2),
+            lambda: L.check(lib.gspn_threeinterpolate_grad(b, n, c2, m, L.ptr(go), L.ptr(fpg.idx), L.ptr(fpg.weight), L.ptr(gp2), L.stream()), "three_interpolate_grad"),
             "L2 atomic throughput: 3*c atomic adds per dense point onto m*c addresses", "three_interpolate_grad_%d" % n)
-        o2 = fp_concat(p2, fpg.idx, fpg.weight, p1, fpg.order, fpg.offsets)
-        g2 = torch.randn_like(o2)
-        add("fp_concat (interpolate + concat, fused)", "%dx%d<-%d, c2=%d c1=%d" % (b, n, m, c2, c1), 1.0 * b * n * (24 + 16 * c2 + 8 * c1), lambda: fp_concat(p2.detach(), fpg.idx, fpg.weight, p1, fpg.order, fpg.offsets),
+        ld2 = (c2 + c1 + 3) // 4 * 4
+        g2 = torch.randn(b * n, ld2, device=dev, generator=gen)
+        add("fp_concat (interpolate + concat, fused)", "%dx%d<-%d, c2=%d c1=%d" % (b, n, m, c2, c1), 1.0 * b * n * (24 + 16 * c2 + 8 * c1), lambda: fp_concat(p2, fpg.idx, fpg.weight, p1, fpg.order, fpg.offsets),
             "memory: one write of the (n, c2+c1) input matrix", "fp_concat_%d" % n)
-        add("fp_concat_grad (gather over inverse lists, no atomics)", "%dx%d->%d, c2=%d" % (b, n, m, c2), 1.0 * b * n * (24 + 16 * c2), lambda: torch.autograd.grad(o2, p2, g2, retain_graph=True),
+        add("fp_concat_grad (gather over inverse lists, no atomics)", "%dx%d->%d, c2=%d" % (b, n, m, c2), 1.0 * b * n * (24 + 16 * c2),
+            lambda: L.check(lib.gspn_fp_concat_grad_csr(b, n, m, c2, c1, ld2, L.ptr(g2), L.ptr(fpg.order), L.ptr(fpg.offsets), L.ptr(fpg.weight), L.ptr(gp2), None,
+                                                        L.stream()), "fp_concat_grad_csr"),
             "dependent-load latency of the inverse-list walk (one wave per sparse point x 64 channels)", "fp_concat_grad_%d" % n)
-        del o, o2
     # group_point (+grad) (tf_grouping_g.cu:43-83): b*m*ns*(4 + 8*c); gather_point (tf_sampling_g.cu:172-192)
     feats = [3, 64, 128]
     for lvl in range(3):
         sa = geo["sa"][lvl]
         n, m, ns, c = lv[lvl].shape[1], sa.idx.shape[1], sa.idx.shape[2], feats[lvl]
-        pts = torch.randn(b, n, c, device=dev, generator=gen).requires_grad_(True)
-        add("group_point", "%dx%d -> (%d,%d), c=%d" % (b, n, m, ns, c), 1.0 * b * m * ns * (4 + 8 * c), lambda: group_point(pts.detach(), sa.idx),
+        pts = torch.randn(b, n, c, device=dev, generator=gen)
+        add("group_point", "%dx%d -> (%d,%d), c=%d" % (b, n, m, ns, c), 1.0 * b * m * ns * (4 + 8 * c), lambda: group_point(pts, sa.idx),
             "memory: the (m, ns, c) write; gathered rows are L2 hits" if c >= 64 else "write coalescing: 12-byte rows", "group_point_%d" % n)
-        o = group_point(pts, sa.idx)
-        go = torch.randn_like(o)
-        add("group_point_grad", "(%d,%d) -> %dx%d, c=%d (scatter-add, hardware fp32 atomics)" % (m, ns, b, n, c), 1.0 * b * m * ns * (4 + 8 * c), lambda: torch.autograd.grad(o, pts, go, retain_graph=True),
+        go = torch.randn(b, m, ns, c, device=dev, generator=gen)
+        gpts = torch.empty(b, n, c, device=dev)
+        add("group_point_grad", "(%d,%d) -> %dx%d, c=%d (scatter-add, hardware fp32 atomics)" % (m, ns, b, n, c), 1.0 * b * m * ns * (4 + 8 * c),
+            lambda: L.check(lib.gspn_grouppoint_grad(b, n, c, m, ns, L.ptr(go), L.ptr(sa.idx), L.ptr(gpts), L.stream()), "group_point_grad"),
             "L2 atomic throughput", "group_point_grad_%d" % n)
-        del o
     fidx = geo["sa"][0].idx[:, :, 0].contiguous()
     add("gather_point", "%dx%d -> %d" % (b, xyz.shape[1], fidx.shape[1]), 1.0 * b * fidx.shape[1] * (4 + 24), lambda: gather_point(xyz, fidx), "launch latency (590 KB moved)", "gather_point")
     # nn_distance (+grad) (tf_nndistance_g.cu:5-151): 12*b*(2*n*m) + 8*b*(n+m); grad b*(n+m)*56
     for (nb, n, m) in ((256 * b, 512, 512), (32, 16384, 1024)):
-        a = torch.randn(nb, n, 3, device=dev, generator=gen).requires_grad_(True)
-        c_ = torch.randn(nb, m, 3, device=dev, generator=gen).requires_grad_(True)
-        add("nn_distance", "%d clouds x (%d, %d)" % (nb, n, m), 12.0 * nb * 2 * n * m + 8.0 * nb * (n + m), lambda: nn_distance(a.detach(), c_.detach()),
+        a = torch.randn(nb, n, 3, device=dev, generator=gen)
+        c_ = torch.randn(nb, m, 3, device=dev, generator=gen)
+        add("nn_distance", "%d clouds x (%d, %d)" % (nb, n, m), 12.0 * nb * 2 * n * m + 8.0 * nb * (n + m), lambda: nn_distance(a, c_),
             "VALU issue: 7 instructions per point pair from LDS tiles (the clouds are on-chip; 38 MB of input for 2048 clouds)", "nn_distance_%d" % n)
-        d1, _, d2, _ = nn_distance(a, c_)
+        with torch.no_grad():
+            d1, i1, d2, i2 = nn_distance(a.detach(), c_.detach())
         g1, g2 = torch.randn_like(d1), torch.randn_like(d2)
-        add("nn_distance_grad", "%d clouds x (%d, %d) (scatter-add, hardware fp32 atomics)" % (nb, n, m), 56.0 * nb * (n + m), lambda: torch.autograd.grad([d1, d2], [a, c_], [g1, g2], retain_graph=True),
+        ga, gc = torch.empty_like(a), torch.empty_like(c_)
+        add("nn_distance_grad", "%d clouds x (%d, %d) (scatter-add, hardware fp32 atomics)" % (nb, n, m), 56.0 * nb * (n + m),
+            lambda: L.check(lib.gspn_nmdistance_grad(nb, n, L.ptr(a), m, L.ptr(c_), L.ptr(g1), L.ptr(i1), L.ptr(g2), L.ptr(i2), L.ptr(ga), L.ptr(gc), L.stream()),
+                            "nn_distance_grad"),
             "L2 atomic throughput + two memsets", "nn_distance_grad_%d" % n)
-        del d1, d2
+    torch.set_grad_enabled(True)
     return {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
             "achieved_is": "effective rate = SURVEY 8(d) algorithmic bytes / stand-alone launch time (HIP events, 20 calls, idle chip); traffic = PMC "
                            "memory-side bytes per launch (profiles/r03_ops_pmc.json) or null",
@@ -712,15 +760,20 @@ def reference_harness(dev):
     tp, t1, t2 = (torch.from_numpy(a).to(dev) for a in (pts, x1, x2))
     dist, idx = three_nn(t1, t2)
     w = torch.full_like(dist, 1.0 / 3.0)                   # tf_interpolate.py:48
-    tpg = tp.clone().requires_grad_(True)
-    o = three_interpolate(tpg, idx, w)
+    from gspn_amd import _lib as L
+    lib = L.lib()
+    with torch.no_grad():
+        o = three_interpolate(tp, idx, w)
     go = torch.randn_like(o)
+    gtp = torch.empty_like(tp)
     idx_np, w_np, go_np = idx.cpu().numpy(), w.cpu().numpy(), go.cpu().numpy()
     have_ref = O.ref_lib() is not None
     ref_out = O.ref_three_interpolate(pts, idx_np, w_np) if have_ref else None
     leg = {"shape": "b=32, n=512, m=128, c=64 (interpolate.cpp:134; tf_interpolate.py:40-47)",
            "hip_ms": {"three_nn": _ev_time(lambda: three_nn(t1, t2), 3, 50), "three_interpolate": _ev_time(lambda: three_interpolate(tp, idx, w), 3, 50),
-                      "three_interpolate_grad": _ev_time(lambda: torch.autograd.grad(o, tpg, go, retain_graph=True), 3, 50)},
+                      # (gradient launches go straight through the C ABI: an autograd backward inside a stream capture crashes this torch build)
+                      "three_interpolate_grad": _ev_time(lambda: L.check(lib.gspn_threeinterpolate_grad(32, 512, 64, 128, L.ptr(go), L.ptr(idx), L.ptr(w), L.ptr(gtp),
+                                                                                                        L.stream()), "three_interpolate_grad"), 3, 50)},
            "cpu_ms": {"three_nn": best(lambda: O.three_nn(x1, x2)),
                       "three_interpolate": best(lambda: (O.ref_three_interpolate if have_ref else O.three_interpolate)(pts, idx_np, w_np)),
                       "three_interpolate_grad": best(lambda: (O.ref_three_interpolate_grad if have_ref else O.three_interpolate_grad)(pts, idx_np, w_np, go_np))},
@@ -728,20 +781,23 @@ def reference_harness(dev):
                         "three_interpolate": "reference (oracle/_ref: interpolate.cpp compiled as is)" if have_ref else "port",
                         "three_interpolate_grad": "reference (oracle/_ref)" if have_ref else "port"},
            "cores": 1,
-           "hip_equals_reference_bits": bool(have_ref and np.array_equal(o.detach().cpu().numpy(), ref_out))}
+           "hip_equals_reference_bits": bool(have_ref and np.array_equal(o.cpu().numpy(), ref_out))}
     leg["tf_interpolate.py loop (100 x three_interpolate)"] = {"hip_ms": 100 * leg["hip_ms"]["three_interpolate"], "cpu_ms": 100 * leg["cpu_ms"]["three_interpolate"]}
     res["3d_interpolation"] = leg
     # ---- tf_nndistance.py ----
     rng = np.random.RandomState(100)
     a = rng.randn(32, 16384, 3).astype(np.float32)
     c = rng.randn(32, 1024, 3).astype(np.float32)
-    ta = torch.from_numpy(a).to(dev).requires_grad_(True)
+    ta = torch.from_numpy(a).to(dev)
     tc = torch.from_numpy(c).to(dev)
+    one1, one2 = torch.ones(32, 16384, device=dev), torch.ones(32, 1024, device=dev)   # d loss / d dist: loss = reduce_sum(reta) + reduce_sum(retc), tf_nndistance.py:59
+    ga, gc = torch.empty_like(ta), torch.empty_like(tc)
 
     def hip_step():
-        d1, _, d2, _ = nn_distance(ta, tc)
-        (d1.sum() + d2.sum()).backward()                   # loss = reduce_sum(reta) + reduce_sum(retc), tf_nndistance.py:59
-        ta.grad = None
+        with torch.no_grad():
+            d1, i1, d2, i2 = nn_distance(ta, tc)
+        L.check(lib.gspn_nmdistance_grad(32, 16384, L.ptr(ta), 1024, L.ptr(tc), L.ptr(one1), L.ptr(i1), L.ptr(one2), L.ptr(i2), L.ptr(ga), L.ptr(gc), L.stream()),
+                "nn_distance_grad")
 
     def cpu_step():
         d1, i1, d2, i2 = O.nn_distance(a, c, cpu_twin=True)

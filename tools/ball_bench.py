@@ -1,6 +1,6 @@
 """ball query: wave-per-query over the L2-resident scene (default) vs LDS-staged tiles shared by a workgroup; same output required"""
 import sys, numpy as np, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import bench
 from gspn_amd import _lib as L
 from gspn_amd.tf_sampling import farthest_point_sample, gather_point

@@ -1,7 +1,7 @@
 """pass B kernel alone (gspn_mlp_bwd_data_ex: dX = dY.W^T with dY rebuilt from (dz, Y) or the pool arg-max, the previous layer's BN reductions in
 the epilogue) at the bench's layer shapes: microseconds, TB/s of algorithmic bytes, TFLOP/s (library chosen by GSPN_HIP_LIB)"""
 import ctypes, os, sys, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from gspn_amd import _lib as L
 lib = L.lib(); dev = torch.device('cuda', 0)
 # (rows, cin, cout, pool_ns)

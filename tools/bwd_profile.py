@@ -1,7 +1,7 @@
 """phase breakdown of the register-staged pass B kernel (library built with -DABL_BWD_PROFILE): cycles per (tile, chunk) step in the MFMA
 loop, the tile epilogue, commit (transform + LDS writes; waits for the loads), the fetch issue and the barrier"""
 import ctypes, os, sys, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from gspn_amd import _lib as L
 lib = L.lib(); dev = torch.device('cuda', 0)
 for rows, cin, cout in [(262144, 64, 64), (131072, 64, 64), (32768, 128, 128), (16384, 192, 128), (4096, 384, 256), (4096, 256, 128)]:

@@ -1,6 +1,6 @@
 """BASELINE configs[3] per-GPU shard (multi_encoding_net + Chamfer, fwd+bwd) alone, a few steps: target of rocprofv3 --stats"""
 import sys, numpy as np, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import bench
 from gspn_amd import tf_util
 from gspn_amd.proposal_head import chamfer_recons_loss, multi_encoding_net

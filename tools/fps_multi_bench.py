@@ -5,7 +5,7 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from gspn_amd import _lib as L  # noqa: E402
 from gspn_amd import tf_sampling  # noqa: E402
 

@@ -1,7 +1,7 @@
 """the roofline kernel alone: FPS of SA level 1 (8 x n -> 2048), a few launches (target of the PMC passes).
 usage: fps_only.py [launches] [n]   (n = 32768: single-CU cell kernel; n > 32768: multi-CU kernel)"""
 import sys, numpy as np, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import bench
 from gspn_amd.tf_sampling import farthest_point_sample
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 32768

@@ -1,6 +1,6 @@
 """wall time of the FPS of each SA level of the bench (torch events, 20 launches each)"""
 import sys, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import bench
 from gspn_amd.tf_sampling import farthest_point_sample
 for n, m in ((32768, 2048), (2048, 512), (512, 128), (16384, 1024), (8192, 2048)):

@@ -1,6 +1,6 @@
 """forward GEMM kernel alone at chosen layer shapes: microseconds, TB/s of algorithmic bytes, TFLOP/s (library chosen by GSPN_HIP_LIB)"""
 import os, sys, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from gspn_amd import _lib as L
 lib = L.lib(); dev = torch.device('cuda', 0)
 shapes = [(262144, 64, 64), (524288, 32, 64), (524288, 32, 32), (131072, 64, 128), (131072, 64, 64), (32768, 128, 128), (32768, 128, 256), (16384, 192, 128), (4096, 384, 256), (4096, 256, 128)]

@@ -1,7 +1,7 @@
 """phase breakdown of the streaming forward kernel (library built with -DABL_FWD_PROFILE): cycles per tile iteration spent waiting for the
 tile (vmcnt + barrier), issuing the next tile's DMA, in the previous tile's epilogue (stores + statistics) and in the k loop"""
 import os, sys, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from gspn_amd import _lib as L
 lib = L.lib(); dev = torch.device('cuda', 0)
 for rows, cin, cout in [(262144, 64, 64), (524288, 32, 64), (524288, 32, 32), (131072, 64, 128), (131072, 64, 64)]:

@@ -1,6 +1,6 @@
 """sweep the column-tile width of the register-staged forward / pass-B kernels (GSPN_FWD_FORCE_BN / GSPN_BWD_FORCE_BN) at the bench layer shapes"""
 import ctypes, os, sys, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from gspn_amd import _lib as L
 lib = L.lib(); st = L.stream()
 shapes = [("SA2-L1", 131072, 68, 67, 64), ("SA2-L3p", 131072, 64, 64, 128),

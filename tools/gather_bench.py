@@ -1,6 +1,6 @@
 """first SA layer, materialised rows (sa_group_concat + mlp_fwd / wgrad) vs gathered rows (mlp_fwd_gather / wgrad_gather), stand-alone"""
 import ctypes, sys, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from gspn_amd import _lib as L
 from gspn_amd.geometry import sa_geometry
 lib = L.lib()

@@ -1,7 +1,7 @@
 """cProfile of the host side of one training step (where does the enqueue time go?)"""
 import cProfile, pstats, sys, io, time
 import numpy as np, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import bench
 from gspn_amd import parallel, tf_util
 from gspn_amd.fea_extractor import pn2_fea_extractor, pn2_geometry

@@ -3,7 +3,7 @@ kind, shape, microseconds, algorithmic bytes / flops, TB/s, TFLOP/s, and the rat
 streaming rate, 157.3 TF).  usage: layer_table.py [reps]"""
 import sys
 import numpy as np, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import bench
 from gspn_amd import mlp as M, tf_util
 from gspn_amd.fea_extractor import pn2_fea_extractor, pn2_geometry

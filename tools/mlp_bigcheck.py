@@ -1,6 +1,6 @@
 """debug: where does the dX error of a bench-size stack sit? (rows near a ReLU kink, or spread over all rows)"""
 import sys, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from tests import test_gpu_mlp as T
 from oracle import mlp_ref as R
 from gspn_amd.mlp import mlp_stack

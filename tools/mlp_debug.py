@@ -1,6 +1,6 @@
 """per-layer gradient errors of mlp_stack vs the fp64 restatement (debug aid)"""
 import sys, torch
-sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))); sys.path.insert(0, 'tests')
 from oracle import mlp_ref as R
 from test_gpu_mlp import make_params, to_layers, rel_err
 from gspn_amd.mlp import mlp_stack

@@ -1,6 +1,6 @@
 """three_nn at the bench's FP shapes (torch events after a clock warm-up, us per call)"""
 import sys, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from gspn_amd import tf_interpolate
 from gspn_amd.tf_sampling import farthest_point_sample, gather_point
 import bench

@@ -1,6 +1,6 @@
 """three_nn with the dense points taken in Morton order vs the given order (kernel time by torch events, 50 launches)"""
 import sys, ctypes, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from gspn_amd import _lib as L
 from gspn_amd.tf_sampling import farthest_point_sample, gather_point
 import bench

@@ -2,7 +2,7 @@
 (three_nn_weights_kernel on 256*(k+101) elements; the geometry itself launches that kernel on 4096 / 16384 / 262144): the target of the PMC passes of tools/pmc_ops.sh.  Prints the key table."""
 import ctypes, json, sys
 import torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import bench
 from gspn_amd import _lib as L
 from gspn_amd.fea_extractor import pn2_geometry

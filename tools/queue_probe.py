@@ -1,7 +1,7 @@
 """cost of a busy second HW queue on a chain of dependent kernels: N launches of an elementwise kernel (graph-replayed) with and
 without a long single-workgroup kernel running on another stream"""
 import sys, time, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from gspn_amd.tf_sampling import farthest_point_sample
 dev = torch.device('cuda', 0)
 xyz1 = torch.rand(1, 32768, 3, device=dev)

@@ -1,5 +1,5 @@
 import sys, time, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from gspn_amd import tf_sampling
 from gspn_amd.tf_sampling import farthest_point_sample
 dev = torch.device('cuda', 0)

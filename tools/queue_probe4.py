@@ -1,6 +1,6 @@
 """which layer kernels does a concurrent FPS launch slow down?  chains of one MLP kernel (graph-replayed) with / without FPS on a side stream"""
 import ctypes, sys, time, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from gspn_amd import _lib as L
 from gspn_amd.tf_sampling import farthest_point_sample
 lib = L.lib(); dev = torch.device('cuda', 0)

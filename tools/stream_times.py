@@ -1,6 +1,6 @@
 """how long does each stream need per step? geometry alone, layers alone (graph replay + eager tail), and both overlapped"""
 import sys, time, numpy as np, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import bench
 from gspn_amd import parallel, tf_util
 from gspn_amd.fea_extractor import pn2_fea_extractor, pn2_geometry

@@ -1,6 +1,6 @@
 """time gspn_mlp_bwd_wgrad / bwd_data / fwd at the bench layer shapes (torch events), report effective GB/s"""
 import ctypes, sys, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from gspn_amd import _lib as L
 lib = L.lib(); st = L.stream()
 shapes = [("SA1-L1", 524288, 8, 6, 32, False), ("SA1-L2", 524288, 32, 32, 32, False), ("SA1-L3p", 524288, 32, 32, 64, True),

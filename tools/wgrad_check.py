@@ -1,6 +1,6 @@
 """direct check of gspn_mlp_bwd_wgrad against fp64 torch: r0, r1, g3 (read from the workspace) and dW"""
 import ctypes, sys, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from gspn_amd import _lib as L
 lib = L.lib(); st = L.stream()
 torch.manual_seed(0)

@@ -1,6 +1,6 @@
 """wgrad main-kernel time vs rows for a few (cin, cout, pooled) shapes: slope (per-row cost) and intercept (fixed overhead)"""
 import ctypes, sys, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from gspn_amd import _lib as L
 lib = L.lib(); st = L.stream()
 def run(rows, ldx, cin, cout, pooled, tr=1):

@@ -1,6 +1,6 @@
 """sweep the wgrad tile shape / chunk count (GSPN_WGRAD_FORCE) for the small-row layers of the bench stack; prints us per gspn_mlp_bwd_wgrad"""
 import ctypes, os, sys, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from gspn_amd import _lib as L
 lib = L.lib(); st = L.stream()
 shapes = [("SA3-L1", 32768, 132, 131, 128, False), ("SA3-L2", 32768, 128, 128, 128, False), ("SA3-L3p", 32768, 128, 128, 256, True),
