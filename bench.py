@@ -837,6 +837,31 @@ def _time_steps(fn, warm, reps):
     return (time.perf_counter() - t0) / reps
 
 
+def _fps_leg_roofline(step_fn, reps=3):
+    """FPS launches of `reps` runs of a leg, bracketed by HIP events (tf_sampling.PROFILE): the leg's dominant geometry kernel against
+    SURVEY 8(d)'s algorithmic bytes 20*b*(m-1)*n + 4*b*m"""
+    from gspn_amd import tf_sampling
+    tf_sampling.PROFILE, tf_sampling.PROFILE_BUDGET[0], tf_sampling.PROFILE_MIN_N = [], 1 << 30, 0
+    try:
+        for _ in range(reps):
+            step_fn()
+        torch.cuda.synchronize()
+        ev = tf_sampling.PROFILE
+    finally:
+        tf_sampling.PROFILE = None
+    if not ev:
+        return None
+    big = max(ev, key=lambda e: e[2] * e[3] * e[4])
+    same = [e for e in ev if e[2:] == big[2:]]
+    ms = float(np.mean([e[0].elapsed_time(e[1]) for e in same]))
+    b_, n_, m_ = big[2:]
+    alg = 20.0 * b_ * (m_ - 1) * n_ + 4.0 * b_ * m_
+    ach = alg / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "farthest point sampling %d x %d -> %d (largest FPS launch of the leg)" % (b_, n_, m_), "avg_launch_ms": ms,
+            "us_per_pick": ms * 1e3 / m_, "algorithmic_bytes_per_launch": alg, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "achieved_is": "effective rate = algorithmic bytes / time (on-chip resident kernel)"}
+
+
 def other_configs(xyz, col, dev):
     """Timed legs at the other BASELINE configs' per-GPU shapes (not the headline metric; same kernels, eager, geometry inline)."""
     from gspn_amd import tf_util
@@ -854,7 +879,7 @@ def other_configs(xyz, col, dev):
                 pointnet_sa_module(xyz, col, 1024, 0.1, 32, [64, 64, 128], None, False, True, 0.5, 'c1')
         t = _time_steps(c1, 3, 10)
         out["configs[1]"] = {"workload": "8 x 32768 pts, SA(1024, 0.1, 32, [64,64,128]) fwd only, FPS + ball query + group + 3 layers + max-pool inline on one stream",
-                             "ms_per_step": t * 1e3, "scenes_per_s": b / t}
+                             "ms_per_step": t * 1e3, "scenes_per_s": b / t, "roofline": _fps_leg_roofline(c1)}
         # configs[3], one GPU's shard (8 of the 32 scenes): multi_encoding_net (model_rpointnet.py:377) + Chamfer on 2048 x (512, 512) clouds
         tf_util.set_variable_store(tf_util.VariableStore(device=dev, seed=3))
         gen = torch.Generator(device=dev).manual_seed(9)
@@ -874,7 +899,11 @@ def other_configs(xyz, col, dev):
         gf = 3 * 2.0 * rows * (6 * 64 + 64 * 128 + 128 * 256)
         out["configs[3] per-GPU shard"] = {"workload": "8 x 32768 pts: multi_encoding_net(256 seeds, r .5/1/1.5, ns 256/256/512, mlp [64,128,256] x3, use_xyz) + "
                                                       "Chamfer nn_distance on 2048 x (512,512) clouds, fwd+bwd, eager, geometry inline",
-                                           "ms_per_step": t * 1e3, "scenes_per_s": b / t, "grouped_rows": rows, "mlp_TFLOPs_fwd_bwd_over_whole_step": gf / t / 1e12}
+                                           "ms_per_step": t * 1e3, "scenes_per_s": b / t, "grouped_rows": rows, "mlp_TFLOPs_fwd_bwd_over_whole_step": gf / t / 1e12,
+                                           "roofline": {"bound": "mfma_f32", "kernels": "the three 6 -> 64 -> 128 -> 256 stacks (forward, pass A, pass B): 3 x 2 x rows x (6*64 + 64*128 + "
+                                                        "128*256) flops over the WHOLE leg (geometry, pooling and Chamfer included in the time)",
+                                                        "achieved": gf / t / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": gf / t / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                                                        "per_kernel": "profiles/r03_c3_kernel_stats.csv, r03_c3_sq_pmc_by_kernel.txt, r03_c3_sq_insts_by_kernel.txt"}}
         # configs[4], one GPU's shard of the SA/FP part (8 of the 64 scenes): 65536-pt scenes through pn2_fea_extractor, fwd+bwd
         from gspn_amd.fea_extractor import pn2_fea_extractor
         tf_util.set_variable_store(tf_util.VariableStore(device=dev, seed=4))
@@ -890,7 +919,27 @@ def other_configs(xyz, col, dev):
             o.square().mean().backward()
         t = _time_steps(c4, 2, 5)
         out["configs[4] per-GPU shard (SA/FP part)"] = {"workload": "8 x 65536 pts: pn2_fea_extractor 3 x SA + 3 x FP fwd+bwd, eager, geometry inline (FPS on the multi-CU kernel, "
-                                                                    "4 CUs per scene)", "ms_per_step": t * 1e3, "scenes_per_s": b / t}
+                                                                    "4 CUs per scene)", "ms_per_step": t * 1e3, "scenes_per_s": b / t, "roofline": _fps_leg_roofline(c4)}
+        # configs[4], the proposal half on the same 65536-pt scenes: the context encoder as model_rpointnet.py:377 calls it (given seeds, a
+        # stop-gradient shift) + the Chamfer reconstruction loss (:1346-1355), fwd+bwd
+        tf_util.set_variable_store(tf_util.VariableStore(device=dev, seed=5))
+        from gspn_amd.tf_sampling import farthest_point_sample
+        seeds = farthest_point_sample(256, xyz5)
+        shift = torch.randn(b, 256, 3, device=dev, generator=gen) * 0.05
+
+        def c4p():
+            for p_ in tf_util.get_variable_store().parameters():
+                p_.grad = None
+            pred = pred0.clone().requires_grad_(True)
+            _, fea, _, _ = multi_encoding_net(xyz5, col5, 256, [0.5, 1.0, 1.5], [256, 256, 512], [[64, 128, 256]] * 3, [], True, 0.5, 'c4p', use_xyz=True,
+                                              shift_pred=shift, fps_idx=seeds)
+            (fea.mean() + chamfer_recons_loss(pred, gt, mask)).backward()
+        t = _time_steps(c4p, 2, 5)
+        out["configs[4] per-GPU shard (proposal part)"] = {"workload": "8 x 65536 pts: multi_encoding_net(256 given seeds, stop-gradient shift, r .5/1/1.5, ns 256/256/512, mlp "
+                                                                       "[64,128,256] x3, use_xyz) + Chamfer on 2048 x (512,512) clouds, fwd+bwd, eager", "ms_per_step": t * 1e3,
+                                                           "scenes_per_s": b / t,
+                                                           "roofline": {"bound": "mfma_f32", "achieved": gf / t / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                                                        "frac": gf / t / 1e12 / MFMA_F32_PEAK_TFLOPS, "kernels": "as configs[3]: the layers' flops over the whole leg"}}
     finally:
         tf_util.set_variable_store(keep)
         torch.cuda.empty_cache()

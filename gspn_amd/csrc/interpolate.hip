@@ -128,6 +128,96 @@ __global__ __launch_bounds__(NN_BLOCK) void three_nn_kernel(int b, int n, int m,
     }
     }
 }
+// ---- small known clouds (m <= NN_WAVE_MAX_M): one WAVE per query ------------------------------------------------------------
+// The thread-per-query kernel above walks the known cloud serially and is fast only once a query's third-best distance has dropped far
+// enough for the cheap rejection test to discard whole batches; on the small levels of the feature-propagation stack (2048 <- 512,
+// 512 <- 128) the known points come in farthest-point order -- coarse to fine -- so nearly every batch improves some query of the wave
+// and the exact path runs all the time: 76 / 27 us for 64 / 16 workgroups' worth of work (r03).  Here the known cloud of the scene
+// sits in REGISTERS, spread over the lanes of a wave (candidate k = lane + 64 i), every lane evaluates the reference's expression for
+// its <= NN_WAVE_P candidates of the wave's current query and keeps its own three best by the reference's rule (strict '<' in ascending
+// k), and three wave-wide (distance, index) minima pick the result: the three smallest pairs in (d, k) order are exactly what the
+// sequential cascade of tf_interpolate.cpp:69-89 leaves (ties keep the lower k).
+#define NN_WAVE_P 16
+#define NN_WAVE_MAX_M (64 * NN_WAVE_P)
+#define NN_WAVE_QPW 16            // queries per wave (sequential): amortises loading the known cloud into registers
+__device__ __forceinline__ int wave_min_i32(int v) {
+    v = min(v, dpp_i32<DPP_QUAD_XOR1>(v));
+    v = min(v, dpp_i32<DPP_QUAD_XOR2>(v));
+    v = min(v, dpp_i32<DPP_ROW_HALF_MIRROR>(v));
+    v = min(v, dpp_i32<DPP_ROW_MIRROR>(v));
+    const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16), c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    return min(min(a, b), min(c, d));
+}
+template <int P>
+__global__ __launch_bounds__(256) void three_nn_wave_kernel(int b, int n, int m, const float* __restrict__ xyz1, const float* __restrict__ xyz2,
+                                                            float* __restrict__ dist, int* __restrict__ idx, int wpscene) {
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);           // global wave: (scene, run of NN_WAVE_QPW queries)
+    const int scene = gw / wpscene;
+    if (scene >= b) return;
+    const int q0 = (gw - scene * wpscene) * NN_WAVE_QPW;
+    const float* sp = xyz2 + (size_t)scene * m * 3;
+    float px[P], py[P], pz[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        const int k = lane + 64 * i;
+        const int kc = k < m ? k : 0;                              // clamped, unconditional loads
+        px[i] = sp[kc * 3 + 0]; py[i] = sp[kc * 3 + 1]; pz[i] = sp[kc * 3 + 2];
+    }
+    const int INF_BITS = 0x7F800000;
+    for (int qi = 0; qi < NN_WAVE_QPW; ++qi) {
+        const int j = q0 + qi;
+        if (j >= n) break;                                         // wave-uniform
+        const float* q = xyz1 + ((size_t)scene * n + j) * 3;
+        const float qx = q[0], qy = q[1], qz = q[2];               // uniform address: scalar loads
+        // (float)1e40 == +inf: any finite distance is smaller, +inf / NaN never enter (tf_interpolate.cpp:66, :75-89)
+        float b1 = INFINITY, b2 = INFINITY, b3 = INFINITY;
+        int i1 = 0, i2 = 0, i3 = 0;
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            const int k = lane + 64 * i;
+            const float d = dist2_host(px[i] - qx, py[i] - qy, pz[i] - qz);                       // :71-74, unfused, left to right
+            if (k < m && d < b3) {
+                if (d < b1) { b3 = b2; i3 = i2; b2 = b1; i2 = i1; b1 = d; i1 = k; }
+                else if (d < b2) { b3 = b2; i3 = i2; b2 = d; i2 = k; }
+                else { b3 = d; i3 = k; }
+            }
+        }
+        float od[3];
+        int oi[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            // distances are >= 0 (or +inf): their bit patterns order like the values
+            const int dmin = wave_min_i32(__float_as_int(b1));
+            const int kmin = wave_min_i32(__float_as_int(b1) == dmin ? i1 : 0x7FFFFFFF);
+            od[r] = __int_as_float(dmin);
+            oi[r] = dmin == INF_BITS ? 0 : kmin;                   // fewer than three known points: the slot keeps (inf, 0) (:91-96)
+            if (__float_as_int(b1) == dmin && i1 == kmin && dmin != INF_BITS) { b1 = b2; i1 = i2; b2 = b3; i2 = i3; b3 = INFINITY; i3 = 0; }
+        }
+        if (lane < 3) {
+            const float dv = lane == 0 ? od[0] : (lane == 1 ? od[1] : od[2]);
+            const int iv = lane == 0 ? oi[0] : (lane == 1 ? oi[1] : oi[2]);
+            dist[((size_t)scene * n + j) * 3 + lane] = dv;
+            idx[((size_t)scene * n + j) * 3 + lane] = iv;
+        }
+    }
+}
+static bool nn_wave_ok(int n, int m) {
+    static const int on = [] { const char* e = getenv("GSPN_NN_WAVE"); return e ? atoi(e) : 1; }();     // (tuning / A-B hook)
+    return on && m >= 1 && m <= NN_WAVE_MAX_M && n >= 1;
+}
+static int launch_three_nn_wave(int b, int n, int m, const float* xyz1, const float* xyz2, float* dist, int* idx, hipStream_t st) {
+    const int wpscene = (n + NN_WAVE_QPW - 1) / NN_WAVE_QPW;
+    const long long waves = (long long)b * wpscene;
+    const long long blocks = (waves + 3) / 4;
+    if (blocks > 0x7FFFFFFFll) return GSPN_ERR_UNSUPPORTED;
+    if (m <= 64 * 2) hipLaunchKernelGGL(three_nn_wave_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, b, n, m, xyz1, xyz2, dist, idx, wpscene);
+    else if (m <= 64 * 4) hipLaunchKernelGGL(three_nn_wave_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, b, n, m, xyz1, xyz2, dist, idx, wpscene);
+    else if (m <= 64 * 8) hipLaunchKernelGGL(three_nn_wave_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, st, b, n, m, xyz1, xyz2, dist, idx, wpscene);
+    else hipLaunchKernelGGL(three_nn_wave_kernel<NN_WAVE_P>, dim3((unsigned)blocks), dim3(256), 0, st, b, n, m, xyz1, xyz2, dist, idx, wpscene);
+    return gspn_launch_status();
+}
+
 static unsigned nn_grid(long long blocks) {
     static const long long cap = [] { const char* e = getenv("GSPN_NN_GRID"); const long long v = e ? atoll(e) : 0; return v > 0 ? v : (1ll << 31); }();
     return (unsigned)(blocks < cap ? blocks : cap);
@@ -135,6 +225,7 @@ static unsigned nn_grid(long long blocks) {
 extern "C" int gspn_threenn(int b, int n, int m, const float* xyz1, const float* xyz2, float* dist, int* idx, void* stream) {
     if (b < 0 || n < 0 || m < 0) return GSPN_ERR_ARG;
     if (b == 0 || n == 0) return 0;
+    if (nn_wave_ok(n, m)) return launch_three_nn_wave(b, n, m, xyz1, xyz2, dist, idx, (hipStream_t)stream);
     const long long blocks = (long long)b * ((n + NN_BLOCK * NN_Q - 1) / (NN_BLOCK * NN_Q));
     if (blocks > 0x7FFFFFFFll) return GSPN_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(three_nn_kernel, dim3(nn_grid(blocks)), dim3(NN_BLOCK), 0, (hipStream_t)stream, b, n, m, xyz1, xyz2, dist, idx, (const int*)nullptr, (unsigned)blocks);
@@ -143,6 +234,7 @@ extern "C" int gspn_threenn(int b, int n, int m, const float* xyz1, const float*
 extern "C" int gspn_threenn_ordered(int b, int n, int m, const float* xyz1, const float* xyz2, const int* order, float* dist, int* idx, void* stream) {
     if (b < 0 || n < 0 || m < 0) return GSPN_ERR_ARG;
     if (b == 0 || n == 0) return 0;
+    if (nn_wave_ok(n, m)) return launch_three_nn_wave(b, n, m, xyz1, xyz2, dist, idx, (hipStream_t)stream);       // (the result never depends on `order`)
     const long long blocks = (long long)b * ((n + NN_BLOCK * NN_Q - 1) / (NN_BLOCK * NN_Q));
     if (blocks > 0x7FFFFFFFll) return GSPN_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(three_nn_kernel, dim3(nn_grid(blocks)), dim3(NN_BLOCK), 0, (hipStream_t)stream, b, n, m, xyz1, xyz2, dist, idx, order, (unsigned)blocks);

@@ -161,6 +161,28 @@ def test_three_nn_matches_oracle(b, n, m):
     np.testing.assert_array_equal(d.cpu().numpy(), rd)
 
 
+@pytest.mark.parametrize("b,n,m", [(2, 777, 128), (3, 2048, 129), (1, 100, 256), (2, 513, 257), (1, 4099, 512), (2, 600, 513), (1, 333, 1024), (1, 50, 1025),
+                                   (8, 2048, 512), (8, 512, 128)])
+def test_three_nn_small_known_clouds_on_a_lattice(b, n, m):
+    """the wave-per-query kernel (m <= 1024: every lane keeps its own three best, three wave-wide (distance, index) minima pick the
+    result) against the oracle's sequential cascade (tf_interpolate.cpp:60-103) on integer lattices -- equal distances everywhere, so the
+    tie rule (the LOWER index stays) decides most slots -- at every template-instance boundary and just past the kernel's range"""
+    from gspn_amd.tf_interpolate import three_nn
+    rng = np.random.default_rng(b * 1000 + m)
+    dense = rng.integers(0, 6, size=(b, n, 3)).astype(np.float32)
+    sparse = rng.integers(0, 6, size=(b, m, 3)).astype(np.float32)
+    rd, ri = O.three_nn(dense, sparse)
+    d, i = three_nn(dev(dense), dev(sparse))
+    np.testing.assert_array_equal(i.cpu().numpy(), ri)
+    np.testing.assert_array_equal(d.cpu().numpy(), rd)
+    # and on continuous clouds with duplicated points
+    dense, sparse = D.batch("D", b, n, 3), D.batch("D", b, m, 4)
+    rd, ri = O.three_nn(dense, sparse)
+    d, i = three_nn(dev(dense), dev(sparse))
+    np.testing.assert_array_equal(i.cpu().numpy(), ri)
+    np.testing.assert_array_equal(d.cpu().numpy(), rd)
+
+
 @pytest.mark.parametrize("kind,b,n,m", [("D", 2, 9000, 700), ("S", 3, 12000, 300), ("U", 1, 8192, 3)])
 def test_three_nn_in_a_given_order(kind, b, n, m):
     """three_nn(..., order=): the order the unknown points are handed to the threads in (a random permutation, and the spatial order
