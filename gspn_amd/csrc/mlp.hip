@@ -23,6 +23,7 @@
 #include <type_traits>
 #include <stdlib.h>
 #include <stdio.h>
+#include <algorithm>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -2630,6 +2631,255 @@ void mlp_bwd_data_kernel(long rows, int cin, int cout, gspn_dy_args a, const flo
         }
     }
 }
+// ============================================================================================
+// Pass B, lean form (r03).  Same decomposition as mlp_bwd_data_kernel -- 128-row tiles, K chunks of 32, dY rebuilt while staging,
+// W^T staged transposed, optional dW-reduction ride and BN-reduction epilogue -- for the shapes the network actually runs: 16-byte
+// aligned pitches, rows a multiple of 128, cout a multiple of 32, a column range that is a whole number of BN-wide blocks, pool groups
+// of 32 rows or of a power of two >= 128, every offset below 2^32 bytes.  What it drops is vector arithmetic: the counters say these
+// GEMM kernels issue 12-32 VALU instructions per MFMA (profiles/r03_sq_insts_by_kernel.txt) and fp32 MFMAs do not hide them, and in
+// the general kernel most of them are 64-bit index arithmetic, clamps and masks.  Here
+//   * a thread's quads sit at CONSTANT byte offsets inside a tile and a chunk (three registers in all); tile and chunk position go into
+//     uniform bases (scalar arithmetic): the loads of a step are `global_load v, v_off, s[base]` without any vector address work;
+//   * no row / column guards anywhere (full tiles only); the negated shift is staged once, the ReLU mask is one multiply + one compare;
+//   * the MFMA loop is unrolled: every LDS address is a lane base plus an immediate;
+//   * the epilogue's 16 loads of the previous layer's output and 16 stores per 32x32 tile take their row from a scalar base as well.
+// dY = fma(cA, dyh, fma(cB, y, cC)) -- the form pass A's one-GEMM kernel uses (the general kernel rounds the three terms separately).
+// ============================================================================================
+template <int NT, int PK, bool RSUM, bool DW>      // PK: 0 dense dz, 1 pool groups of 32 rows, 2 pool groups of 2^k >= 128 rows (one group per tile)
+__global__ __launch_bounds__(256) void bwd_lean_kernel(int rows, int cout, gspn_dy_args a, const float* __restrict__ W, float* __restrict__ dX, int ldx,
+                                                       int col0, DwJob dwj, RsumArgs rs, int rowgrid, int pool_sh, int rs_cin) {
+    constexpr int BN = 32 * NT;
+    constexpr int LDA = 129, LDB = BN + 1;
+    __shared__ __attribute__((aligned(16))) float sA[32 * LDA];
+    __shared__ __attribute__((aligned(16))) float sB[32 * LDB];
+    extern __shared__ __attribute__((aligned(16))) float s_chan[];         // [5][cpad]: forward scale, MINUS shift, cA, cB, cC of the cout channels
+    const int cpad = (cout + 3) / 4 * 4 + 4;
+    unsigned bx = blockIdx.x;
+    if constexpr (DW) {
+        if (bx < (unsigned)(dwj.nblk + dwj.nblk2)) {
+            if (bx < (unsigned)dwj.nblk) wgrad_dw_block<256>(dwj, bx, reinterpret_cast<double*>(sA));
+            else {
+                DwJob j2 = dwj;
+                j2.PP = dwj.PP2; j2.dW = dwj.dW2; j2.cin = dwj.cin2; j2.nslots = dwj.nslots2; j2.plain = 1; j2.use_bn = 0; j2.gq = 0;
+                wgrad_dw_block<256>(j2, bx - (unsigned)dwj.nblk, reinterpret_cast<double*>(sA));
+            }
+            return;
+        }
+        bx -= (unsigned)(dwj.nblk + dwj.nblk2);
+    }
+    const int by = (int)(bx / (unsigned)rowgrid);
+    bx -= (unsigned)by * (unsigned)rowgrid;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int n0 = col0 + by * BN;
+    const int ntiles = rows >> 7;
+    const int nchunks = cout >> 5;
+    for (int i = t; i < cpad; i += 256) {
+        const bool in = i < cout;
+        s_chan[i] = in ? a.scale[i] : 1.f;
+        s_chan[cpad + i] = in ? -a.shift[i] : 0.f;
+        s_chan[2 * cpad + i] = in ? a.cA[i] : 0.f;
+        s_chan[3 * cpad + i] = in ? a.cB[i] : 0.f;
+        s_chan[4 * cpad + i] = in ? a.cC[i] : 0.f;
+    }
+    const int kq = (t & 7) * 4, arow = t >> 3;                  // this thread's quad: rows arow + 32 i, k = kq .. kq+3 of the chunk
+    const unsigned oy = (unsigned)(arow * a.ldy + kq) * 4u;
+    constexpr bool POOLED = PK != 0;
+    constexpr int NZ = PK == 2 ? 1 : 4;                         // (PK 2: the tile's rows share ONE (arg, dPool) quad per k)
+    const unsigned oz = POOLED ? (unsigned)kq * 4u : (unsigned)(arow * a.ldz + kq) * 4u;
+    const unsigned ow = (unsigned)(arow * cout + kq) * 4u;      // W row n0 + arow + 32 i
+    float4 ry[4], rz[NZ], rb[NT];
+    int4 rarg[PK == 1 ? 4 : 1];
+    auto fetch = [&](int tile, int c) {
+        const int m0 = tile << 7;
+        const char* yb = reinterpret_cast<const char*>(a.Y + (size_t)m0 * a.ldy + c * 32);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ry[i] = *reinterpret_cast<const float4*>(yb + (size_t)(32 * i) * a.ldy * 4 + oy);
+        if constexpr (PK == 1) {                                 // groups of 32 rows: rows arow + 32 i of the tile belong to group (m0 >> 5) + i
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const size_t g = (size_t)((m0 >> 5) + i) * cout + c * 32;
+                rarg[i] = *reinterpret_cast<const int4*>(reinterpret_cast<const char*>(a.pool_arg + g) + oz);
+                rz[i] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.dPool + g) + oz);
+            }
+        } else if constexpr (PK == 2) {                          // groups of >= 128 rows: the whole tile lies in one group
+            const size_t g = (size_t)(m0 >> pool_sh) * cout + c * 32;
+            rarg[0] = *reinterpret_cast<const int4*>(reinterpret_cast<const char*>(a.pool_arg + g) + oz);
+            rz[0] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.dPool + g) + oz);
+        } else {
+            const char* zb = reinterpret_cast<const char*>(a.dZ + (size_t)m0 * a.ldz + c * 32);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rz[i] = *reinterpret_cast<const float4*>(zb + (size_t)(32 * i) * a.ldz * 4 + oz);
+        }
+        const char* wb = reinterpret_cast<const char*>(W + (size_t)n0 * cout + c * 32);
+#pragma unroll
+        for (int i = 0; i < NT; ++i) rb[i] = *reinterpret_cast<const float4*>(wb + (size_t)(32 * i) * cout * 4 + ow);
+    };
+    auto commit = [&](int tile, int c) {
+        const int k = c * 32 + kq;
+        const float4 q_sc = *reinterpret_cast<const float4*>(s_chan + k), q_ns = *reinterpret_cast<const float4*>(s_chan + cpad + k);
+        const float4 q_a = *reinterpret_cast<const float4*>(s_chan + 2 * cpad + k), q_b = *reinterpret_cast<const float4*>(s_chan + 3 * cpad + k);
+        const float4 q_c = *reinterpret_cast<const float4*>(s_chan + 4 * cpad + k);
+        const float sc[4] = {q_sc.x, q_sc.y, q_sc.z, q_sc.w}, ns[4] = {q_ns.x, q_ns.y, q_ns.z, q_ns.w};
+        const float cA[4] = {q_a.x, q_a.y, q_a.z, q_a.w}, cB[4] = {q_b.x, q_b.y, q_b.z, q_b.w}, cC[4] = {q_c.x, q_c.y, q_c.z, q_c.w};
+        const int off0 = PK == 1 ? arow : (PK == 2 ? (((tile << 7) & ((1 << pool_sh) - 1)) + arow) : 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float yv[4] = {ry[i].x, ry[i].y, ry[i].z, ry[i].w};
+            float zv[4];
+            if constexpr (POOLED) {
+                const int gi = PK == 1 ? i : 0;
+                const int off = PK == 1 ? off0 : off0 + 32 * i;
+                const int av[4] = {rarg[gi].x, rarg[gi].y, rarg[gi].z, rarg[gi].w};
+                const float dv[4] = {rz[gi].x, rz[gi].y, rz[gi].z, rz[gi].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) zv[j] = av[j] == off ? dv[j] : 0.f;
+            } else {
+                zv[0] = rz[i].x; zv[1] = rz[i].y; zv[2] = rz[i].z; zv[3] = rz[i].w;
+            }
+            float* d = sA + kq * LDA + arow + 32 * i;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float dyh = yv[j] * sc[j] > ns[j] ? zv[j] : 0.f;                                   // relu_open: the forward's own mask
+                d[j * LDA] = __builtin_fmaf(cA[j], dyh, __builtin_fmaf(cB[j], yv[j], cC[j]));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            float* d = sB + kq * LDB + arow + 32 * i;
+            d[0 * LDB] = rb[i].x; d[1 * LDB] = rb[i].y; d[2 * LDB] = rb[i].z; d[3 * LDB] = rb[i].w;
+        }
+    };
+    f32x16 acc[NT];
+    float p_sc[NT], p_ns[NT], p_rs[NT], p_mr[NT], r0s[NT], r1s[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        r0s[nt] = r1s[nt] = 0.f;
+        p_sc[nt] = p_ns[nt] = p_rs[nt] = p_mr[nt] = 0.f;
+        if constexpr (RSUM) {
+            const int col = n0 + nt * 32 + l31;
+            p_sc[nt] = rs.scale[col];
+            p_ns[nt] = -rs.shift[col];
+            p_rs[nt] = (float)(1.0 / sqrt((double)rs.var[col] + (double)rs.eps));
+            p_mr[nt] = -rs.mean[col] * p_rs[nt];
+        }
+    }
+    const float* pa = sA + kh * LDA + wave * 32 + l31;
+    const float* pb = sB + kh * LDB + l31;
+    const unsigned lo_x = (unsigned)(4 * kh * ldx + n0 + l31) * 4u;
+    const unsigned lo_p = RSUM ? (unsigned)(4 * kh * rs.ldyp + n0 + l31) * 4u : 0u;
+    // tile loop around a chunk loop (not one flat loop over (tile, chunk) steps: with `if (chunk == 0) acc = 0` inside a flat loop hipcc
+    // keeps the accumulators in VGPRs and moves all of them to the AGPRs and back around every chunk's MFMAs -- 96 moves per chunk)
+    if ((int)bx < ntiles) fetch((int)bx, 0);
+    __syncthreads();                                          // the channel constants
+    for (int tile = (int)bx; tile < ntiles; tile += rowgrid) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+        for (int c = 0; c < nchunks; ++c) {
+            commit(tile, c);
+            __syncthreads();
+            {   // the next step's loads fly during this step's MFMAs
+                int nc = c + 1, ntl = tile;
+                if (nc == nchunks) { nc = 0; ntl = tile + rowgrid; }
+                if (ntl < ntiles) fetch(ntl, nc);
+            }
+            constexpr int U = NT >= 4 ? 2 : 4;                   // k-pairs whose operands are fetched ahead of their MFMAs (register budget)
+#pragma unroll
+            for (int k0 = 0; k0 < 32; k0 += 2 * U) {
+                float av[U], bv[U][NT];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    av[u] = pa[(k0 + 2 * u) * LDA];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) bv[u][nt] = pb[(k0 + 2 * u) * LDB + nt * 32];
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u][nt], acc[nt], 0, 0, 0);
+            }
+            __syncthreads();
+        }
+        const int m0 = (tile << 7) + wave * 32;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            if constexpr (RSUM) {
+                float yv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    yv[r] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(rs.Yp + (size_t)(m0 + (r & 3) + 8 * (r >> 2)) * rs.ldyp) + lo_p + nt * 128);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float dyh = yv[r] * p_sc[nt] > p_ns[nt] ? acc[nt][r] : 0.f;
+                    r0s[nt] += dyh;
+                    r1s[nt] = __builtin_fmaf(dyh, __builtin_fmaf(yv[r], p_rs[nt], p_mr[nt]), r1s[nt]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                *reinterpret_cast<float*>(reinterpret_cast<char*>(dX + (size_t)(m0 + (r & 3) + 8 * (r >> 2)) * ldx) + lo_x + nt * 128) = acc[nt][r];
+        }
+    }
+    if constexpr (RSUM) {
+        float* sR = sA;                                  // [4 waves][2][BN]
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            r0s[nt] += __shfl_xor(r0s[nt], 32, 64);
+            r1s[nt] += __shfl_xor(r1s[nt], 32, 64);
+            if (lane < 32) {
+                sR[(wave * 2 + 0) * BN + nt * 32 + lane] = r0s[nt];
+                sR[(wave * 2 + 1) * BN + nt * 32 + lane] = r1s[nt];
+            }
+        }
+        __syncthreads();
+        float* pr = rs.part + (size_t)bx * 2 * rs_cin;
+        for (int j = t; j < BN; j += 256) {
+            float v0 = 0.f, v1 = 0.f;
+            for (int w = 0; w < 4; ++w) { v0 += sR[(w * 2 + 0) * BN + j]; v1 += sR[(w * 2 + 1) * BN + j]; }
+            pr[n0 + j] = v0;
+            pr[rs_cin + n0 + j] = v1;
+        }
+    }
+}
+// the lean kernel takes the launch if every one of its shape assumptions holds (GSPN_BWD_LEAN=0: never -- A/B hook); returns false otherwise
+static bool bwd_lean_try(long rows, int cin, int cout, const gspn_dy_args* a, const float* W, int col0, int ncols, float* dX, int ldx, const DwJob* dwj,
+                         hipStream_t st, const RsumArgs& rs, int* nparts_out, const DwJob& none) {
+    static const int on = env_int("GSPN_BWD_LEAN", 1);
+    if (!on) return false;
+    const bool pooled = a->dZ == nullptr;
+    if ((rows & 127) || rows <= 0 || (cout & 31) || (ncols & 31) || (col0 & 3)) return false;
+    if (!vec_ok(a->Y, a->ldy) || !vec_ok(W, cout) || !vec_ok(dX, ldx)) return false;
+    const long maxld = std::max(std::max((long)a->ldy, (long)ldx), std::max((long)(pooled ? 0 : a->ldz), (long)(rs.Yp ? rs.ldyp : 0)));
+    if (rows * maxld >= (1L << 30) || (long)cin * cout >= (1L << 30)) return false;
+    int pool_sh = 0;
+    if (pooled) {
+        if (a->ns < 32 || (a->ns & (a->ns - 1)) || (a->ns > 32 && a->ns < 128)) return false;
+        if (((uintptr_t)a->dPool % 16) || ((uintptr_t)a->pool_arg % 16)) return false;
+        pool_sh = __builtin_ctz(a->ns);
+    } else if (!vec_ok(a->dZ, a->ldz)) return false;
+    if (rs.Yp && (rs.ldyp & 3)) return false;
+    const int bn = (ncols % 128 == 0 && rows >= 32768) ? 128 : (ncols % 64 == 0 ? 64 : 32);
+    const int yt = ncols / bn;
+    const unsigned extra = dwj ? (unsigned)(dwj->nblk + dwj->nblk2) : 0u;
+    const unsigned rg = row_grid(rows, yt, bn >= 128 ? 2 : bwd_bpc_narrow());
+    if (nparts_out) *nparts_out = (int)rg;
+    DwJob dj = dwj ? *dwj : none;
+    dj.rowgrid = (int)rg;
+    const dim3 g(rg * (unsigned)yt + extra);
+    const size_t dyn = sizeof(float) * 5 * chan_pad(cout);
+#define BL_GO(NT_, P_, R_, D_) hipLaunchKernelGGL((bwd_lean_kernel<NT_, P_, R_, D_>), g, dim3(256), dyn, st, (int)rows, cout, *a, W, dX, ldx, col0, dj, rs, (int)rg, pool_sh, col0 + ncols)
+#define BL_D(NT_, P_, R_) do { if (dwj) BL_GO(NT_, P_, R_, true); else BL_GO(NT_, P_, R_, false); } while (0)
+#define BL_R(NT_, P_) do { if (rs.Yp) BL_D(NT_, P_, true); else BL_D(NT_, P_, false); } while (0)
+#define BL_P(NT_) do { if (!pooled) BL_R(NT_, 0); else if (pool_sh == 5) BL_R(NT_, 1); else BL_R(NT_, 2); } while (0)
+    if (bn == 128) BL_P(4); else if (bn == 64) BL_P(2); else BL_P(1);
+#undef BL_P
+#undef BL_R
+#undef BL_D
+#undef BL_GO
+    return true;
+}
 static int bwd_data_launch(long rows, int cin, int cout, const gspn_dy_args* a, const float* W, int col0, int ncols, float* dX, int ldx, const DwJob* dwj,
                            hipStream_t st, const RsumArgs* rsp = nullptr, int* nparts_out = nullptr) {
     const RsumArgs rs = rsp ? *rsp : RsumArgs{nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr};
@@ -2643,6 +2893,7 @@ static int bwd_data_launch(long rows, int cin, int cout, const gspn_dy_args* a, 
     // 64-column tiles under 168 VGPRs; 2 for 128), yet 4 measures best (pass B of the bench step: 648 / 596 / 581 us at 2 / 3 / 4):
     // the fourth quarter of the workgroups fills the slots the first finishers free.  GSPN_BWD_BPC overrides (tuning hook).
     const int bpc_narrow = bwd_bpc_narrow();
+    if (bwd_lean_try(rows, cin, cout, a, W, col0, ncols, dX, ldx, dwj, st, rs, nparts_out, none)) return gspn_launch_status();
 #define BD_GO(BN_, V_, P_, YT_)                                                                                                       \
     do {                                                                                                                               \
         const unsigned rg = row_grid(rows, YT_, BN_ >= 128 ? 2 : bpc_narrow);                                                          \
