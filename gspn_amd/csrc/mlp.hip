@@ -759,6 +759,139 @@ extern "C" long gspn_mlp_fwd_stats_bytes(long rows, int cout) {
 }
 static inline bool vec_ok(const void* p, int ld) { return (ld % 4 == 0) && (((uintptr_t)p) % 16 == 0); }
 
+// ============================================================================================
+// Forward, lean form of the register-staged kernel (r03; see bwd_lean_kernel for the reasoning: these kernels are bound by the vector
+// instructions they issue around the MFMAs, and most of those were 64-bit index arithmetic, clamps and masks).  Shapes: 16-byte aligned
+// pitches, rows a multiple of 128, cin and cout multiples of 32, every offset below 2^32 bytes.  Same arithmetic as mlp_fwd_kernel in the
+// same order -- relu(x*scale + shift) with two roundings on the operand, K chunks of 32 accumulated in ascending k, bias added last --
+// so Y is bit-identical to that kernel's; the column sums of squares use one fused multiply-add per element.
+// ============================================================================================
+template <int NT, bool ACT, bool POOL>
+__global__ __launch_bounds__(256) void fwd_lean_kernel(int rows, int cin, int cout, const float* __restrict__ X, int ldx, const float* __restrict__ in_scale,
+                                                       const float* __restrict__ in_shift, const float* __restrict__ W, const float* __restrict__ bias,
+                                                       float* __restrict__ Y, int ldy, float* __restrict__ stats, PoolOut po) {
+    constexpr int BN = 32 * NT;
+    constexpr int LDA = 129, LDB = BN + 4;
+    __shared__ __attribute__((aligned(16))) float sA[32 * LDA];
+    __shared__ __attribute__((aligned(16))) float sB[32 * LDB];
+    __shared__ float sRed[2 * 4 * BN];
+    extern __shared__ __attribute__((aligned(16))) float s_chan[];         // [2][cpad]: scale, shift of the input channels
+    const int cpad = (cin + 3) / 4 * 4 + 4;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int n0 = blockIdx.y * BN;
+    const int ntiles = rows >> 7, nchunks = cin >> 5;
+    if constexpr (ACT) {
+        for (int i = t; i < cpad; i += 256) {
+            s_chan[i] = i < cin ? in_scale[i] : 1.f;
+            s_chan[cpad + i] = i < cin ? in_shift[i] : 0.f;
+        }
+    }
+    const int kq = (t & 7) * 4, arow = t >> 3;                  // A: rows arow + 32 i, k = kq .. kq+3 of the chunk
+    const unsigned oa = (unsigned)(arow * ldx + kq) * 4u;
+    constexpr int BQ = BN / 4;                                  // B: W rows (k) of the chunk, float4 along n
+    const int bk = t / BQ, bq = (t % BQ) * 4;                   // + (256 / BQ) k-rows per i
+    const unsigned ob = (unsigned)(bk * cout + bq) * 4u;
+    float4 ra[4], rb[NT];
+    auto fetch = [&](int tile, int c) {
+        const char* xb = reinterpret_cast<const char*>(X + (size_t)(tile << 7) * ldx + c * 32);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const float4*>(xb + (size_t)(32 * i) * ldx * 4 + oa);
+        const char* wb = reinterpret_cast<const char*>(W + (size_t)(c * 32) * cout + n0);
+#pragma unroll
+        for (int i = 0; i < NT; ++i) rb[i] = *reinterpret_cast<const float4*>(wb + (size_t)(i * (256 / BQ)) * cout * 4 + ob);
+    };
+    auto commit = [&](int c) {
+        float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (ACT) {
+            const float4 q_sc = *reinterpret_cast<const float4*>(s_chan + c * 32 + kq), q_sh = *reinterpret_cast<const float4*>(s_chan + cpad + c * 32 + kq);
+            sc[0] = q_sc.x; sc[1] = q_sc.y; sc[2] = q_sc.z; sc[3] = q_sc.w;
+            sh[0] = q_sh.x; sh[1] = q_sh.y; sh[2] = q_sh.z; sh[3] = q_sh.w;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float xv[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+            float* d = sA + kq * LDA + arow + 32 * i;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d[j * LDA] = act1(xv[j], ACT, sc[j], sh[j]);
+        }
+#pragma unroll
+        for (int i = 0; i < NT; ++i) *reinterpret_cast<float4*>(sB + (bk + i * (256 / BQ)) * LDB + bq) = rb[i];
+    };
+    float bv[NT], csum[NT], csq[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        bv[nt] = bias ? bias[n0 + nt * 32 + l31] : 0.f;
+        csum[nt] = csq[nt] = 0.f;
+    }
+    f32x16 acc[NT];
+    const float* pa = sA + kh * LDA + wave * 32 + l31;
+    const float* pb = sB + kh * LDB + l31;
+    const unsigned lo_y = (unsigned)(4 * kh * ldy + n0 + l31) * 4u;
+    if ((int)blockIdx.x < ntiles) fetch((int)blockIdx.x, 0);
+    __syncthreads();
+    for (int tile = (int)blockIdx.x; tile < ntiles; tile += (int)gridDim.x) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+        for (int c = 0; c < nchunks; ++c) {
+            commit(c);
+            __syncthreads();
+            {
+                int nc = c + 1, ntl = tile;
+                if (nc == nchunks) { nc = 0; ntl = tile + (int)gridDim.x; }
+                if (ntl < ntiles) fetch(ntl, nc);
+            }
+#pragma unroll
+            for (int k0 = 0; k0 < 32; k0 += 8) {
+                float av[4], bw[4][NT];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    av[u] = pa[(k0 + 2 * u) * LDA];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) bw[u][nt] = pb[(k0 + 2 * u) * LDB + nt * 32];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bw[u][nt], acc[nt], 0, 0, 0);
+            }
+            __syncthreads();
+        }
+        const int m0 = (tile << 7) + wave * 32;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            if constexpr (POOL) pool32_tile(acc[nt], bv[nt], lane, po, (size_t)(m0 >> 5) * cout + n0 + nt * 32 + l31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = acc[nt][r] + bv[nt];
+                *reinterpret_cast<float*>(reinterpret_cast<char*>(Y + (size_t)(m0 + (r & 3) + 8 * (r >> 2)) * ldy) + lo_y + nt * 128) = v;
+                csum[nt] += v;
+                csq[nt] = __builtin_fmaf(v, v, csq[nt]);
+            }
+        }
+    }
+    if (stats) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            csum[nt] += __shfl_xor(csum[nt], 32, 64);
+            csq[nt] += __shfl_xor(csq[nt], 32, 64);
+            if (lane < 32) {
+                sRed[(wave * 2 + 0) * BN + nt * 32 + lane] = csum[nt];
+                sRed[(wave * 2 + 1) * BN + nt * 32 + lane] = csq[nt];
+            }
+        }
+        __syncthreads();
+        float* ws = stats + (size_t)blockIdx.x * 2 * cout;
+        for (int j = t; j < BN; j += 256) {
+            float sm = 0.f, q = 0.f;
+            for (int w = 0; w < 4; ++w) { sm += sRed[(w * 2 + 0) * BN + j]; q += sRed[(w * 2 + 1) * BN + j]; }
+            ws[n0 + j] = sm;
+            ws[cout + n0 + j] = q;
+        }
+    }
+}
 static int mlp_fwd_impl(long rows, int cin, int cout, const float* X, int ldx, const float* in_scale, const float* in_shift,
                         const float* W, const float* bias, float* Y, int ldy, float* stats, PoolOut po, void* stream,
                         const GatherSrc* gsrc = nullptr) {
@@ -768,6 +901,29 @@ static int mlp_fwd_impl(long rows, int cin, int cout, const float* X, int ldx, c
     if (cin > MAXCH || cout > MAXCH) return GSPN_ERR_UNSUPPORTED;
     if (rows == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
+    {
+        static const int lean_on = env_int("GSPN_FWD_LEAN", 1);             // (A/B hook)
+        static const int lean_bn = env_int("GSPN_FWD_LEAN_BN", 0);          // (tuning hook)
+        // (beyond ~0.75 M rows the eight 32-column blocks of a 256-column layer re-read X from beyond the L2s: 1 M x 128 -> 256 946 us against
+        //  874 for the 128-column register-staged kernel, 1 M x 64 -> 128 274 against 259 for the streaming kernel; 0.5 M rows: 431 / 437, 137 / 151)
+        if (lean_on && !gsrc && rows <= 786432 && vec_ok(X, ldx) && vec_ok(W, cout) && !(rows & 127) && !(cin & 31) && !(cout & 31) && rows * (long)std::max(ldx, ldy) < (1L << 30) && (long)cin * cout < (1L << 30) &&
+            (!po.vmax || !(rows & 31))) {
+            // 32-column blocks: measured best on every layer shape of the benchmark and of the configs[3] shard (tools/fwd_ablate.py with
+            // GSPN_FWD_LEAN_BN = 32 / 64): 131072 x 64 -> 128 35 us against 39 (and 44 for the LDS-DMA streaming kernel), 32768 x 128 -> 256 30 against 40
+            int bn = 32;
+            if (lean_bn && cout % lean_bn == 0 && lean_bn <= 64) bn = lean_bn;
+            const dim3 g(fwd_blocks(rows, cout), cout / bn);
+            const size_t dyn = sizeof(float) * 2 * chan_pad(cin);
+#define FL_GO(NT_, A_, P_) hipLaunchKernelGGL((fwd_lean_kernel<NT_, A_, P_>), g, dim3(256), dyn, st, (int)rows, cin, cout, X, ldx, in_scale, in_shift, W, bias, Y, ldy, stats, po)
+#define FL_P(NT_, A_) do { if (po.vmax) FL_GO(NT_, A_, true); else FL_GO(NT_, A_, false); } while (0)
+#define FL_A(NT_) do { if (in_scale) FL_P(NT_, true); else FL_P(NT_, false); } while (0)
+            if (bn == 64) FL_A(2); else FL_A(1);
+#undef FL_A
+#undef FL_P
+#undef FL_GO
+            return gspn_launch_status();
+        }
+    }
     {
         // streaming kernel: needs 16-byte rows, 32-bit offsets and W + two row tiles within 80 KB of LDS (>= 2 workgroups per CU)
         const int BNs = cout <= 32 ? 32 : (cout <= 64 ? 64 : 128);
@@ -2860,10 +3016,15 @@ static bool bwd_lean_try(long rows, int cin, int cout, const gspn_dy_args* a, co
         pool_sh = __builtin_ctz(a->ns);
     } else if (!vec_ok(a->dZ, a->ldz)) return false;
     if (rs.Yp && (rs.ldyp & 3)) return false;
-    const int bn = (ncols % 128 == 0 && rows >= 32768) ? 128 : (ncols % 64 == 0 ? 64 : 32);
+    static const int force_bn = env_int("GSPN_BWD_LEAN_BN", 0);          // (tuning hook)
+    // measured on MI355X (tools/bwd_ablate.py, GSPN_BWD_LEAN_BN sweep): 64-column blocks everywhere they divide the range -- also for 128
+    // columns, where a 128-wide block would read dY once instead of twice but leaves one wave per SIMD (1 M x 128 <- 256 pooled: 934 us
+    // against 1165) -- and 32-column blocks for the short layers (<= 16384 rows), which need the workgroups
+    int bn = (ncols % 64 == 0 && rows > 16384) ? 64 : 32;
+    if (force_bn && ncols % force_bn == 0 && force_bn <= 64) bn = force_bn;
     const int yt = ncols / bn;
     const unsigned extra = dwj ? (unsigned)(dwj->nblk + dwj->nblk2) : 0u;
-    const unsigned rg = row_grid(rows, yt, bn >= 128 ? 2 : bwd_bpc_narrow());
+    const unsigned rg = row_grid(rows, yt, bwd_bpc_narrow());
     if (nparts_out) *nparts_out = (int)rg;
     DwJob dj = dwj ? *dwj : none;
     dj.rowgrid = (int)rg;
@@ -2873,7 +3034,7 @@ static bool bwd_lean_try(long rows, int cin, int cout, const gspn_dy_args* a, co
 #define BL_D(NT_, P_, R_) do { if (dwj) BL_GO(NT_, P_, R_, true); else BL_GO(NT_, P_, R_, false); } while (0)
 #define BL_R(NT_, P_) do { if (rs.Yp) BL_D(NT_, P_, true); else BL_D(NT_, P_, false); } while (0)
 #define BL_P(NT_) do { if (!pooled) BL_R(NT_, 0); else if (pool_sh == 5) BL_R(NT_, 1); else BL_R(NT_, 2); } while (0)
-    if (bn == 128) BL_P(4); else if (bn == 64) BL_P(2); else BL_P(1);
+    if (bn == 64) BL_P(2); else BL_P(1);
 #undef BL_P
 #undef BL_R
 #undef BL_D

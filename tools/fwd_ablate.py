@@ -3,7 +3,7 @@ import os, sys, torch
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from gspn_amd import _lib as L
 lib = L.lib(); dev = torch.device('cuda', 0)
-shapes = [(262144, 64, 64), (524288, 32, 64), (524288, 32, 32), (131072, 64, 128), (131072, 64, 64), (32768, 128, 128), (32768, 128, 256), (16384, 192, 128), (4096, 384, 256), (4096, 256, 128)]
+shapes = [(262144, 64, 64), (524288, 32, 64), (524288, 32, 32), (131072, 64, 128), (131072, 64, 64), (32768, 128, 128), (32768, 128, 256), (16384, 192, 128), (4096, 384, 256), (4096, 256, 128), (524288, 64, 128), (1048576, 64, 128), (524288, 128, 256), (1048576, 128, 256)]
 def run(rows, cin, cout, reps=20):
     X = torch.randn(rows, cin, device=dev); Y = torch.empty(rows, cout, device=dev)
     W = torch.randn(cin, cout, device=dev) * 0.1; bias = torch.zeros(cout, device=dev)
