@@ -1842,7 +1842,8 @@ static WgradPlan wgrad_plan(long rows, int cin, int cout, bool generic = false, 
     if (forced_chunks > 0) chunks = forced_chunks;
     long rpc = (rows + chunks - 1) / chunks;
     if (rpc < 4L * p.TKW) rpc = 4L * p.TKW;
-    p.rpc = (rpc + p.TKW - 1) / p.TKW * p.TKW;
+    const long rq = p.TKW > 32 ? p.TKW : 32;              // (r03) whole stages of the lean kernel (32 rows) as well as of the streaming one (TKW)
+    p.rpc = (rpc + rq - 1) / rq * rq;
     p.nch = (rows + p.rpc - 1) / p.rpc;
     if (p.nch < 1) p.nch = 1;
     const long tile_bytes = 8L * cin * cout;
@@ -2045,6 +2046,214 @@ static DwJob dw_job(long rows, int cin, int cout, long nslots, const float* PP, 
 }
 
 // which kernel / plan a (layer, operand alignment) gets: shared by gspn_mlp_bwd_wgrad and gspn_mlp_bwd_dw so both find the same workspace layout
+// ============================================================================================
+// Pass A with known coefficients, lean form (r03): dW = act(X)^T . dY over one row chunk per workgroup, into the chunk's partial-tile slot
+// (same workspace layout and chunking as wgrad_stream_kernel, so the reductions that follow do not care which kernel ran).
+// The streaming kernel builds both MFMA operands while it READS them from the raw LDS-DMA tiles -- relu(bn(x)) and
+// dY = cA*[mask]*dz + cB*y + cC are recomputed by every wave for every MFMA that consumes the element: 11-23 VALU instructions per MFMA
+// (profiles/r03_sq_insts_by_kernel.txt), and fp32 MFMAs do not hide them.  Here a stage of 32 rows is loaded into registers, each element
+// is transformed ONCE on its way into LDS (row-major, 16-byte stores), and the MFMA loop reads finished operands: a workgroup covers a
+// block of MB x NB 32x32 tiles of dW, 3/NB + 5/MB vector instructions per MFMA.  Full stages only (rows and chunk length multiples of
+// 32), 16-byte aligned pitches, per-thread constant offsets on uniform bases as in bwd_lean_kernel.
+// ============================================================================================
+template <int MB, int NB, int PK, bool ACT>
+__global__ __launch_bounds__(256) void wgrad_lean_kernel(int rows, int cin, int cout, gspn_dy_args a, const float* __restrict__ X, int ldx,
+                                                         const float* __restrict__ in_scale, const float* __restrict__ in_shift, float* __restrict__ PP,
+                                                         int rpc, int nch, int nbm, int nbn, int pool_sh) {
+    constexpr int CM = 32 * MB, CN = 32 * NB;
+    constexpr int WGM = MB >= 4 ? 4 : MB, WGN = 4 / WGM;        // wave grid over the block's tiles
+    constexpr int AM = MB / WGM, BNW = NB / WGN;
+    static_assert(WGM * WGN == 4 && AM >= 1 && BNW >= 1 && AM * WGM == MB && BNW * WGN == NB, "4 waves tile the block");
+    constexpr int LDXS = CM + 4, LDYS = CN + 4;                 // (+4 floats: the two k halves of an operand read start 4 banks apart)
+    __shared__ __attribute__((aligned(16))) float sX[32 * LDXS];
+    __shared__ __attribute__((aligned(16))) float sD[32 * LDYS];
+    extern __shared__ __attribute__((aligned(16))) float s_chan[];         // [2][cpin] input scale / shift, [5][cpout] scale, -shift, cA, cB, cC
+    const int cpin = (cin + 3) / 4 * 4 + 4, cpout = (cout + 3) / 4 * 4 + 4;
+    float* s_in = s_chan;
+    float* s_out = s_chan + 2 * cpin;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int l31 = lane & 31, kh = lane >> 5;
+    // block -> (chunk, output block): the blocks of one chunk are adjacent in launch order AND on the same XCD (id % 8)
+    const int nblk = nbm * nbn;
+    const int bid = blockIdx.x, rest = bid >> 3;
+    const int blk = rest % nblk;
+    const int chunk = (rest / nblk) * 8 + (bid & 7);
+    if (chunk >= nch) return;
+    const int m0 = (blk % nbm) * CM, n0 = (blk / nbm) * CN;
+    const int r_begin = chunk * rpc;
+    const int nst = (min(r_begin + rpc, rows) - r_begin) >> 5;         // stages of 32 rows
+    if constexpr (ACT) {
+        for (int i = t; i < cpin; i += 256) {
+            s_in[i] = i < cin ? in_scale[i] : 1.f;
+            s_in[cpin + i] = i < cin ? in_shift[i] : 0.f;
+        }
+    }
+    for (int i = t; i < cpout; i += 256) {
+        const bool in = i < cout;
+        s_out[i] = in ? a.scale[i] : 1.f;
+        s_out[cpout + i] = in ? -a.shift[i] : 0.f;
+        s_out[2 * cpout + i] = in ? a.cA[i] : 0.f;
+        s_out[3 * cpout + i] = in ? a.cB[i] : 0.f;
+        s_out[4 * cpout + i] = in ? a.cC[i] : 0.f;
+    }
+    // X block: 32 rows x CM columns = 8 MB quads per row; thread t takes quad (t % (8 MB)) of rows t / (8 MB) + i * (32 / MB), i < MB
+    constexpr int XQ = 8 * MB, XR = 32 / MB;
+    const int xq = (t % XQ) * 4, xr = t / XQ;
+    const unsigned ox = (unsigned)(xr * ldx + m0 + xq) * 4u;
+    constexpr int YQ = 8 * NB, YR = 32 / NB;
+    const int yq = (t % YQ) * 4, yr = t / YQ;
+    const unsigned oy = (unsigned)(yr * a.ldy + n0 + yq) * 4u;
+    const unsigned oz = PK ? (unsigned)(n0 + yq) * 4u : (unsigned)(yr * a.ldz + n0 + yq) * 4u;
+    float4 rx[MB], ry[NB], rz[PK ? 1 : NB];
+    int4 rarg[PK ? 1 : 1];
+    auto fetch = [&](int s) {
+        const int r0 = r_begin + (s << 5);
+        const char* xb = reinterpret_cast<const char*>(X + (size_t)r0 * ldx);
+#pragma unroll
+        for (int i = 0; i < MB; ++i) rx[i] = *reinterpret_cast<const float4*>(xb + (size_t)(i * XR) * ldx * 4 + ox);
+        const char* yb = reinterpret_cast<const char*>(a.Y + (size_t)r0 * a.ldy);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) ry[i] = *reinterpret_cast<const float4*>(yb + (size_t)(i * YR) * a.ldy * 4 + oy);
+        if constexpr (PK != 0) {                                 // the 32 rows of a stage lie in ONE pool group (ns = 32, or a power of two >= 64)
+            const size_t g = (size_t)(r0 >> pool_sh) * cout;
+            rarg[0] = *reinterpret_cast<const int4*>(reinterpret_cast<const char*>(a.pool_arg + g) + oz);
+            rz[0] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.dPool + g) + oz);
+        } else {
+            const char* zb = reinterpret_cast<const char*>(a.dZ + (size_t)r0 * a.ldz);
+#pragma unroll
+            for (int i = 0; i < NB; ++i) rz[i] = *reinterpret_cast<const float4*>(zb + (size_t)(i * YR) * a.ldz * 4 + oz);
+        }
+    };
+    auto commit = [&](int s) {
+        {
+            float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (ACT) {
+                const float4 q_sc = *reinterpret_cast<const float4*>(s_in + m0 + xq), q_sh = *reinterpret_cast<const float4*>(s_in + cpin + m0 + xq);
+                sc[0] = q_sc.x; sc[1] = q_sc.y; sc[2] = q_sc.z; sc[3] = q_sc.w;
+                sh[0] = q_sh.x; sh[1] = q_sh.y; sh[2] = q_sh.z; sh[3] = q_sh.w;
+            }
+#pragma unroll
+            for (int i = 0; i < MB; ++i) {
+                float4 v;
+                v.x = act1(rx[i].x, ACT, sc[0], sh[0]); v.y = act1(rx[i].y, ACT, sc[1], sh[1]);
+                v.z = act1(rx[i].z, ACT, sc[2], sh[2]); v.w = act1(rx[i].w, ACT, sc[3], sh[3]);
+                *reinterpret_cast<float4*>(sX + (xr + i * XR) * LDXS + xq) = v;
+            }
+        }
+        const int k = n0 + yq;
+        const float4 q_sc = *reinterpret_cast<const float4*>(s_out + k), q_ns = *reinterpret_cast<const float4*>(s_out + cpout + k);
+        const float4 q_a = *reinterpret_cast<const float4*>(s_out + 2 * cpout + k), q_b = *reinterpret_cast<const float4*>(s_out + 3 * cpout + k);
+        const float4 q_c = *reinterpret_cast<const float4*>(s_out + 4 * cpout + k);
+        const float sc[4] = {q_sc.x, q_sc.y, q_sc.z, q_sc.w}, ns[4] = {q_ns.x, q_ns.y, q_ns.z, q_ns.w};
+        const float cA[4] = {q_a.x, q_a.y, q_a.z, q_a.w}, cB[4] = {q_b.x, q_b.y, q_b.z, q_b.w}, cC[4] = {q_c.x, q_c.y, q_c.z, q_c.w};
+        const int off0 = PK ? (((r_begin + (s << 5)) & ((1 << pool_sh) - 1)) + yr) : 0;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const float yv[4] = {ry[i].x, ry[i].y, ry[i].z, ry[i].w};
+            float zv[4];
+            if constexpr (PK != 0) {
+                const int off = off0 + i * YR;
+                const int av[4] = {rarg[0].x, rarg[0].y, rarg[0].z, rarg[0].w};
+                const float dv[4] = {rz[0].x, rz[0].y, rz[0].z, rz[0].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) zv[j] = av[j] == off ? dv[j] : 0.f;
+            } else {
+                zv[0] = rz[i].x; zv[1] = rz[i].y; zv[2] = rz[i].z; zv[3] = rz[i].w;
+            }
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float dyh = yv[j] * sc[j] > ns[j] ? zv[j] : 0.f;
+                o[j] = __builtin_fmaf(cA[j], dyh, __builtin_fmaf(cB[j], yv[j], cC[j]));       // the streaming kernel's own form of dY
+            }
+            *reinterpret_cast<float4*>(sD + (yr + i * YR) * LDYS + yq) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    };
+    f32x16 acc[AM][BNW];
+#pragma unroll
+    for (int x = 0; x < AM; ++x)
+#pragma unroll
+        for (int y = 0; y < BNW; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
+    const int gm = wave % WGM, gn = wave / WGM;                 // this wave's tiles: rows (gm + WGM x) of the block, columns (gn + WGN y)
+    const float* pa = sX + kh * LDXS + gm * 32 + l31;
+    const float* pb = sD + kh * LDYS + gn * 32 + l31;
+    if (nst > 0) fetch(0);
+    __syncthreads();
+    for (int s = 0; s < nst; ++s) {
+        commit(s);
+        __syncthreads();
+        if (s + 1 < nst) fetch(s + 1);
+#pragma unroll
+        for (int k0 = 0; k0 < 32; k0 += 4) {
+            float av[2][AM], bw[2][BNW];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+#pragma unroll
+                for (int x = 0; x < AM; ++x) av[u][x] = pa[(k0 + 2 * u) * LDXS + x * WGM * 32];
+#pragma unroll
+                for (int y = 0; y < BNW; ++y) bw[u][y] = pb[(k0 + 2 * u) * LDYS + y * WGN * 32];
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int x = 0; x < AM; ++x)
+#pragma unroll
+                    for (int y = 0; y < BNW; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][x], bw[u][y], acc[x][y], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    float* P1 = PP + (size_t)chunk * 2 * cin * cout;
+#pragma unroll
+    for (int x = 0; x < AM; ++x)
+#pragma unroll
+        for (int y = 0; y < BNW; ++y) {
+            const int mrow = m0 + (gm + WGM * x) * 32 + 4 * kh;
+            const unsigned lo = (unsigned)(n0 + (gn + WGN * y) * 32 + l31) * 4u;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                *reinterpret_cast<float*>(reinterpret_cast<char*>(P1 + (size_t)(mrow + (r & 3) + 8 * (r >> 2)) * cout) + lo) = acc[x][y][r];
+        }
+}
+// the lean kernel takes a known-coefficient pass A when its shape assumptions hold (GSPN_WGRAD_LEAN=0: never); false otherwise
+static bool wgrad_lean_try(long rows, int cin, int cout, const gspn_dy_args* a, const float* X, int ldx, const float* in_scale, const float* in_shift,
+                           float* PP, const WgradPlan& p, hipStream_t st) {
+    static const int on = env_int("GSPN_WGRAD_LEAN", 1);
+    if (!on || p.shared || (rows & 31) || (p.rpc & 31) || (cin & 31) || (cout & 63)) return false;
+    const bool pooled = a->dZ == nullptr;
+    // Measured against the LDS-DMA streaming kernel on MI355X (tools/wgrad_ablate.py, us lean / streaming): it wins where the streaming
+    // kernel's on-read operand construction is most expensive -- the pooled top layers with >= 128 output channels (131072 x 64^T x 128:
+    // 42 / 52, 32768 x 128^T x 256: 56 / 59, 1 M x 128^T x 256: 1021 / 1126) -- and loses on the dense layers (262144 x 64^T x 64: 54 / 48,
+    // 32768 x 128^T x 128: 56 / 33, 4096 x 384^T x 256: 39 / 24): two barriers per 32-row stage and the chunk count planned for the streaming
+    // kernel's finer tiles leave it short of workgroups there.  GSPN_WGRAD_LEAN=2 takes every eligible shape (A/B hook).
+    if (on != 2 && !(pooled && cout >= 128)) return false;
+    int pool_sh = 0;
+    if (pooled) {
+        if (a->ns < 32 || (a->ns & (a->ns - 1)) || rows % a->ns) return false;
+        pool_sh = __builtin_ctz(a->ns);
+    }
+    const long ldmax = std::max(std::max((long)ldx, (long)a->ldy), (long)(pooled ? 0 : a->ldz));
+    if (p.rpc * ldmax >= (1L << 30) || rows * ldmax >= (1L << 40)) return false;
+    const int mt = cin / 32, nt = cout / 32;
+    const int MBs = (mt % 4 == 0) ? 4 : ((mt % 2 == 0) ? 2 : 0);
+    if (!MBs) return false;
+    const int NBs = 2;                                         // (cout % 64 == 0)
+    const int nbm = mt / MBs, nbn = nt / NBs;
+    const dim3 g((unsigned)((p.nch + 7) / 8 * 8 * nbm * nbn));
+    const size_t dyn = sizeof(float) * (2 * chan_pad(cin) + 5 * chan_pad(cout));
+    const bool act = in_scale != nullptr;
+#define WL_GO(MB_, PK_, A_) hipLaunchKernelGGL((wgrad_lean_kernel<MB_, 2, PK_, A_>), g, dim3(256), dyn, st, (int)rows, cin, cout, *a, X, ldx, in_scale, in_shift, PP, \
+                                               (int)p.rpc, (int)p.nch, nbm, nbn, pool_sh)
+#define WL_A(MB_, PK_) do { if (act) WL_GO(MB_, PK_, true); else WL_GO(MB_, PK_, false); } while (0)
+#define WL_P(MB_) do { if (pooled) WL_A(MB_, 1); else WL_A(MB_, 0); } while (0)
+    if (MBs == 4) WL_P(4); else WL_P(2);
+#undef WL_P
+#undef WL_A
+#undef WL_GO
+    return true;
+}
+
 static WgradPlan wgrad_choose(long rows, int cin, int cout, const gspn_dy_args* a, const float* X, int ldx, bool* use_stream_out) {
     const bool pooled = a->dZ == nullptr;
     // streaming kernel: 16-byte aligned rows, 32-bit in-chunk offsets, pool groups that tile the stage
@@ -2102,6 +2311,7 @@ static int wgrad_impl(long rows, int cin, int cout, const gspn_dy_args* a, const
     const float* vr = use_bn ? var : nullptr;
     if (use_stream) {
         int launched = 0;
+        if (known && !gsrc && wgrad_lean_try(rows, cin, cout, a, X, ldx, in_scale, in_shift, PP, p, st)) launched = 1;
         const dim3 grid((unsigned)((p.nch + 7) / 8 * 8 * p.nrow * p.ncol));
 #define WS_ARGS (int)rows, cin, cout, *a, X, ldx, in_scale, in_shift, mu, vr, eps, RP, GP, PP, (int)p.rpc, (int)p.nslots, p.shared, (int)p.nch, p.nrow, p.ncol
 #define WS_GO(MT_, NT_, TKW_, G_, P_) hipLaunchKernelGGL((wgrad_stream_kernel<MT_, NT_, TKW_, G_, P_>), grid, dim3(256), 0, st, WS_ARGS, GatherSrc{})
@@ -2118,7 +2328,7 @@ static int wgrad_impl(long rows, int cin, int cout, const gspn_dy_args* a, const
             else hipLaunchKernelGGL((wgrad_stream_kernel<MT_, NT_, TKW_, false, false, false, true>), grid, dim3(256), 0, st, WS_ARGS, GatherSrc{});        \
             launched = 1;                                                                       \
         }
-        WS_KNOWN(1, 1, 64) WS_KNOWN(1, 2, 32)
+        if (!launched) { WS_KNOWN(1, 1, 64) WS_KNOWN(1, 2, 32) }
         if (!launched && known && !gsrc && p.MTs == 1 && p.NTs == 4 && p.TKW == 16) {
             if (pooled) hipLaunchKernelGGL((wgrad_stream_kernel<1, 4, 16, false, true, false, true>), grid, dim3(256), 0, st, WS_ARGS, GatherSrc{});
             else hipLaunchKernelGGL((wgrad_stream_kernel<1, 4, 16, false, false, false, true>), grid, dim3(256), 0, st, WS_ARGS, GatherSrc{});
