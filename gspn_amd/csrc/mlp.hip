@@ -3146,12 +3146,10 @@ __global__ __launch_bounds__(256) void bwd_lean_kernel(int rows, int cout, gspn_
         for (int c = 0; c < nchunks; ++c) {
             commit(tile, c);
             __syncthreads();
-            {   // the next step's loads fly during this step's MFMAs
-                int nc = c + 1, ntl = tile;
-                if (nc == nchunks) { nc = 0; ntl = tile + rowgrid; }
-                if (ntl < ntiles) fetch(ntl, nc);
-            }
-            constexpr int U = NT >= 4 ? 2 : 4;                   // k-pairs whose operands are fetched ahead of their MFMAs (register budget)
+            // the next chunk's loads fly during this chunk's MFMAs; the next TILE's first chunk is fetched after this tile's epilogue (its ten
+            // quads would otherwise be live across the epilogue's own 16 loads + 16 stores per column tile: 185 registers, two waves per SIMD)
+            if (c + 1 < nchunks) fetch(tile, c + 1);
+            constexpr int U = NT >= 2 ? 2 : 4;                   // k-pairs whose operands are fetched ahead of their MFMAs (register budget)
 #pragma unroll
             for (int k0 = 0; k0 < 32; k0 += 2 * U) {
                 float av[U], bv[U][NT];
@@ -3169,24 +3167,32 @@ __global__ __launch_bounds__(256) void bwd_lean_kernel(int rows, int cout, gspn_
             __syncthreads();
         }
         const int m0 = (tile << 7) + wave * 32;
+        // (opaque per tile: otherwise hipcc hoists the 32 (lane offset + row * pitch) sums out of the tile loop as 64-bit pairs -- 50 registers,
+        //  a wave per SIMD -- instead of adding a scalar row base per access)
+        unsigned lpx = lo_p, lxx = lo_x;
+        asm volatile("" : "+v"(lpx), "+v"(lxx));
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             if constexpr (RSUM) {
-                float yv[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    yv[r] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(rs.Yp + (size_t)(m0 + (r & 3) + 8 * (r >> 2)) * rs.ldyp) + lo_p + nt * 128);
+                for (int h = 0; h < 2; ++h) {                  // eight loads in flight at a time (register budget: three waves per SIMD)
+                    float yv[8];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float dyh = yv[r] * p_sc[nt] > p_ns[nt] ? acc[nt][r] : 0.f;
-                    r0s[nt] += dyh;
-                    r1s[nt] = __builtin_fmaf(dyh, __builtin_fmaf(yv[r], p_rs[nt], p_mr[nt]), r1s[nt]);
+                    for (int r = 0; r < 8; ++r)
+                        yv[r] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(rs.Yp + (size_t)(m0 + (r & 3) + 8 * ((8 * h + r) >> 2)) * rs.ldyp) + lpx + nt * 128);
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        const float dyh = yv[r] * p_sc[nt] > p_ns[nt] ? acc[nt][8 * h + r] : 0.f;
+                        r0s[nt] += dyh;
+                        r1s[nt] = __builtin_fmaf(dyh, __builtin_fmaf(yv[r], p_rs[nt], p_mr[nt]), r1s[nt]);
+                    }
                 }
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                *reinterpret_cast<float*>(reinterpret_cast<char*>(dX + (size_t)(m0 + (r & 3) + 8 * (r >> 2)) * ldx) + lo_x + nt * 128) = acc[nt][r];
+                *reinterpret_cast<float*>(reinterpret_cast<char*>(dX + (size_t)(m0 + (r & 3) + 8 * (r >> 2)) * ldx) + lxx + nt * 128) = acc[nt][r];
         }
+        if (tile + rowgrid < ntiles) fetch(tile + rowgrid, 0);
     }
     if constexpr (RSUM) {
         float* sR = sA;                                  // [4 waves][2][BN]
