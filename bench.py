@@ -562,7 +562,7 @@ def mlp_roofline(mlp_mod, eager_step, state, reps=3):
         prof = mlp_mod.PROFILE
     finally:
         mlp_mod.PROFILE = None
-    by = {"fwd": 0.0, "wgrad": 0.0, "bwd": 0.0}
+    by = {"fwd": 0.0, "wgrad": 0.0, "bwd": 0.0, "fused": 0.0}      # fused: pass A + pass B of a layer in one launch (gspn_mlp_bwd_fused)
     flops = 0.0
     nbytes = 0.0
     executed = 0.0
@@ -582,7 +582,7 @@ def mlp_roofline(mlp_mod, eager_step, state, reps=3):
     tf = flops / (total_ms * 1e-3) / 1e12
     hbm_floor_ms = nbytes / (HBM_PEAK_GBS * 1e9) * 1e3
     return {"bound": "mfma_f32", "unit": "TFLOP/s", "peak": MFMA_F32_PEAK_TFLOPS, "achieved": tf, "frac": tf / MFMA_F32_PEAK_TFLOPS,
-            "kernels": "mlp_fwd_* / wgrad_* (+ finalize) / mlp_bwd_data_* of the 16 layers of pn2_fea_extractor",
+            "kernels": "fwd_* / wgrad_* (+ finalize) / bwd_* (pass B) / bwd_fused_* (both passes) of the 16 layers of pn2_fea_extractor",
             "flops_per_step": flops, "executed_flops_per_step": executed, "executed_TFLOPs": executed / (total_ms * 1e-3) / 1e12,
             "gemm_ms_per_step": total_ms, "ms_by_pass": by,
             "algorithmic_bytes_per_step": nbytes, "algorithmic_TBps": nbytes / (total_ms * 1e-3) / 1e12,

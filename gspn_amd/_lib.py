@@ -83,6 +83,7 @@ SIGNATURES = {
     "gspn_mlp_bwd_wgrad_known": [_L, _I, _I, _c.POINTER(DyArgs), _P, _I, _P, _P, _c.POINTER(GatherArgs), _P, _P, _P],
     "gspn_mlp_bwd_data_ex": [_L, _I, _I, _c.POINTER(DyArgs), _P, _I, _I, _P, _I, _P, _I, _P, _P, _F, _I, _I, _P, _P,
                              _P, _I, _P, _P, _P, _P, _F, _P, _c.POINTER(_I), _P],
+    "gspn_mlp_bwd_fused": [_L, _I, _I, _c.POINTER(DyArgs), _P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _F, _P, _c.POINTER(_I), _P],
     "gspn_bn_finalize": [_L, _I, _P, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P],
     "gspn_bn_finalize_parts": [_L, _I, _P, _I, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P],
     "gspn_bnrelu_maxpool": [_L, _I, _I, _P, _I, _P, _P, _P, _P, _P],
@@ -109,6 +110,7 @@ SIGNATURES = {
 SPECIAL = {
     "gspn_ball_threshold": ([_F], _F),
     "gspn_mlp_bwd_work_bytes": ([_L, _I, _I], _L),
+    "gspn_mlp_bwd_fused_work_bytes": ([_L, _I, _I], _L),
     "gspn_mlp_fwd_stats_bytes": ([_L, _I], _L),
     "gspn_fps_cells_ws_bytes": ([_I, _I], _L),
     "gspn_fps_multi_ws_bytes": ([_I, _I], _L),
@@ -121,7 +123,7 @@ SPECIAL = {
     "gspn_inverse_lists_work_ints": ([_I, _I, _I], _L),
 }
 
-ABI_VERSION = 3         # == GSPN_ABI_VERSION of include/gspn_hip.h this binding was written against
+ABI_VERSION = 4         # == GSPN_ABI_VERSION of include/gspn_hip.h this binding was written against
 
 _lib = None
 

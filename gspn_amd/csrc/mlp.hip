@@ -21,6 +21,7 @@
 // B[k=l>>5][j=l&31];  C/D: 16 registers, reg r -> row (r&3)+8*(r>>2)+4*(l>>5), col l&31.
 #include "common.h"
 #include <type_traits>
+#include <utility>
 #include <stdlib.h>
 #include <stdio.h>
 #include <algorithm>
@@ -1862,6 +1863,7 @@ static size_t ws_off_rp(int cin, int cout) { return ws_off_g3(cout) + sizeof(flo
 static size_t ws_off_gp(long nch, int cin, int cout) { return ws_off_rp(cin, cout) + sizeof(float) * (size_t)nch * 2 * cout; }
 static size_t ws_off_pp(long nch, int cin, int cout) { return (ws_off_gp(nch, cin, cout) + sizeof(float) * (size_t)nch * cin + 15) / 16 * 16; }
 static size_t ws_total(long nch, long nslots, int cin, int cout) { return ws_off_pp(nch, cin, cout) + sizeof(float) * (size_t)nslots * 2 * cin * cout; }
+extern "C" long gspn_mlp_bwd_fused_work_bytes(long rows, int cin, int cout);
 extern "C" long gspn_mlp_bwd_work_bytes(long rows, int cin, int cout) {
     if (rows <= 0 || cin <= 0 || cout <= 0) return GSPN_ERR_ARG;
     const WgradPlan p = wgrad_plan(rows, cin, cout), q = wgrad_plan(rows, cin, cout, true), r = wgrad_plan(rows, cin, cout, false, true);
@@ -1869,6 +1871,8 @@ extern "C" long gspn_mlp_bwd_work_bytes(long rows, int cin, int cout) {
     const size_t b = ws_total(q.nch, q.nslots, cin, cout), c = ws_total(r.nch, r.nslots, cin, cout);
     if (b > a) a = b;
     if (c > a) a = c;
+    const size_t f = (size_t)gspn_mlp_bwd_fused_work_bytes(rows, cin, cout);      // (one partial tile set per workgroup of the fused kernel)
+    if (f > a) a = f;
     return (long)a;
 }
 
@@ -3256,6 +3260,304 @@ static bool bwd_lean_try(long rows, int cin, int cout, const gspn_dy_args* a, co
 #undef BL_D
 #undef BL_GO
     return true;
+}
+// ============================================================================================
+// Pass A and pass B of one layer in ONE launch (r03): dW = x^T . dY and dX = dY . W^T from the same staged dY tile.
+// The two-launch form reads (x, Y, dZ) for dW and (Y, dZ, previous Y for the BN reductions) again for dX, and rebuilds dY from
+// (Y, dZ, coefficients) in both -- seven row streams and twice the vector work for four streams' worth of information.  Here a
+// workgroup walks row tiles; per tile it stages dY (built once) and the previous layer's raw output y_p (= x before BN + ReLU)
+// TRANSPOSED in LDS, and every wave runs two 32x32 products from them:
+//     dX tile (its 32 rows x 32 input channels)   += dY[rows, :] . W^T         A = dY column k, B = W^T (resident in LDS for the whole kernel)
+//     dW tile (32 input x 32 output channels)     += x^T[:, rows] . dY[rows, :]  A = relu(y_p*scale + shift) (two roundings, the forward's
+//                                                                               operand), B = dY; accumulated over ALL tiles of the workgroup
+// and the epilogue of dX takes the previous layer's BN reductions (sum dyh, sum dyh*xhat) with y_p read back from LDS instead of HBM.
+// Each workgroup leaves one partial dW tile set (slot = workgroup) for the usual fixed-order reduction (wgrad_dw_kernel, plain) and one
+// partial row of BN reductions: results do not depend on scheduling.  Shapes: dense dZ, known coefficients, cin and cout in {32, 64},
+// rows a multiple of the tile (128 / (cin/32)), 16-byte aligned pitches.
+// ============================================================================================
+// ---- MFMA operand streams from LDS with explicit immediates and explicit waits ------------------------------------------------------
+// hipcc pairs the unrolled operand reads of a k loop into ds_read2_b32 whose 8-bit offsets do not reach across k steps of a transposed
+// tile: it materialises one base register per pair (30 registers in the 64 x 64 fused kernel, an occupancy step) and waits lgkmcnt(0)
+// in front of every pair of MFMAs.  lds_product issues ds_read_b32 with 16-bit byte offsets from ONE base per operand, four k-pairs per
+// batch, the next batch in flight during the current batch's MFMAs.  The waits carry the operand registers as "+v" so that no use can
+// move above them; LDS returns in order, so `lgkmcnt(8)` with the next batch's eight reads behind it covers the current one whatever
+// else the compiler has in flight.
+template <int OFF> __device__ __forceinline__ void lds_rd(float& v, unsigned addr) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds_read_b32 offset field");
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const float* p) { return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float*)p; }
+#define LDS_WAIT(N_, A_, B_)                                                                                                             \
+    asm volatile("s_waitcnt lgkmcnt(" #N_ ")" : "+v"(A_[0]), "+v"(A_[1]), "+v"(A_[2]), "+v"(A_[3]), "+v"(B_[0]), "+v"(B_[1]), "+v"(B_[2]), "+v"(B_[3]) :: "memory")
+template <class F, int... Is> __device__ __forceinline__ void sfor_(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F> __device__ __forceinline__ void sfor(F&& f) { sfor_(f, std::make_integer_sequence<int, N>{}); }
+// acc += sum over NS k-pairs s of A_s x B_s, A_s at a_addr + s*SA bytes, B_s at b_addr + s*SB bytes (this lane's element of each operand);
+// XF: the A operand goes through relu(a*xs + xh), two roundings (the forward's operand form)
+template <int NS, int SA, int SB, bool XF, int ABL>
+__device__ __forceinline__ void lds_product(f32x16& acc, unsigned a_addr, unsigned b_addr, float xs, float xh) {
+    static_assert(NS % 4 == 0, "four k-pairs per batch");
+    constexpr int NB = NS / 4;
+    float a[2][4], b[2][4];
+    sfor<4>([&](auto u_) { constexpr int u = decltype(u_)::value; lds_rd<u * SA>(a[0][u], a_addr); lds_rd<u * SB>(b[0][u], b_addr); });
+    sfor<NB>([&](auto bi_) {
+        constexpr int bi = decltype(bi_)::value, cur = bi & 1, nxt = cur ^ 1;
+        if constexpr (bi + 1 < NB) {
+            sfor<4>([&](auto u_) {
+                constexpr int u = decltype(u_)::value;
+                lds_rd<((bi + 1) * 4 + u) * SA>(a[nxt][u], a_addr);
+                lds_rd<((bi + 1) * 4 + u) * SB>(b[nxt][u], b_addr);
+            });
+            LDS_WAIT(8, a[cur], b[cur]);
+        } else {
+            LDS_WAIT(0, a[cur], b[cur]);
+        }
+        sfor<4>([&](auto u_) {
+            constexpr int u = decltype(u_)::value;
+            float x = a[cur][u];
+            if constexpr (XF) { x = x * xs + xh; x = x > 0.f ? x : 0.f; }
+            if constexpr (ABL) acc[u] += x * b[cur][u];
+            else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x, b[cur][u], acc, 0, 0, 0);
+        });
+    });
+}
+#ifndef GSPN_FUSED_ABL
+#define GSPN_FUSED_ABL 0
+#endif
+template <int CI, int CO, bool RSUM>
+__global__ __launch_bounds__(256) void bwd_fused_kernel(int rows, gspn_dy_args a, const float* __restrict__ W, const float* __restrict__ Xp, int ldxp,
+                                                        const float* __restrict__ in_scale, const float* __restrict__ in_shift,
+                                                        float* __restrict__ dX, int ldx, float* __restrict__ PP, RsumArgs rs) {
+    constexpr int CIN = 32 * CI, COUT = 32 * CO;
+    constexpr int TR = 128 / CI;                                  // rows per tile: (TR / 32) * CI = 4 dX tiles, one per wave
+    constexpr int LD = TR + 1, LDW = CIN + 1;                     // odd pitches: lanes along either axis of a transposed tile hit distinct banks
+    constexpr int S = (CI * CO >= 4) ? 1 : 4 / (CI * CO);         // waves sharing one dW tile (each takes TR / S rows of every row tile)
+    constexpr int QY = 8 * CO, RY = 256 / QY, PY = TR / RY;       // Y / dZ: quads per row, rows per pass, passes
+    constexpr int QX = 8 * CI, RX = 256 / QX, PX = TR / RX;       // y_p
+    __shared__ __attribute__((aligned(16))) float s_tile[COUT * LD + CIN * LD];
+    float* const sdY = s_tile;                                     // [o][r]
+    float* const sX = s_tile + COUT * LD;                          // [i][r]   raw y_p
+    __shared__ __attribute__((aligned(16))) float sW[COUT * LDW];  // [o][i]   W^T
+    __shared__ __attribute__((aligned(16))) float s_chan[5 * COUT];     // forward scale, MINUS shift, cA, cB, cC
+    static_assert(4 * 32 * 33 <= COUT * LD + CIN * LD, "the end-of-kernel reductions reuse the tile buffers");
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int bx = blockIdx.x, grid = gridDim.x;
+    const int ntiles = rows / TR;
+    for (int i = t; i < COUT; i += 256) {
+        s_chan[i] = a.scale[i];
+        s_chan[COUT + i] = -a.shift[i];
+        s_chan[2 * COUT + i] = a.cA[i];
+        s_chan[3 * COUT + i] = a.cB[i];
+        s_chan[4 * COUT + i] = a.cC[i];
+    }
+    for (int i = t; i < CIN * COUT; i += 256) {                   // W (cin, cout) row-major -> sW[o][i]
+        const int ci = i / COUT, o = i - ci * COUT;
+        sW[o * LDW + ci] = W[i];
+    }
+    const int kqy = (t % QY) * 4, ary = t / QY;
+    const int kqx = (t % QX) * 4, arx = t / QX;
+    const unsigned oy = (unsigned)(ary * a.ldy + kqy) * 4u, oz = (unsigned)(ary * a.ldz + kqy) * 4u, ox = (unsigned)(arx * ldxp + kqx) * 4u;
+    float4 ry[PY], rz[PY], rx[PX];
+    auto fetch = [&](int tile) {
+        const size_t m0 = (size_t)tile * TR;
+        const char* yb = reinterpret_cast<const char*>(a.Y + m0 * a.ldy);
+        const char* zb = reinterpret_cast<const char*>(a.dZ + m0 * a.ldz);
+        const char* xb = reinterpret_cast<const char*>(Xp + m0 * ldxp);
+#pragma unroll
+        for (int i = 0; i < PY; ++i) ry[i] = *reinterpret_cast<const float4*>(yb + (size_t)(RY * i) * a.ldy * 4 + oy);
+#pragma unroll
+        for (int i = 0; i < PY; ++i) rz[i] = *reinterpret_cast<const float4*>(zb + (size_t)(RY * i) * a.ldz * 4 + oz);
+#pragma unroll
+        for (int i = 0; i < PX; ++i) rx[i] = *reinterpret_cast<const float4*>(xb + (size_t)(RX * i) * ldxp * 4 + ox);
+    };
+    auto commit = [&]() {
+        const float4 q_sc = *reinterpret_cast<const float4*>(s_chan + kqy), q_ns = *reinterpret_cast<const float4*>(s_chan + COUT + kqy);
+        const float4 q_a = *reinterpret_cast<const float4*>(s_chan + 2 * COUT + kqy), q_b = *reinterpret_cast<const float4*>(s_chan + 3 * COUT + kqy);
+        const float4 q_c = *reinterpret_cast<const float4*>(s_chan + 4 * COUT + kqy);
+        const float sc[4] = {q_sc.x, q_sc.y, q_sc.z, q_sc.w}, ns[4] = {q_ns.x, q_ns.y, q_ns.z, q_ns.w};
+        const float cA[4] = {q_a.x, q_a.y, q_a.z, q_a.w}, cB[4] = {q_b.x, q_b.y, q_b.z, q_b.w}, cC[4] = {q_c.x, q_c.y, q_c.z, q_c.w};
+#pragma unroll
+        for (int i = 0; i < PY; ++i) {
+            const float yv[4] = {ry[i].x, ry[i].y, ry[i].z, ry[i].w};
+            const float zv[4] = {rz[i].x, rz[i].y, rz[i].z, rz[i].w};
+            float* d = sdY + kqy * LD + ary + RY * i;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#if GSPN_FUSED_ABL & 4
+                d[j * LD] = yv[j] + zv[j];
+#else
+                const float dyh = yv[j] * sc[j] > ns[j] ? zv[j] : 0.f;                                   // relu_open: the forward's own mask
+                d[j * LD] = __builtin_fmaf(cA[j], dyh, __builtin_fmaf(cB[j], yv[j], cC[j]));
+#endif
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < PX; ++i) {
+            float* d = sX + kqx * LD + arx + RX * i;
+            d[0 * LD] = rx[i].x; d[1 * LD] = rx[i].y; d[2 * LD] = rx[i].z; d[3 * LD] = rx[i].w;
+        }
+    };
+    // this wave's tiles
+    const int rt = wave / CI, ct = wave % CI;                    // dX: rows rt*32.., input channels ct*32..
+    const int wt = wave / S, part = wave % S;                    // dW: tile wt = (mi, ni), rows part*(TR/S).. of every row tile
+    const int mi = wt / CO, ni = wt % CO;
+    constexpr int KW = TR / S;                                   // rows (k) of a row tile this wave feeds into its dW tile
+    const float* pa_x = sdY + kh * LD + rt * 32 + l31;           // dX  A: dY[row][k]   at sdY[k][row]
+    const float* pb_x = sW + kh * LDW + ct * 32 + l31;           //     B: W^T[k][i]    at sW[k][i]
+    const float* pa_w = sX + (mi * 32 + l31) * LD + part * KW + kh;     // dW  A: x[row k][i]  at sX[i][row]
+    const float* pb_w = sdY + (ni * 32 + l31) * LD + part * KW + kh;    //     B: dY[row k][o] at sdY[o][row]
+    const float w_sc = in_scale[mi * 32 + l31], w_sh = in_shift[mi * 32 + l31];
+    float p_sc = 0.f, p_ns = 0.f, p_rs = 0.f, p_mr = 0.f, r0s = 0.f, r1s = 0.f;
+    if constexpr (RSUM) {
+        const int col = ct * 32 + l31;
+        p_sc = rs.scale[col];
+        p_ns = -rs.shift[col];
+        p_rs = (float)(1.0 / sqrt((double)rs.var[col] + (double)rs.eps));
+        p_mr = -rs.mean[col] * p_rs;
+    }
+    const unsigned ax_x = lds_addr(pa_x), bx_x = lds_addr(pb_x), ax_w = lds_addr(pa_w), bx_w = lds_addr(pb_w);
+    const float* pe = sX + (ct * 32 + l31) * LD + rt * 32 + 4 * kh;     // the epilogue's y_p: rows 8*(r>>2) + (r&3) from here
+    const unsigned lo_x = (unsigned)((rt * 32 + 4 * kh) * ldx + ct * 32 + l31) * 4u;
+    f32x16 accw;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accw[r] = 0.f;
+    fetch(bx);
+    __syncthreads();                                             // the constants and W^T
+    for (int tile = bx; tile < ntiles; tile += grid) {
+        commit();
+        __syncthreads();
+        if (!(GSPN_FUSED_ABL & 32) && tile + grid < ntiles) fetch(tile + grid);            // the next tile's twelve quads fly during this tile's MFMAs
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        lds_product<COUT / 2, 2 * LD * 4, 2 * LDW * 4, false, (GSPN_FUSED_ABL & 1)>(acc, ax_x, bx_x, 0.f, 0.f);
+        lds_product<KW / 2, 8, 8, true, (GSPN_FUSED_ABL & 2)>(accw, ax_w, bx_w, w_sc, w_sh);
+        if constexpr (RSUM && !(GSPN_FUSED_ABL & 16)) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float yv[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) yv[r] = pe[8 * ((8 * h + r) >> 2) + (r & 3)];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const float dyh = yv[r] * p_sc > p_ns ? acc[8 * h + r] : 0.f;
+                    r0s += dyh;
+                    r1s = __builtin_fmaf(dyh, __builtin_fmaf(yv[r], p_rs, p_mr), r1s);
+                }
+            }
+        }
+        if (!(GSPN_FUSED_ABL & 8) || acc[0] == 1.2345f) {
+            // (opaque per tile: otherwise hipcc hoists the 16 (lane offset + row * pitch) sums out of the tile loop as 64-bit pairs)
+            unsigned lxx = lo_x;
+            asm volatile("" : "+v"(lxx));
+            const char* xrow = reinterpret_cast<const char*>(dX + (size_t)tile * TR * ldx);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                *reinterpret_cast<float*>(const_cast<char*>(xrow) + (size_t)(8 * (r >> 2) + (r & 3)) * ldx * 4 + lxx) = acc[r];
+        }
+        __syncthreads();
+    }
+    // ---- the workgroup's partial dW tile set -> slot bx; its BN-reduction row -> part[bx] ----
+    float* sred = s_tile;                                        // [4 waves][32][33] (the tile buffers are free now)
+    float* slot = PP + (size_t)bx * 2 * CIN * COUT;
+    if constexpr (S == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) slot[(size_t)(mi * 32 + c_row(r, lane)) * COUT + ni * 32 + l31] = accw[r];
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sred[(wave * 32 + c_row(r, lane)) * 33 + l31] = accw[r];
+        __syncthreads();
+        for (int i = t; i < CIN * COUT; i += 256) {
+            const int m = i / COUT, n = i - m * COUT;
+            const int w0 = ((m >> 5) * CO + (n >> 5)) * S;       // the first of the S waves of tile (m / 32, n / 32)
+            float v = 0.f;
+#pragma unroll
+            for (int q = 0; q < S; ++q) v += sred[((w0 + q) * 32 + (m & 31)) * 33 + (n & 31)];
+            slot[i] = v;
+        }
+        __syncthreads();
+    }
+    if constexpr (RSUM) {
+        float* sR = sX;                                          // [4 waves][2][32]
+        r0s += __shfl_xor(r0s, 32, 64);
+        r1s += __shfl_xor(r1s, 32, 64);
+        if (lane < 32) { sR[(wave * 2 + 0) * 32 + lane] = r0s; sR[(wave * 2 + 1) * 32 + lane] = r1s; }
+        __syncthreads();
+        float* pr = rs.part + (size_t)bx * 2 * CIN;
+        for (int j = t; j < CIN; j += 256) {
+            const int c = j >> 5;                                // waves with wave % CI == c hold column block c
+            float v0 = 0.f, v1 = 0.f;
+            for (int w = c; w < 4; w += CI) { v0 += sR[(w * 2 + 0) * 32 + (j & 31)]; v1 += sR[(w * 2 + 1) * 32 + (j & 31)]; }
+            pr[j] = v0;
+            pr[CIN + j] = v1;
+        }
+    }
+}
+// workgroups of the fused kernel for (rows, cin, cout); 0 = the shape is not one of its own.  The grid is what the chip holds AT ONCE
+// (the kernel's measured occupancy x the planned CUs): 672 workgroups of the two-per-CU 64 x 64 instance ran as one and a half rounds
+// -- 90 us against 73 for 448 (tools/fused_ablate.py, GSPN_BWD_FUSED_BPC sweep).
+template <int CI, int CO> static int fused_occupancy() {
+    static int occ = 0;
+    if (!occ) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bwd_fused_kernel<CI, CO, true>, 256, 0) != hipSuccess || n < 1) n = 2;
+        occ = n > 4 ? 4 : n;
+    }
+    return occ;
+}
+static unsigned fused_grid(long rows, int cin, int cout) {
+    static const int on = env_int("GSPN_BWD_FUSED", 1);
+    if (!on) return 0;
+    if (!((cin == 32 || cin == 64) && (cout == 32 || cout == 64))) return 0;
+    const int tr = 128 / (cin / 32);
+    if (rows < 65536 || rows % tr || rows % 128) return 0;        // (short layers: their launches are latency chains, two kernels overlap better)
+    static const int bpc_env = env_int("GSPN_BWD_FUSED_BPC", 0);
+    int bpc = cin == 32 ? (cout == 32 ? fused_occupancy<1, 1>() : fused_occupancy<1, 2>()) : (cout == 32 ? fused_occupancy<2, 1>() : fused_occupancy<2, 2>());
+    if (bpc_env > 0) bpc = bpc_env > 4 ? 4 : bpc_env;
+    // never more workgroups than 128-row tiles: the BN-reduction buffer (gspn_rsum_part_floats) holds one row per such tile at most
+    const long ntiles = rows / 128, cap = (long)GSPN_PLAN_CUS * bpc;
+    return (unsigned)(ntiles < cap ? ntiles : cap);
+}
+extern "C" long gspn_mlp_bwd_fused_work_bytes(long rows, int cin, int cout) {
+    const unsigned g = fused_grid(rows, cin, cout);
+    return g ? (long)(sizeof(float) * (size_t)g * 2 * cin * cout + 64) : 0;
+}
+// One launch for both backward products of a layer with KNOWN coefficients (a->cA/cB/cC final) and a dense upstream gradient:
+//   dW (cin, cout) = relu(Xp*in_scale + in_shift)^T . dY        (work: gspn_mlp_bwd_work_bytes(rows, cin, cout) bytes, as for pass A)
+//   dX (rows, ldx >= cin) = dY . W^T
+//   part (optional, with Xp's layer statistics): the BN reductions of dX against Xp, as gspn_mlp_bwd_data_ex leaves them; *nparts_out rows
+// GSPN_ERR_UNSUPPORTED for every shape outside the kernel's own (the caller then runs pass A and pass B).
+extern "C" int gspn_mlp_bwd_fused(long rows, int cin, int cout, const gspn_dy_args* a, const float* W, const float* Xp, int ldxp, const float* in_scale,
+                                  const float* in_shift, float* dX, int ldx, float* work, float* dW, const float* mean_p, const float* var_p,
+                                  float eps_p, float* part, int* nparts_out, void* stream) {
+    if (rows <= 0 || cin <= 0 || cout <= 0 || !a || !a->Y || !a->scale || !a->shift || !W || !Xp || !dX || !work || !dW || ldxp < cin || ldx < cin)
+        return GSPN_ERR_ARG;
+    if (part && (!mean_p || !var_p || !nparts_out)) return GSPN_ERR_ARG;
+    const unsigned g = fused_grid(rows, cin, cout);
+    if (!g || !a->dZ || !a->cA || !a->cB || !a->cC || !in_scale || !in_shift) return GSPN_ERR_UNSUPPORTED;
+    if (!vec_ok(a->Y, a->ldy) || !vec_ok(a->dZ, a->ldz) || !vec_ok(Xp, ldxp) || (ldx & 3) || ((uintptr_t)dX % 16) || ((uintptr_t)work % 16))
+        return GSPN_ERR_UNSUPPORTED;
+    const long maxld = std::max(std::max((long)a->ldy, (long)a->ldz), std::max((long)ldx, (long)ldxp));
+    if (rows * maxld >= (1L << 30)) return GSPN_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    // in_scale / in_shift ARE the previous layer's forward scale / shift: the epilogue's mask uses the same pair
+    RsumArgs rs{Xp, ldxp, in_scale, in_shift, mean_p, var_p, eps_p, part};
+    float* PP = work;
+#define BF_GO(CI_, CO_)                                                                                                                   \
+    do {                                                                                                                                   \
+        if (part) hipLaunchKernelGGL((bwd_fused_kernel<CI_, CO_, true>), dim3(g), dim3(256), 0, st, (int)rows, *a, W, Xp, ldxp, in_scale, in_shift, dX, ldx, PP, rs);  \
+        else hipLaunchKernelGGL((bwd_fused_kernel<CI_, CO_, false>), dim3(g), dim3(256), 0, st, (int)rows, *a, W, Xp, ldxp, in_scale, in_shift, dX, ldx, PP, rs); \
+    } while (0)
+    if (cin == 32 && cout == 32) BF_GO(1, 1);
+    else if (cin == 32 && cout == 64) BF_GO(1, 2);
+    else if (cin == 64 && cout == 32) BF_GO(2, 1);
+    else BF_GO(2, 2);
+#undef BF_GO
+    if (nparts_out) *nparts_out = (int)g;
+    DwJob j = dw_job(rows, cin, cout, (long)g, PP, nullptr, nullptr, nullptr, nullptr, 0.f, 0, 0, dW);
+    j.plain = 1;
+    hipLaunchKernelGGL(wgrad_dw_kernel, dim3((unsigned)dw_blocks((long)cin * cout, g, 1024)), dim3(1024), 0, st, j);
+    return gspn_launch_status();
 }
 static int bwd_data_launch(long rows, int cin, int cout, const gspn_dy_args* a, const float* W, int col0, int ncols, float* dX, int ldx, const DwJob* dwj,
                            hipStream_t st, const RsumArgs* rsp = nullptr, int* nparts_out = nullptr) {

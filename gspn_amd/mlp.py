@@ -35,6 +35,9 @@ PREAGG_MIN_C = int(os.environ.get("GSPN_PREAGG_MIN_C", "16"))      # below this 
 POOLTOP_STREAM = os.environ.get("GSPN_POOLTOP_STREAM", "1") != "0"
 # one launch for pass B + the dW reduction of the same layer (gspn_mlp_bwd_data_dw) instead of two
 FUSE_DW = os.environ.get("GSPN_FUSE_DW", "1") != "0"
+# pass A and pass B of a layer in one launch where the library has the kernel for the shape (gspn_mlp_bwd_fused: both products from one staged
+# dY tile); the library's own switch is GSPN_BWD_FUSED
+FUSED_BWD = os.environ.get("GSPN_FUSED_BWD", "1") != "0"
 _side_streams = {}
 
 # Optional SyncBN: batch statistics over the global batch of all ranks instead of per replica -- what the single-GPU reference
@@ -279,6 +282,34 @@ class _MlpStack(torch.autograd.Function):
                 wcin = int(lib.gspn_mlp_gather_cin(ctypes.byref(ctx.gargs))) if gather0 is not None else cin
                 work = torch.empty(int(lib.gspn_mlp_bwd_work_bytes(rows, wcin, cout)) // 4 + 4, dtype=torch.float32, device=dev)
                 has_dx = li > 0 or ctx.x_needs_grad
+                # ---- both passes in one launch (known coefficients, dense dz, an inner layer of a shape the fused kernel takes) ----
+                if (FUSED_BWD and known is not None and dz is not None and li > 0 and not DEFER_DW
+                        and int(lib.gspn_mlp_bwd_fused_work_bytes(rows, cin, cout)) > 0):
+                    prev = layers[li - 1]
+                    want_rsum = tr_all and prev.bn
+                    (_, _, _, _, _, pY, pmean, pvar, pscale, pshift) = ctx.saved[li - 1]
+                    dx = torch.empty((rows, cin), dtype=torch.float32, device=dev)
+                    part = torch.empty(int(lib.gspn_rsum_part_floats(rows, cin)), dtype=torch.float32, device=dev) if want_rsum else None
+                    npart = ctypes.c_int(0)
+                    ev = _tic()
+                    try:
+                        L.check(lib.gspn_mlp_bwd_fused(rows, cin, cout, ctypes.byref(a), L.ptr(lp.weights), L.ptr(xin), xld, L.ptr(in_scale), L.ptr(in_shift),
+                                                       L.ptr(dx), cin, L.ptr(work), L.ptr(dW), L.ptr(pmean), L.ptr(pvar), BN_EPS, L.ptr(part),
+                                                       ctypes.byref(npart), st), "mlp_bwd_fused")
+                        fused = True
+                    except NotImplementedError:
+                        fused = False
+                    if fused:
+                        _toc(ev, "fused", rows, cin, cout, 4.0 * rows * cin * cout)
+                        if want_rsum:
+                            coef[li - 1] = _coef_from_parts(lib, rows, cin, npart.value, part, pmean, pvar, prev, dev, st)
+                        g = [dW, dbias]
+                        if lp.bn:
+                            g += [dbeta, dgamma]
+                        grads = g + grads
+                        dz, ldz = dx, cin
+                        del a
+                        continue
                 fuse_dw = FUSE_DW and has_dx and not DEFER_DW and gather0 is None     # the dW reduction rides in spare workgroups of this layer's pass B
                 # ---- pass A ----
                 ev = _tic()

@@ -297,6 +297,40 @@ def test_early_coefficients_equal_the_two_product_pass(rows, cin, chans, ns, mon
         assert float((a_ - b_).abs().max()) <= 2e-5 * max(scale, 1e-3)
 
 
+@pytest.mark.parametrize("rows,cin,chans,ns", [(65536, 20, [64, 64, 64], None),      # 64 <- 64 twice (FP3's inner layers)
+                                               (131072, 6, [32, 32, 64], 32),         # 32 <- 32 (SA1's second layer)
+                                               (65536 + 128, 16, [32, 64, 32, 64], None),   # 64 <- 32 and 32 <- 64; rows not a multiple of the grid
+                                               (262144, 67, [64, 64, 64], None)])     # FP3 at the bench's row count
+def test_both_backward_passes_in_one_launch_equal_the_two_pass_form(rows, cin, chans, ns, monkeypatch):
+    """gspn_mlp_bwd_fused (dW and dX of a layer from one staged dY tile, the previous layer's BN reductions in its epilogue) against
+    pass A + pass B: dX takes the same products in the same order (equal to rounding of the dY form), dW sums the rows in another
+    order -- every gradient of the stack within 2e-5 of its scale; the fused path must really have run"""
+    from gspn_amd import mlp as M
+    g = torch.Generator().manual_seed(rows + cin)
+    ld = (cin + 3) // 4 * 4
+    x0 = torch.randn(rows, ld, generator=g)
+    x0[:, cin:] = 0
+    go = (torch.randn(rows // ns if ns else rows, chans[-1], generator=g) / rows).cuda()
+    res, kinds = [], []
+    for fused in (True, False):
+        monkeypatch.setattr(M, "FUSED_BWD", fused)
+        layers = to_layers(make_params(chans, cin, seed=3))
+        x = x0.cuda().requires_grad_(True)
+        out = M.mlp_stack(x, cin, layers, True, 0.7, pool_ns=ns)
+        M.PROFILE = []
+        try:
+            out.backward(go)
+            torch.cuda.synchronize()
+            kinds.append([e[0] for e in M.PROFILE])
+        finally:
+            M.PROFILE = None
+        res.append([x.grad[:, :cin].clone()] + [t.grad.clone() for lp in layers for t in lp.tensors()])
+    assert "fused" in kinds[0] and "fused" not in kinds[1]
+    for a_, b_ in zip(res[0], res[1]):
+        scale = float(b_.abs().max())
+        assert float((a_ - b_).abs().max()) <= 2e-5 * max(scale, 1e-9), (float((a_ - b_).abs().max()), scale)
+
+
 @pytest.mark.parametrize("stream", [True, False])
 @pytest.mark.parametrize("rows,cin,chans", [(4096, 32, [32, 64]), (2048 + 64, 6, [32, 32, 64]), (8192, 20, [24, 64, 128]), (1024, 64, [64, 128])])
 def test_pooled_top_layer_backward_from_its_input(rows, cin, chans, stream, monkeypatch):

@@ -27,12 +27,12 @@ for _ in range(reps):
 torch.cuda.synchronize()
 prof, M.PROFILE = M.PROFILE, None
 n = len(prof) // reps
-tot = {"fwd": 0.0, "wgrad": 0.0, "bwd": 0.0}
+tot = {"fwd": 0.0, "wgrad": 0.0, "bwd": 0.0, "fused": 0.0}
 print("%-6s %8s %5s %5s %9s %9s %7s %7s %6s" % ("kind", "rows", "cin", "cout", "us", "floor_us", "TB/s", "TF", "x"))
 for i in range(n):
     kind, rows, cin, cout = prof[i][:4]
     us = np.median([prof[i + r * n][4].elapsed_time(prof[i + r * n][5]) for r in range(reps)]) * 1e3
-    by = 4.0 * rows * {"fwd": cin + cout, "wgrad": cin + 2 * cout, "bwd": 2 * cout + cin}[kind]
+    by = 4.0 * rows * {"fwd": cin + cout, "wgrad": cin + 2 * cout, "bwd": 2 * cout + cin, "fused": 2 * cout + 2 * cin}[kind]
     fl = prof[i][6]
     floor = max(by / 6.3e12, fl / 157.3e12) * 1e6
     tot[kind] += us
