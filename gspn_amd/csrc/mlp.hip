@@ -760,6 +760,62 @@ extern "C" long gspn_mlp_fwd_stats_bytes(long rows, int cout) {
 }
 static inline bool vec_ok(const void* p, int ld) { return (ld % 4 == 0) && (((uintptr_t)p) % 16 == 0); }
 
+// ---- MFMA operand streams from LDS with explicit immediates and explicit waits ------------------------------------------------------
+// hipcc pairs the unrolled operand reads of a k loop into ds_read2_b32 whose 8-bit offsets do not reach across k steps of a transposed
+// tile: it materialises one base register per pair (30 registers in the 64 x 64 fused kernel, an occupancy step) and waits lgkmcnt(0)
+// in front of every pair of MFMAs.  lds_product issues ds_read_b32 with 16-bit byte offsets from ONE base per operand, four k-pairs per
+// batch, the next batch in flight during the current batch's MFMAs.  The waits carry the operand registers as "+v" so that no use can
+// move above them; LDS returns in order, so `lgkmcnt(8)` with the next batch's eight reads behind it covers the current one whatever
+// else the compiler has in flight.
+template <int OFF> __device__ __forceinline__ void lds_rd(float& v, unsigned addr) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds_read_b32 offset field");
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const float* p) { return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float*)p; }
+#define LDS_WAIT(N_, A_, B_)                                                                                                             \
+    asm volatile("s_waitcnt lgkmcnt(" #N_ ")" : "+v"(A_[0]), "+v"(A_[1]), "+v"(A_[2]), "+v"(A_[3]), "+v"(B_[0]), "+v"(B_[1]), "+v"(B_[2]), "+v"(B_[3]) :: "memory")
+// wait until at most CNT LDS operations are outstanding; the N registers of `v` are tied to the wait
+template <int CNT, int N> __device__ __forceinline__ void lds_wait_n(float (&v)[N]) {
+    static_assert(N == 4 || N == 8 || N == 16, "operand batch");
+    static_assert(CNT >= 0 && CNT <= 15, "lgkmcnt is a 4-bit counter");
+    if constexpr (N == 4) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) : "n"(CNT) : "memory");
+    else if constexpr (N == 8)
+        asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) : "n"(CNT) : "memory");
+    else
+        asm volatile("s_waitcnt lgkmcnt(%16)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),
+                     "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]) : "n"(CNT) : "memory");
+}
+template <class F, int... Is> __device__ __forceinline__ void sfor_(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F> __device__ __forceinline__ void sfor(F&& f) { sfor_(f, std::make_integer_sequence<int, N>{}); }
+// acc += sum over NS k-pairs s of A_s x B_s, A_s at a_addr + s*SA bytes, B_s at b_addr + s*SB bytes (this lane's element of each operand);
+// XF: the A operand goes through relu(a*xs + xh), two roundings (the forward's operand form)
+template <int NS, int SA, int SB, bool XF, int ABL>
+__device__ __forceinline__ void lds_product(f32x16& acc, unsigned a_addr, unsigned b_addr, float xs, float xh) {
+    static_assert(NS % 4 == 0, "four k-pairs per batch");
+    constexpr int NB = NS / 4;
+    float a[2][4], b[2][4];
+    sfor<4>([&](auto u_) { constexpr int u = decltype(u_)::value; lds_rd<u * SA>(a[0][u], a_addr); lds_rd<u * SB>(b[0][u], b_addr); });
+    sfor<NB>([&](auto bi_) {
+        constexpr int bi = decltype(bi_)::value, cur = bi & 1, nxt = cur ^ 1;
+        if constexpr (bi + 1 < NB) {
+            sfor<4>([&](auto u_) {
+                constexpr int u = decltype(u_)::value;
+                lds_rd<((bi + 1) * 4 + u) * SA>(a[nxt][u], a_addr);
+                lds_rd<((bi + 1) * 4 + u) * SB>(b[nxt][u], b_addr);
+            });
+            LDS_WAIT(8, a[cur], b[cur]);
+        } else {
+            LDS_WAIT(0, a[cur], b[cur]);
+        }
+        sfor<4>([&](auto u_) {
+            constexpr int u = decltype(u_)::value;
+            float x = a[cur][u];
+            if constexpr (XF) { x = x * xs + xh; x = x > 0.f ? x : 0.f; }
+            if constexpr (ABL) acc[u] += x * b[cur][u];
+            else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x, b[cur][u], acc, 0, 0, 0);
+        });
+    });
+}
 // ============================================================================================
 // Forward, lean form of the register-staged kernel (r03; see bwd_lean_kernel for the reasoning: these kernels are bound by the vector
 // instructions they issue around the MFMAs, and most of those were 64-bit index arithmetic, clamps and masks).  Shapes: 16-byte aligned
@@ -3275,51 +3331,6 @@ static bool bwd_lean_try(long rows, int cin, int cout, const gspn_dy_args* a, co
 // partial row of BN reductions: results do not depend on scheduling.  Shapes: dense dZ, known coefficients, cin and cout in {32, 64},
 // rows a multiple of the tile (128 / (cin/32)), 16-byte aligned pitches.
 // ============================================================================================
-// ---- MFMA operand streams from LDS with explicit immediates and explicit waits ------------------------------------------------------
-// hipcc pairs the unrolled operand reads of a k loop into ds_read2_b32 whose 8-bit offsets do not reach across k steps of a transposed
-// tile: it materialises one base register per pair (30 registers in the 64 x 64 fused kernel, an occupancy step) and waits lgkmcnt(0)
-// in front of every pair of MFMAs.  lds_product issues ds_read_b32 with 16-bit byte offsets from ONE base per operand, four k-pairs per
-// batch, the next batch in flight during the current batch's MFMAs.  The waits carry the operand registers as "+v" so that no use can
-// move above them; LDS returns in order, so `lgkmcnt(8)` with the next batch's eight reads behind it covers the current one whatever
-// else the compiler has in flight.
-template <int OFF> __device__ __forceinline__ void lds_rd(float& v, unsigned addr) {
-    static_assert(OFF >= 0 && OFF < 65536, "ds_read_b32 offset field");
-    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
-}
-__device__ __forceinline__ unsigned lds_addr(const float* p) { return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float*)p; }
-#define LDS_WAIT(N_, A_, B_)                                                                                                             \
-    asm volatile("s_waitcnt lgkmcnt(" #N_ ")" : "+v"(A_[0]), "+v"(A_[1]), "+v"(A_[2]), "+v"(A_[3]), "+v"(B_[0]), "+v"(B_[1]), "+v"(B_[2]), "+v"(B_[3]) :: "memory")
-template <class F, int... Is> __device__ __forceinline__ void sfor_(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
-template <int N, class F> __device__ __forceinline__ void sfor(F&& f) { sfor_(f, std::make_integer_sequence<int, N>{}); }
-// acc += sum over NS k-pairs s of A_s x B_s, A_s at a_addr + s*SA bytes, B_s at b_addr + s*SB bytes (this lane's element of each operand);
-// XF: the A operand goes through relu(a*xs + xh), two roundings (the forward's operand form)
-template <int NS, int SA, int SB, bool XF, int ABL>
-__device__ __forceinline__ void lds_product(f32x16& acc, unsigned a_addr, unsigned b_addr, float xs, float xh) {
-    static_assert(NS % 4 == 0, "four k-pairs per batch");
-    constexpr int NB = NS / 4;
-    float a[2][4], b[2][4];
-    sfor<4>([&](auto u_) { constexpr int u = decltype(u_)::value; lds_rd<u * SA>(a[0][u], a_addr); lds_rd<u * SB>(b[0][u], b_addr); });
-    sfor<NB>([&](auto bi_) {
-        constexpr int bi = decltype(bi_)::value, cur = bi & 1, nxt = cur ^ 1;
-        if constexpr (bi + 1 < NB) {
-            sfor<4>([&](auto u_) {
-                constexpr int u = decltype(u_)::value;
-                lds_rd<((bi + 1) * 4 + u) * SA>(a[nxt][u], a_addr);
-                lds_rd<((bi + 1) * 4 + u) * SB>(b[nxt][u], b_addr);
-            });
-            LDS_WAIT(8, a[cur], b[cur]);
-        } else {
-            LDS_WAIT(0, a[cur], b[cur]);
-        }
-        sfor<4>([&](auto u_) {
-            constexpr int u = decltype(u_)::value;
-            float x = a[cur][u];
-            if constexpr (XF) { x = x * xs + xh; x = x > 0.f ? x : 0.f; }
-            if constexpr (ABL) acc[u] += x * b[cur][u];
-            else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x, b[cur][u], acc, 0, 0, 0);
-        });
-    });
-}
 #ifndef GSPN_FUSED_ABL
 #define GSPN_FUSED_ABL 0
 #endif
