@@ -79,6 +79,7 @@ SIGNATURES = {
     "gspn_mlp_fwd_gather": [_L, _c.POINTER(GatherArgs), _I, _P, _P, _P, _I, _P, _P],
     "gspn_mlp_bwd_wgrad_gather": [_L, _c.POINTER(GatherArgs), _I, _c.POINTER(DyArgs), _P, _P, _P, _F, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "gspn_pool_rsum": [_L, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _F, _P, _c.POINTER(_I), _P],
+    "gspn_dense_rsum": [_L, _I, _P, _I, _P, _I, _P, _P, _P, _P, _F, _P, _c.POINTER(_I), _P],
     "gspn_mlp_bwd_coef": [_L, _I, _I, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P],
     "gspn_mlp_bwd_wgrad_known": [_L, _I, _I, _c.POINTER(DyArgs), _P, _I, _P, _P, _c.POINTER(GatherArgs), _P, _P, _P],
     "gspn_mlp_bwd_data_ex": [_L, _I, _I, _c.POINTER(DyArgs), _P, _I, _I, _P, _I, _P, _I, _P, _P, _F, _I, _I, _P, _P,
@@ -123,7 +124,7 @@ SPECIAL = {
     "gspn_inverse_lists_work_ints": ([_I, _I, _I], _L),
 }
 
-ABI_VERSION = 4         # == GSPN_ABI_VERSION of include/gspn_hip.h this binding was written against
+ABI_VERSION = 5         # == GSPN_ABI_VERSION of include/gspn_hip.h this binding was written against
 
 _lib = None
 

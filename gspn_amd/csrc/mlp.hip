@@ -2507,6 +2507,84 @@ extern "C" int gspn_pool_rsum(long groups, int ns, int c, const float* dPool, co
     *nparts_out = (int)nblk;
     return gspn_launch_status();
 }
+// top layer of a DENSE stack (the feature-propagation stacks: the upstream gradient is a full (rows, c) tensor): the two sums in one
+// streaming pass over (dZ, Y) -- 2 x rows x c x 4 bytes, a quad of channels per thread, a slab of rows per workgroup, fixed order --
+// so that this layer, too, runs pass A as one GEMM (or both passes as one launch) instead of the two-product form.
+__global__ __launch_bounds__(256) void dense_rsum_kernel(long rows, int c, const float* __restrict__ dZ, int ldz, const float* __restrict__ Y, int ldy,
+                                                         const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
+                                                         const float* __restrict__ var, float eps, float* __restrict__ part, long rpb) {
+    extern __shared__ float sred[];                       // [nsub][2][c]
+    const int cq = c >> 2, nsub = 256 / cq;
+    const int sub = threadIdx.x / cq, col = (threadIdx.x % cq) * 4;
+    const long g0 = blockIdx.x * rpb, g1 = min(rows, g0 + rpb);
+    float sc[4], ns[4], rs[4], mr[4], r0[4] = {0.f, 0.f, 0.f, 0.f}, r1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        sc[j] = scale[col + j];
+        ns[j] = -shift[col + j];
+        rs[j] = (float)(1.0 / sqrt((double)var[col + j] + (double)eps));
+        mr[j] = -mean[col + j] * rs[j];
+    }
+    if (sub < nsub) {
+        long g = g0 + sub;
+        for (; g + 3L * nsub < g1; g += 4L * nsub) {      // four rows in flight per thread
+            float4 z[4], y[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                z[u] = *reinterpret_cast<const float4*>(dZ + (g + (long)u * nsub) * ldz + col);
+                y[u] = *reinterpret_cast<const float4*>(Y + (g + (long)u * nsub) * ldy + col);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float zv[4] = {z[u].x, z[u].y, z[u].z, z[u].w}, yv[4] = {y[u].x, y[u].y, y[u].z, y[u].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float dyh = yv[j] * sc[j] > ns[j] ? zv[j] : 0.f;       // relu_open
+                    r0[j] += dyh;
+                    r1[j] = __builtin_fmaf(dyh, __builtin_fmaf(yv[j], rs[j], mr[j]), r1[j]);
+                }
+            }
+        }
+        for (; g < g1; g += nsub) {
+            const float4 z = *reinterpret_cast<const float4*>(dZ + g * ldz + col), y = *reinterpret_cast<const float4*>(Y + g * ldy + col);
+            const float zv[4] = {z.x, z.y, z.z, z.w}, yv[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float dyh = yv[j] * sc[j] > ns[j] ? zv[j] : 0.f;
+                r0[j] += dyh;
+                r1[j] = __builtin_fmaf(dyh, __builtin_fmaf(yv[j], rs[j], mr[j]), r1[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            sred[(sub * 2 + 0) * c + col + j] = r0[j];
+            sred[(sub * 2 + 1) * c + col + j] = r1[j];
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * c; i += 256) {
+        float v = 0.f;
+        for (int q = 0; q < nsub; ++q) v += sred[(size_t)q * 2 * c + i];
+        part[(size_t)blockIdx.x * 2 * c + i] = v;
+    }
+}
+// part [*nparts_out][2][c] <- (sum dyh, sum dyh * xhat) of a layer with a dense upstream gradient dZ (rows, ldz) and output Y (rows, ldy):
+// the input of gspn_mlp_bwd_coef.  c a multiple of 4 with c / 4 <= 256, 16-byte aligned pitches; GSPN_ERR_UNSUPPORTED otherwise.
+extern "C" int gspn_dense_rsum(long rows, int c, const float* dZ, int ldz, const float* Y, int ldy, const float* scale, const float* shift,
+                               const float* mean, const float* var, float eps, float* part, int* nparts_out, void* stream) {
+    if (rows <= 0 || c <= 0 || !dZ || !Y || ldz < c || ldy < c || !scale || !shift || !mean || !var || !part || !nparts_out) return GSPN_ERR_ARG;
+    if ((c & 3) || (c >> 2) > 256 || !vec_ok(dZ, ldz) || !vec_ok(Y, ldy)) return GSPN_ERR_UNSUPPORTED;
+    const int nsub = 256 / (c >> 2);
+    long nblk = (rows + 4L * nsub - 1) / (4L * nsub);                      // at least one four-row round per thread
+    if (nblk > RSUM_POOL_BLOCKS) nblk = RSUM_POOL_BLOCKS;
+    if (nblk < 1) nblk = 1;
+    const long rpb = (rows + nblk - 1) / nblk;
+    nblk = (rows + rpb - 1) / rpb;
+    hipLaunchKernelGGL(dense_rsum_kernel, dim3((unsigned)nblk), dim3(256), sizeof(float) * 2 * c * nsub, (hipStream_t)stream, rows, c, dZ, ldz, Y, ldy, scale, shift,
+                       mean, var, eps, part, rpb);
+    *nparts_out = (int)nblk;
+    return gspn_launch_status();
+}
 __global__ __launch_bounds__(256) void bwd_coef_kernel(long rows, int c, int nparts, const float* __restrict__ part, const float* __restrict__ mean,
                                                        const float* __restrict__ var, const float* __restrict__ gamma, float eps,
                                                        float* __restrict__ cA, float* __restrict__ cB, float* __restrict__ cC,

@@ -38,6 +38,9 @@ FUSE_DW = os.environ.get("GSPN_FUSE_DW", "1") != "0"
 # pass A and pass B of a layer in one launch where the library has the kernel for the shape (gspn_mlp_bwd_fused: both products from one staged
 # dY tile); the library's own switch is GSPN_BWD_FUSED
 FUSED_BWD = os.environ.get("GSPN_FUSED_BWD", "1") != "0"
+# the top layer of a stack with a dense upstream gradient takes its BN reductions in a streaming pre-pass (gspn_dense_rsum) from this many rows on
+DENSE_TOP_RSUM = os.environ.get("GSPN_DENSE_TOP_RSUM", "1") != "0"
+DENSE_TOP_MIN_ROWS = int(os.environ.get("GSPN_DENSE_TOP_MIN_ROWS", "65536"))
 _side_streams = {}
 
 # Optional SyncBN: batch statistics over the global batch of all ranks instead of per replica -- what the single-GPU reference
@@ -254,6 +257,18 @@ class _MlpStack(torch.autograd.Function):
                                                cout if yarg is None else 0, L.ptr(scale), L.ptr(shift),
                                                L.ptr(mean), L.ptr(var), BN_EPS, L.ptr(part), ctypes.byref(npart), st), "pool_rsum")
                     coef[li] = _coef_from_parts(lib, rows, cout, npart.value, part, mean, var, lp, dev, st)
+                # ---- early coefficients of the top layer of a DENSE stack: one streaming pass over (d_out, Y); worth its launch on the long
+                #      layers only (the two-product pass A of a short layer costs less than the extra dependent kernels) ----
+                if (tr_all and DENSE_TOP_RSUM and lp.bn and dz is not None and li == len(layers) - 1 and li not in coef and li > 0
+                        and rows >= DENSE_TOP_MIN_ROWS):
+                    part = torch.empty(int(lib.gspn_rsum_part_floats(rows, cout)), dtype=torch.float32, device=dev)
+                    npart = ctypes.c_int(0)
+                    try:
+                        L.check(lib.gspn_dense_rsum(rows, cout, L.ptr(dz), ldz, L.ptr(y), cout, L.ptr(scale), L.ptr(shift), L.ptr(mean), L.ptr(var),
+                                                    BN_EPS, L.ptr(part), ctypes.byref(npart), st), "dense_rsum")
+                        coef[li] = _coef_from_parts(lib, rows, cout, npart.value, part, mean, var, lp, dev, st)
+                    except NotImplementedError:
+                        pass
                 known = coef.get(li)
                 if known is not None:
                     cA, cB, cC, dgamma, dbeta, dbias = known

@@ -33,7 +33,7 @@ extern "C" {
  * compares it with gspn_abi_version() of the library it loaded (gspn_amd/_lib.py raises on a mismatch: a stale .so fails loudly).
  *   1: round 1.   2: round 2 (gspn_fps_background removed, ~30 entry points added, finalize / workspace layouts changed).
  *   3: round 3 (gspn_sa_rel_shift, gspn_bn_apply, gspn_mlp_gemm_*, gspn_small_geometry, status word of the multi-CU FPS checked). */
-#define GSPN_ABI_VERSION 4
+#define GSPN_ABI_VERSION 5
 int gspn_dist_policy(void);
 int gspn_abi_version(void);
 
@@ -347,6 +347,10 @@ struct gspn_gather_args;
 long gspn_rsum_part_floats(long rows, int c);
 int gspn_pool_rsum(long groups, int ns, int c, const float* dPool, const int* arg, const float* Y, int ldy, const float* scale,
                    const float* shift, const float* mean, const float* var, float eps, float* part, int* nparts_out, void* stream);
+/* the same sums for the top layer of a stack with a DENSE upstream gradient dZ (rows, ldz): one streaming pass over (dZ, Y).
+ * c a multiple of 4, c <= 1024, 16-byte aligned pitches (GSPN_ERR_UNSUPPORTED otherwise: use gspn_mlp_bwd_wgrad's two-product form). */
+int gspn_dense_rsum(long rows, int c, const float* dZ, int ldz, const float* Y, int ldy, const float* scale, const float* shift,
+                    const float* mean, const float* var, float eps, float* part, int* nparts_out, void* stream);
 int gspn_mlp_bwd_coef(long rows, int c, int nparts, const float* part, const float* mean, const float* var, const float* gamma, float eps,
                       float* cA, float* cB, float* cC, float* dgamma, float* dbeta, float* dbias, void* stream);
 int gspn_mlp_bwd_wgrad_known(long rows, int cin, int cout, const gspn_dy_args* a, const float* X, int ldx, const float* in_scale,

@@ -331,6 +331,29 @@ def test_both_backward_passes_in_one_launch_equal_the_two_pass_form(rows, cin, c
         assert float((a_ - b_).abs().max()) <= 2e-5 * max(scale, 1e-9), (float((a_ - b_).abs().max()), scale)
 
 
+@pytest.mark.parametrize("rows,cin,chans", [(65536, 20, [64, 64, 64]), (65536 + 4, 12, [40, 128]), (70000, 8, [32, 36])])
+def test_dense_top_layer_reductions_in_a_pre_pass_equal_the_two_product_pass(rows, cin, chans, monkeypatch):
+    """gspn_dense_rsum: the top layer of a stack with a dense upstream gradient takes (sum dyh, sum dyh*xhat) in one streaming pass over
+    (d_out, Y) and then runs with known coefficients (one-GEMM pass A, or the fused launch) -- same gradients as the two-product pass A"""
+    from gspn_amd import mlp as M
+    g = torch.Generator().manual_seed(rows + cin)
+    ld = (cin + 3) // 4 * 4
+    x0 = torch.randn(rows, ld, generator=g)
+    x0[:, cin:] = 0
+    go = (torch.randn(rows, chans[-1], generator=g) / rows).cuda()
+    res = []
+    for pre in (True, False):
+        monkeypatch.setattr(M, "DENSE_TOP_RSUM", pre)
+        layers = to_layers(make_params(chans, cin, seed=5))
+        x = x0.cuda().requires_grad_(True)
+        out = M.mlp_stack(x, cin, layers, True, 0.7)
+        out.backward(go)
+        res.append([x.grad[:, :cin].clone()] + [t.grad.clone() for lp in layers for t in lp.tensors()])
+    for a_, b_ in zip(res[0], res[1]):
+        scale = float(b_.abs().max())
+        assert float((a_ - b_).abs().max()) <= 2e-5 * max(scale, 1e-9), (float((a_ - b_).abs().max()), scale)
+
+
 @pytest.mark.parametrize("stream", [True, False])
 @pytest.mark.parametrize("rows,cin,chans", [(4096, 32, [32, 64]), (2048 + 64, 6, [32, 32, 64]), (8192, 20, [24, 64, 128]), (1024, 64, [64, 128])])
 def test_pooled_top_layer_backward_from_its_input(rows, cin, chans, stream, monkeypatch):
