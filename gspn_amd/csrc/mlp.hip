@@ -3412,7 +3412,7 @@ static bool bwd_lean_try(long rows, int cin, int cout, const gspn_dy_args* a, co
 #ifndef GSPN_FUSED_ABL
 #define GSPN_FUSED_ABL 0
 #endif
-template <int CI, int CO, bool RSUM>
+template <int CI, int CO, bool RSUM, bool POOL32>      // POOL32: the upstream gradient is (rows / 32, cout) + arg-max rows (a max-pool over groups of 32 rows)
 __global__ __launch_bounds__(256) void bwd_fused_kernel(int rows, gspn_dy_args a, const float* __restrict__ W, const float* __restrict__ Xp, int ldxp,
                                                         const float* __restrict__ in_scale, const float* __restrict__ in_shift,
                                                         float* __restrict__ dX, int ldx, float* __restrict__ PP, RsumArgs rs) {
@@ -3445,17 +3445,30 @@ __global__ __launch_bounds__(256) void bwd_fused_kernel(int rows, gspn_dy_args a
     }
     const int kqy = (t % QY) * 4, ary = t / QY;
     const int kqx = (t % QX) * 4, arx = t / QX;
-    const unsigned oy = (unsigned)(ary * a.ldy + kqy) * 4u, oz = (unsigned)(ary * a.ldz + kqy) * 4u, ox = (unsigned)(arx * ldxp + kqx) * 4u;
-    float4 ry[PY], rz[PY], rx[PX];
+    const unsigned oy = (unsigned)(ary * a.ldy + kqy) * 4u, oz = POOL32 ? 0u : (unsigned)(ary * a.ldz + kqy) * 4u, ox = (unsigned)(arx * ldxp + kqx) * 4u;
+    constexpr int NG = TR / 32;                                   // pool groups per tile
+    constexpr int NZ = POOL32 ? NG : PY;
+    static_assert(!POOL32 || (RY <= 32 && 32 % RY == 0), "a pass of the pooled form stays inside one group");
+    float4 ry[PY], rz[NZ], rx[PX];
+    int4 rarg[POOL32 ? NG : 1];
     auto fetch = [&](int tile) {
         const size_t m0 = (size_t)tile * TR;
         const char* yb = reinterpret_cast<const char*>(a.Y + m0 * a.ldy);
-        const char* zb = reinterpret_cast<const char*>(a.dZ + m0 * a.ldz);
         const char* xb = reinterpret_cast<const char*>(Xp + m0 * ldxp);
 #pragma unroll
         for (int i = 0; i < PY; ++i) ry[i] = *reinterpret_cast<const float4*>(yb + (size_t)(RY * i) * a.ldy * 4 + oy);
+        if constexpr (POOL32) {                                   // this thread's four channels of the tile's NG groups
+            const size_t g0 = (size_t)tile * NG * COUT + kqy;
 #pragma unroll
-        for (int i = 0; i < PY; ++i) rz[i] = *reinterpret_cast<const float4*>(zb + (size_t)(RY * i) * a.ldz * 4 + oz);
+            for (int gi = 0; gi < NG; ++gi) {
+                rz[gi] = *reinterpret_cast<const float4*>(a.dPool + g0 + (size_t)gi * COUT);
+                rarg[gi] = *reinterpret_cast<const int4*>(a.pool_arg + g0 + (size_t)gi * COUT);
+            }
+        } else {
+            const char* zb = reinterpret_cast<const char*>(a.dZ + m0 * a.ldz);
+#pragma unroll
+            for (int i = 0; i < PY; ++i) rz[i] = *reinterpret_cast<const float4*>(zb + (size_t)(RY * i) * a.ldz * 4 + oz);
+        }
 #pragma unroll
         for (int i = 0; i < PX; ++i) rx[i] = *reinterpret_cast<const float4*>(xb + (size_t)(RX * i) * ldxp * 4 + ox);
     };
@@ -3468,7 +3481,17 @@ __global__ __launch_bounds__(256) void bwd_fused_kernel(int rows, gspn_dy_args a
 #pragma unroll
         for (int i = 0; i < PY; ++i) {
             const float yv[4] = {ry[i].x, ry[i].y, ry[i].z, ry[i].w};
-            const float zv[4] = {rz[i].x, rz[i].y, rz[i].z, rz[i].w};
+            float zv[4];
+            if constexpr (POOL32) {                               // row ary + RY*i of the tile: group (ary + RY*i) / 32, row in group the remainder
+                constexpr int PPG = 32 / RY;                      // passes per group
+                const int gi = i / PPG, rin = ary + RY * (i % PPG);
+                const int av[4] = {rarg[gi].x, rarg[gi].y, rarg[gi].z, rarg[gi].w};
+                const float dv[4] = {rz[gi].x, rz[gi].y, rz[gi].z, rz[gi].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) zv[j] = av[j] == rin ? dv[j] : 0.f;
+            } else {
+                zv[0] = rz[i].x; zv[1] = rz[i].y; zv[2] = rz[i].z; zv[3] = rz[i].w;
+            }
             float* d = sdY + kqy * LD + ary + RY * i;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -3589,7 +3612,7 @@ template <int CI, int CO> static int fused_occupancy() {
     static int occ = 0;
     if (!occ) {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bwd_fused_kernel<CI, CO, true>, 256, 0) != hipSuccess || n < 1) n = 2;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bwd_fused_kernel<CI, CO, true, false>, 256, 0) != hipSuccess || n < 1) n = 2;
         occ = n > 4 ? 4 : n;
     }
     return occ;
@@ -3623,10 +3646,14 @@ extern "C" int gspn_mlp_bwd_fused(long rows, int cin, int cout, const gspn_dy_ar
         return GSPN_ERR_ARG;
     if (part && (!mean_p || !var_p || !nparts_out)) return GSPN_ERR_ARG;
     const unsigned g = fused_grid(rows, cin, cout);
-    if (!g || !a->dZ || !a->cA || !a->cB || !a->cC || !in_scale || !in_shift) return GSPN_ERR_UNSUPPORTED;
-    if (!vec_ok(a->Y, a->ldy) || !vec_ok(a->dZ, a->ldz) || !vec_ok(Xp, ldxp) || (ldx & 3) || ((uintptr_t)dX % 16) || ((uintptr_t)work % 16))
-        return GSPN_ERR_UNSUPPORTED;
-    const long maxld = std::max(std::max((long)a->ldy, (long)a->ldz), std::max((long)ldx, (long)ldxp));
+    const bool pooled = a->dZ == nullptr;
+    if (!g || !a->cA || !a->cB || !a->cC || !in_scale || !in_shift) return GSPN_ERR_UNSUPPORTED;
+    if (pooled) {                                                 // a max-pool over groups of 32 rows (nsample = 32): (rows / 32, cout) gradient + arg rows
+        if (!a->dPool || !a->pool_arg) return GSPN_ERR_ARG;
+        if (a->ns != 32 || ((uintptr_t)a->dPool % 16) || ((uintptr_t)a->pool_arg % 16)) return GSPN_ERR_UNSUPPORTED;
+    } else if (!vec_ok(a->dZ, a->ldz)) return GSPN_ERR_UNSUPPORTED;
+    if (!vec_ok(a->Y, a->ldy) || !vec_ok(Xp, ldxp) || (ldx & 3) || ((uintptr_t)dX % 16) || ((uintptr_t)work % 16)) return GSPN_ERR_UNSUPPORTED;
+    const long maxld = std::max(std::max((long)a->ldy, pooled ? 0L : (long)a->ldz), std::max((long)ldx, (long)ldxp));
     if (rows * maxld >= (1L << 30)) return GSPN_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     // in_scale / in_shift ARE the previous layer's forward scale / shift: the epilogue's mask uses the same pair
@@ -3634,8 +3661,11 @@ extern "C" int gspn_mlp_bwd_fused(long rows, int cin, int cout, const gspn_dy_ar
     float* PP = work;
 #define BF_GO(CI_, CO_)                                                                                                                   \
     do {                                                                                                                                   \
-        if (part) hipLaunchKernelGGL((bwd_fused_kernel<CI_, CO_, true>), dim3(g), dim3(256), 0, st, (int)rows, *a, W, Xp, ldxp, in_scale, in_shift, dX, ldx, PP, rs);  \
-        else hipLaunchKernelGGL((bwd_fused_kernel<CI_, CO_, false>), dim3(g), dim3(256), 0, st, (int)rows, *a, W, Xp, ldxp, in_scale, in_shift, dX, ldx, PP, rs); \
+        if (pooled) {                                                                                                                      \
+            if (part) hipLaunchKernelGGL((bwd_fused_kernel<CI_, CO_, true, true>), dim3(g), dim3(256), 0, st, (int)rows, *a, W, Xp, ldxp, in_scale, in_shift, dX, ldx, PP, rs);  \
+            else hipLaunchKernelGGL((bwd_fused_kernel<CI_, CO_, false, true>), dim3(g), dim3(256), 0, st, (int)rows, *a, W, Xp, ldxp, in_scale, in_shift, dX, ldx, PP, rs); \
+        } else if (part) hipLaunchKernelGGL((bwd_fused_kernel<CI_, CO_, true, false>), dim3(g), dim3(256), 0, st, (int)rows, *a, W, Xp, ldxp, in_scale, in_shift, dX, ldx, PP, rs);  \
+        else hipLaunchKernelGGL((bwd_fused_kernel<CI_, CO_, false, false>), dim3(g), dim3(256), 0, st, (int)rows, *a, W, Xp, ldxp, in_scale, in_shift, dX, ldx, PP, rs); \
     } while (0)
     if (cin == 32 && cout == 32) BF_GO(1, 1);
     else if (cin == 32 && cout == 64) BF_GO(1, 2);

@@ -39,6 +39,7 @@ FUSE_DW = os.environ.get("GSPN_FUSE_DW", "1") != "0"
 # dY tile); the library's own switch is GSPN_BWD_FUSED
 FUSED_BWD = os.environ.get("GSPN_FUSED_BWD", "1") != "0"
 # the top layer of a stack with a dense upstream gradient takes its BN reductions in a streaming pre-pass (gspn_dense_rsum) from this many rows on
+POOLTOP_FUSED = os.environ.get("GSPN_POOLTOP_FUSED", "1") != "0"       # the pooled (nsample = 32) top layer through the fused launch as well
 DENSE_TOP_RSUM = os.environ.get("GSPN_DENSE_TOP_RSUM", "1") != "0"
 DENSE_TOP_MIN_ROWS = int(os.environ.get("GSPN_DENSE_TOP_MIN_ROWS", "65536"))
 _side_streams = {}
@@ -298,7 +299,7 @@ class _MlpStack(torch.autograd.Function):
                 work = torch.empty(int(lib.gspn_mlp_bwd_work_bytes(rows, wcin, cout)) // 4 + 4, dtype=torch.float32, device=dev)
                 has_dx = li > 0 or ctx.x_needs_grad
                 # ---- both passes in one launch (known coefficients, dense dz, an inner layer of a shape the fused kernel takes) ----
-                if (FUSED_BWD and known is not None and dz is not None and li > 0 and not DEFER_DW
+                if (FUSED_BWD and known is not None and (dz is not None or (pool_ns == 32 and POOLTOP_FUSED)) and li > 0 and not DEFER_DW
                         and int(lib.gspn_mlp_bwd_fused_work_bytes(rows, cin, cout)) > 0):
                     prev = layers[li - 1]
                     want_rsum = tr_all and prev.bn

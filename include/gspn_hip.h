@@ -361,7 +361,7 @@ int gspn_mlp_bwd_data_ex(long rows, int cin, int cout, const gspn_dy_args* a, co
                          const float* Yp, int ldyp, const float* scale_p, const float* shift_p, const float* mean_p, const float* var_p,
                          float eps_p, float* part, int* nparts_out, void* stream);
 /* Pass A and pass B of one layer in ONE launch (r03): with known coefficients (a->cA/cB/cC final) and a dense upstream gradient
- * (a->dZ), dW (cin, cout) = relu(Xp*in_scale + in_shift)^T . dY and dX (rows, ldx >= cin) = dY . W^T come from the same staged dY tile;
+ * (a->dZ) or the gradient of a max-pool over groups of 32 rows (a->dZ NULL, a->dPool / a->pool_arg, a->ns == 32), dW (cin, cout) = relu(Xp*in_scale + in_shift)^T . dY and dX (rows, ldx >= cin) = dY . W^T come from the same staged dY tile;
  * Xp (rows, ldxp) is the previous layer's raw output, in_scale / in_shift its forward scale / shift.  part (optional, with that layer's
  * mean_p / var_p): its BN reductions, exactly what gspn_mlp_bwd_data_ex leaves (*nparts_out rows for gspn_mlp_bwd_coef).  work: the
  * gspn_mlp_bwd_work_bytes(rows, cin, cout) buffer.  GSPN_ERR_UNSUPPORTED outside cin, cout in {32, 64}, rows >= 65536 a multiple of 128,
