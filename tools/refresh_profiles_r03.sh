@@ -28,3 +28,9 @@ python tools/pmc_kernels.py gpurun_out/pmc_sq wgrad_stream mlp_fwd mlp_bwd_data 
 bash tools/pmc_ops.sh > $O/pmc_ops.out 2>&1; cp gpurun_out/r03_ops_pmc.json $O/
 bash tools/pmc_fps.sh > $O/pmc_fps.out 2>&1; cp gpurun_out/r02_fps_pmc_32768.json $O/r03_fps_pmc.json 2>/dev/null; cp gpurun_out/r02_fps_pmc_65536.json $O/r03_fps_multi_pmc_65536.json 2>/dev/null
 ls -la $O
+# 7. instruction counts per kernel of one eager step and the SIMD floor they imply (fp32 MFMA and vector instructions add on a SIMD)
+(cd /tmp; rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_ins -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra --no-graph --no-overlap > $GRAFT_REPO_ROOT/gpurun_out/pmc_ins.log 2>&1)
+python tools/simd_budget.py gpurun_out/pmc_ins 6 > $O/r03_simd_budget.txt 2>&1; rm -rf gpurun_out/pmc_ins
+# 8. the stand-alone microbenchmarks behind DESIGN.md's statements on what a SIMD overlaps
+for b in mfma_clock overlap overlap_rw coexec pattern; do [ -x tools/clk/$b ] && (echo "== $b"; tools/clk/$b) ; done > $O/r03_clk_microbenchmarks.txt 2>&1
+ls -la $O

@@ -1,5 +1,5 @@
 """per kernel of a rocprofv3 --pmc run (SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR): calls, average
-microseconds, instruction counts per launch and the SIMD floor they imply on gfx950 -- fp32 MFMAs (64 cycles) and vector instructions (~4.5)
+microseconds, instruction counts per launch and the SIMD floor they imply on gfx950 -- fp32 MFMAs (64 cycles) and vector instructions (~2.8, the v_fma rate of tools/clk/coexec.hip)
 of all waves ADD on a SIMD (tools/clk/coexec.hip) -- as microseconds over 1024 SIMDs at 2.3 GHz, and its share of the measured time.
 usage: simd_budget.py <rocprof dir> [min_us]"""
 import csv, glob, collections, sys
@@ -19,7 +19,7 @@ rows = []
 for k, c in agg.items():
     m = {n: sum(v) / len(v) for n, v in c.items()}
     us = sum(dur[k]) / len(dur[k])
-    floor = (64.0 * m.get("SQ_INSTS_MFMA", 0) + 4.5 * m.get("SQ_INSTS_VALU", 0)) / 1024 / 2300.0
+    floor = (64.0 * m.get("SQ_INSTS_MFMA", 0) + 2.8 * m.get("SQ_INSTS_VALU", 0)) / 1024 / 2300.0
     rows.append((us * len(dur[k]), k, len(dur[k]), us, m, floor))
 rows.sort(reverse=True)
 print("%-62s %5s %8s %9s %9s %9s %7s %8s %6s" % ("kernel", "calls", "us", "MFMA", "VALU", "LDS", "V/M", "simd_us", "share"))
