@@ -1,5 +1,6 @@
 // nndistance.hip -- tf_ops/nn_distance on gfx950: bidirectional nearest neighbour (Chamfer)
 // distance and its gradient.  Reference: tf_ops/nn_distance/tf_nndistance_g.cu:5-157.
+#include <stdlib.h>
 #include "common.h"
 
 // ============================================================================================
@@ -83,12 +84,66 @@ __global__ void nm_distance_grad_kernel(long total, int n, const float* __restri
         }
     }
 }
+// Small clouds (the model's use: b = B * NUM_SAMPLE clouds of 512 x 512 points, model_rpointnet.py:1346-1355): one workgroup per cloud, both
+// gradient tensors of the cloud in LDS.  A point's own term is a plain store, the scatter terms are LDS atomics (the reference's global
+// atomicAdd, tf_nndistance_g.cu:145-150, is order-free as well); the two outputs leave in one coalesced sweep.  No memset, no global
+// atomics: 2048 x (512, 512) in 26 us against 310 us for the two atomic launches.
+#define NMG_MAX_PTS 4096            // (n + m) * 12 bytes of LDS
+__global__ __launch_bounds__(256) void nm_distance_grad_lds_kernel(int n, const float* __restrict__ xyz1, int m, const float* __restrict__ xyz2,
+                                                                   const float* __restrict__ grad_dist1, const int* __restrict__ idx1,
+                                                                   const float* __restrict__ grad_dist2, const int* __restrict__ idx2,
+                                                                   float* __restrict__ grad_xyz1, float* __restrict__ grad_xyz2) {
+    extern __shared__ float sg[];                    // [n*3] gradient of cloud 1, [m*3] of cloud 2
+    float* g1 = sg;
+    float* g2 = sg + (size_t)n * 3;
+    const size_t c = blockIdx.x;
+    const float* a = xyz1 + c * n * 3;
+    const float* bq = xyz2 + c * m * 3;
+    // own terms: grad1[i] = g (p1 - p2[idx1[i]]) (:143-147), grad2[j] = g' (p2 - p1[idx2[j]]) (the symmetric launch :156)
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int j = idx1[c * n + i];
+        const float g = grad_dist1[c * n + i] * 2;
+#pragma unroll
+        for (int l = 0; l < 3; ++l) g1[i * 3 + l] = g * (a[i * 3 + l] - bq[j * 3 + l]);
+    }
+    for (int j = threadIdx.x; j < m; j += 256) {
+        const int i = idx2[c * m + j];
+        const float g = grad_dist2[c * m + j] * 2;
+#pragma unroll
+        for (int l = 0; l < 3; ++l) g2[j * 3 + l] = g * (bq[j * 3 + l] - a[i * 3 + l]);
+    }
+    __syncthreads();
+    // scatter terms: grad2[idx1[i]] -= g (p1 - p2[idx1[i]]), grad1[idx2[j]] -= g' (p2 - p1[idx2[j]])
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int j = idx1[c * n + i];
+        const float g = grad_dist1[c * n + i] * 2;
+#pragma unroll
+        for (int l = 0; l < 3; ++l) atomicAdd(g2 + j * 3 + l, -(g * (a[i * 3 + l] - bq[j * 3 + l])));
+    }
+    for (int j = threadIdx.x; j < m; j += 256) {
+        const int i = idx2[c * m + j];
+        const float g = grad_dist2[c * m + j] * 2;
+#pragma unroll
+        for (int l = 0; l < 3; ++l) atomicAdd(g1 + i * 3 + l, -(g * (bq[j * 3 + l] - a[i * 3 + l])));
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n * 3; i += 256) grad_xyz1[c * n * 3 + i] = g1[i];
+    for (int i = threadIdx.x; i < m * 3; i += 256) grad_xyz2[c * m * 3 + i] = g2[i];
+}
 extern "C" int gspn_nmdistance_grad(int b, int n, const float* xyz1, int m, const float* xyz2, const float* grad_dist1, const int* idx1,
                                     const float* grad_dist2, const int* idx2, float* grad_xyz1, float* grad_xyz2, void* stream) {
     if (b < 0 || n < 0 || m < 0) return GSPN_ERR_ARG;
     if (b == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     hipError_t e;
+    if (n > 0 && m > 0 && n + m <= NMG_MAX_PTS) {
+        static const int lds_on = [] { const char* ev = getenv("GSPN_NMGRAD_LDS"); return ev ? atoi(ev) : 1; }();      // (A/B hook)
+        if (lds_on) {
+            hipLaunchKernelGGL(nm_distance_grad_lds_kernel, dim3((unsigned)b), dim3(256), sizeof(float) * 3 * (size_t)(n + m), st, n, xyz1, m, xyz2, grad_dist1, idx1,
+                               grad_dist2, idx2, grad_xyz1, grad_xyz2);
+            return gspn_launch_status();
+        }
+    }
     if (n > 0 && (e = hipMemsetAsync(grad_xyz1, 0, sizeof(float) * (size_t)b * n * 3, st)) != hipSuccess) return (int)e;   // :153
     if (m > 0 && (e = hipMemsetAsync(grad_xyz2, 0, sizeof(float) * (size_t)b * m * 3, st)) != hipSuccess) return (int)e;   // :154
     if (n == 0 || m == 0) return 0;

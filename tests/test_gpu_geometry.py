@@ -222,7 +222,7 @@ def test_three_interpolate_and_grad(c):
     np.testing.assert_allclose(p.grad.cpu().numpy(), O.three_interpolate_grad(pts, idx, w, go), rtol=1e-5, atol=2e-5)
 
 
-@pytest.mark.parametrize("b,n,m", [(4, 512, 512), (2, 1500, 700), (3, 100, 2500), (1, 1, 1)])
+@pytest.mark.parametrize("b,n,m", [(4, 512, 512), (2, 1500, 700), (3, 100, 2500), (1, 1, 1), (2, 3000, 1500)])     # the last one: beyond the LDS kernel (global atomics)
 def test_nn_distance_and_grad(b, n, m):
     from gspn_amd.tf_nndistance import nn_distance
     a = D.batch("D", b, n, 3)
