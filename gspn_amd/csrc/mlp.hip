@@ -3407,7 +3407,7 @@ static bool bwd_lean_try(long rows, int cin, int cout, const gspn_dy_args* a, co
 // and the epilogue of dX takes the previous layer's BN reductions (sum dyh, sum dyh*xhat) with y_p read back from LDS instead of HBM.
 // Each workgroup leaves one partial dW tile set (slot = workgroup) for the usual fixed-order reduction (wgrad_dw_kernel, plain) and one
 // partial row of BN reductions: results do not depend on scheduling.  Shapes: dense dZ, known coefficients, cin and cout in {32, 64},
-// rows a multiple of the tile (128 / (cin/32)), 16-byte aligned pitches.
+// rows a multiple of the tile (128 / (cin/32)), 16-byte aligned pitches; cout = 128 runs as two chunks of 64 columns.
 // ============================================================================================
 #ifndef GSPN_FUSED_ABL
 #define GSPN_FUSED_ABL 0
@@ -3417,17 +3417,21 @@ __global__ __launch_bounds__(256) void bwd_fused_kernel(int rows, gspn_dy_args a
                                                         const float* __restrict__ in_scale, const float* __restrict__ in_shift,
                                                         float* __restrict__ dX, int ldx, float* __restrict__ PP, RsumArgs rs) {
     constexpr int CIN = 32 * CI, COUT = 32 * CO;
+    // cout wider than 64: the layer is walked in NCH chunks of CW = 2 column tiles -- dY is built and staged one chunk at a time (the dX tile
+    // accumulates over the chunks, every chunk has its own persistent dW tiles), W^T stays resident for all of them
+    constexpr int NCH = CO > 2 ? CO / 2 : 1, CW = CO / NCH, COUTC = 32 * CW;
+    static_assert(CW * NCH == CO && NCH <= 2, "cout in {32, 64, 128}");
     constexpr int TR = 128 / CI;                                  // rows per tile: (TR / 32) * CI = 4 dX tiles, one per wave
     constexpr int LD = TR + 1, LDW = CIN + 1;                     // odd pitches: lanes along either axis of a transposed tile hit distinct banks
-    constexpr int S = (CI * CO >= 4) ? 1 : 4 / (CI * CO);         // waves sharing one dW tile (each takes TR / S rows of every row tile)
-    constexpr int QY = 8 * CO, RY = 256 / QY, PY = TR / RY;       // Y / dZ: quads per row, rows per pass, passes
+    constexpr int S = (CI * CW >= 4) ? 1 : 4 / (CI * CW);         // waves sharing one dW tile (each takes TR / S rows of every row tile)
+    constexpr int QY = 8 * CW, RY = 256 / QY, PY = TR / RY;       // Y / dZ of a chunk: quads per row, rows per pass, passes
     constexpr int QX = 8 * CI, RX = 256 / QX, PX = TR / RX;       // y_p
-    __shared__ __attribute__((aligned(16))) float s_tile[COUT * LD + CIN * LD];
-    float* const sdY = s_tile;                                     // [o][r]
-    float* const sX = s_tile + COUT * LD;                          // [i][r]   raw y_p
+    __shared__ __attribute__((aligned(16))) float s_tile[COUTC * LD + CIN * LD];
+    float* const sdY = s_tile;                                     // [o][r]   (the chunk's columns)
+    float* const sX = s_tile + COUTC * LD;                         // [i][r]   raw y_p
     __shared__ __attribute__((aligned(16))) float sW[COUT * LDW];  // [o][i]   W^T
     __shared__ __attribute__((aligned(16))) float s_chan[5 * COUT];     // forward scale, MINUS shift, cA, cB, cC
-    static_assert(4 * 32 * 33 <= COUT * LD + CIN * LD, "the end-of-kernel reductions reuse the tile buffers");
+    static_assert(4 * 32 * 33 <= COUTC * LD + CIN * LD, "the end-of-kernel reductions reuse the tile buffers");
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int l31 = lane & 31, kh = lane >> 5;
     const int bx = blockIdx.x, grid = gridDim.x;
@@ -3451,31 +3455,34 @@ __global__ __launch_bounds__(256) void bwd_fused_kernel(int rows, gspn_dy_args a
     static_assert(!POOL32 || (RY <= 32 && 32 % RY == 0), "a pass of the pooled form stays inside one group");
     float4 ry[PY], rz[NZ], rx[PX];
     int4 rarg[POOL32 ? NG : 1];
-    auto fetch = [&](int tile) {
+    auto fetch = [&](int tile, int ch) {                           // chunk ch of the tile (y_p comes with chunk 0)
         const size_t m0 = (size_t)tile * TR;
-        const char* yb = reinterpret_cast<const char*>(a.Y + m0 * a.ldy);
+        const char* yb = reinterpret_cast<const char*>(a.Y + m0 * a.ldy + ch * COUTC);
         const char* xb = reinterpret_cast<const char*>(Xp + m0 * ldxp);
 #pragma unroll
         for (int i = 0; i < PY; ++i) ry[i] = *reinterpret_cast<const float4*>(yb + (size_t)(RY * i) * a.ldy * 4 + oy);
         if constexpr (POOL32) {                                   // this thread's four channels of the tile's NG groups
-            const size_t g0 = (size_t)tile * NG * COUT + kqy;
+            const size_t g0 = (size_t)tile * NG * COUT + ch * COUTC + kqy;
 #pragma unroll
             for (int gi = 0; gi < NG; ++gi) {
                 rz[gi] = *reinterpret_cast<const float4*>(a.dPool + g0 + (size_t)gi * COUT);
                 rarg[gi] = *reinterpret_cast<const int4*>(a.pool_arg + g0 + (size_t)gi * COUT);
             }
         } else {
-            const char* zb = reinterpret_cast<const char*>(a.dZ + m0 * a.ldz);
+            const char* zb = reinterpret_cast<const char*>(a.dZ + m0 * a.ldz + ch * COUTC);
 #pragma unroll
             for (int i = 0; i < PY; ++i) rz[i] = *reinterpret_cast<const float4*>(zb + (size_t)(RY * i) * a.ldz * 4 + oz);
         }
+        if (NCH == 1 || ch == 0) {
 #pragma unroll
-        for (int i = 0; i < PX; ++i) rx[i] = *reinterpret_cast<const float4*>(xb + (size_t)(RX * i) * ldxp * 4 + ox);
+            for (int i = 0; i < PX; ++i) rx[i] = *reinterpret_cast<const float4*>(xb + (size_t)(RX * i) * ldxp * 4 + ox);
+        }
     };
-    auto commit = [&]() {
-        const float4 q_sc = *reinterpret_cast<const float4*>(s_chan + kqy), q_ns = *reinterpret_cast<const float4*>(s_chan + COUT + kqy);
-        const float4 q_a = *reinterpret_cast<const float4*>(s_chan + 2 * COUT + kqy), q_b = *reinterpret_cast<const float4*>(s_chan + 3 * COUT + kqy);
-        const float4 q_c = *reinterpret_cast<const float4*>(s_chan + 4 * COUT + kqy);
+    auto commit = [&](int ch) {
+        const int kc = ch * COUTC + kqy;
+        const float4 q_sc = *reinterpret_cast<const float4*>(s_chan + kc), q_ns = *reinterpret_cast<const float4*>(s_chan + COUT + kc);
+        const float4 q_a = *reinterpret_cast<const float4*>(s_chan + 2 * COUT + kc), q_b = *reinterpret_cast<const float4*>(s_chan + 3 * COUT + kc);
+        const float4 q_c = *reinterpret_cast<const float4*>(s_chan + 4 * COUT + kc);
         const float sc[4] = {q_sc.x, q_sc.y, q_sc.z, q_sc.w}, ns[4] = {q_ns.x, q_ns.y, q_ns.z, q_ns.w};
         const float cA[4] = {q_a.x, q_a.y, q_a.z, q_a.w}, cB[4] = {q_b.x, q_b.y, q_b.z, q_b.w}, cC[4] = {q_c.x, q_c.y, q_c.z, q_c.w};
 #pragma unroll
@@ -3503,16 +3510,18 @@ __global__ __launch_bounds__(256) void bwd_fused_kernel(int rows, gspn_dy_args a
 #endif
             }
         }
+        if (NCH == 1 || ch == 0) {
 #pragma unroll
-        for (int i = 0; i < PX; ++i) {
-            float* d = sX + kqx * LD + arx + RX * i;
-            d[0 * LD] = rx[i].x; d[1 * LD] = rx[i].y; d[2 * LD] = rx[i].z; d[3 * LD] = rx[i].w;
+            for (int i = 0; i < PX; ++i) {
+                float* d = sX + kqx * LD + arx + RX * i;
+                d[0 * LD] = rx[i].x; d[1 * LD] = rx[i].y; d[2 * LD] = rx[i].z; d[3 * LD] = rx[i].w;
+            }
         }
     };
     // this wave's tiles
     const int rt = wave / CI, ct = wave % CI;                    // dX: rows rt*32.., input channels ct*32..
     const int wt = wave / S, part = wave % S;                    // dW: tile wt = (mi, ni), rows part*(TR/S).. of every row tile
-    const int mi = wt / CO, ni = wt % CO;
+    const int mi = wt / CW, ni = wt % CW;                        // (ni: column tile inside a chunk)
     constexpr int KW = TR / S;                                   // rows (k) of a row tile this wave feeds into its dW tile
     const float* pa_x = sdY + kh * LD + rt * 32 + l31;           // dX  A: dY[row][k]   at sdY[k][row]
     const float* pb_x = sW + kh * LDW + ct * 32 + l31;           //     B: W^T[k][i]    at sW[k][i]
@@ -3530,20 +3539,28 @@ __global__ __launch_bounds__(256) void bwd_fused_kernel(int rows, gspn_dy_args a
     const unsigned ax_x = lds_addr(pa_x), bx_x = lds_addr(pb_x), ax_w = lds_addr(pa_w), bx_w = lds_addr(pb_w);
     const float* pe = sX + (ct * 32 + l31) * LD + rt * 32 + 4 * kh;     // the epilogue's y_p: rows 8*(r>>2) + (r&3) from here
     const unsigned lo_x = (unsigned)((rt * 32 + 4 * kh) * ldx + ct * 32 + l31) * 4u;
-    f32x16 accw;
+    f32x16 accw[NCH];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) accw[r] = 0.f;
-    fetch(bx);
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accw[c][r] = 0.f;
+    fetch(bx, 0);
     __syncthreads();                                             // the constants and W^T
     for (int tile = bx; tile < ntiles; tile += grid) {
-        commit();
-        __syncthreads();
-        if (!(GSPN_FUSED_ABL & 32) && tile + grid < ntiles) fetch(tile + grid);            // the next tile's twelve quads fly during this tile's MFMAs
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        lds_product<COUT / 2, 2 * LD * 4, 2 * LDW * 4, false, (GSPN_FUSED_ABL & 1)>(acc, ax_x, bx_x, 0.f, 0.f);
-        lds_product<KW / 2, 8, 8, true, (GSPN_FUSED_ABL & 2)>(accw, ax_w, bx_w, w_sc, w_sh);
+        sfor<NCH>([&](auto ch_) {
+            constexpr int ch = decltype(ch_)::value;
+            commit(ch);
+            __syncthreads();
+            // the next (tile, chunk)'s quads fly during this chunk's MFMAs
+            if constexpr (ch + 1 < NCH) fetch(tile, ch + 1);
+            else if (!(GSPN_FUSED_ABL & 32) && tile + grid < ntiles) fetch(tile + grid, 0);
+            lds_product<COUTC / 2, 2 * LD * 4, 2 * LDW * 4, false, (GSPN_FUSED_ABL & 1)>(acc, ax_x, bx_x + ch * COUTC * LDW * 4, 0.f, 0.f);
+            lds_product<KW / 2, 8, 8, true, (GSPN_FUSED_ABL & 2)>(accw[ch], ax_w, bx_w, w_sc, w_sh);
+            if constexpr (ch + 1 < NCH) __syncthreads();         // (the chunk's dY is consumed: the next chunk may overwrite it)
+        });
         if constexpr (RSUM && !(GSPN_FUSED_ABL & 16)) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -3572,22 +3589,25 @@ __global__ __launch_bounds__(256) void bwd_fused_kernel(int rows, gspn_dy_args a
     // ---- the workgroup's partial dW tile set -> slot bx; its BN-reduction row -> part[bx] ----
     float* sred = s_tile;                                        // [4 waves][32][33] (the tile buffers are free now)
     float* slot = PP + (size_t)bx * 2 * CIN * COUT;
-    if constexpr (S == 1) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) slot[(size_t)(mi * 32 + c_row(r, lane)) * COUT + ni * 32 + l31] = accw[r];
-    } else {
+    for (int ch = 0; ch < NCH; ++ch) {
+        if constexpr (S == 1) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sred[(wave * 32 + c_row(r, lane)) * 33 + l31] = accw[r];
-        __syncthreads();
-        for (int i = t; i < CIN * COUT; i += 256) {
-            const int m = i / COUT, n = i - m * COUT;
-            const int w0 = ((m >> 5) * CO + (n >> 5)) * S;       // the first of the S waves of tile (m / 32, n / 32)
-            float v = 0.f;
+            for (int r = 0; r < 16; ++r) slot[(size_t)(mi * 32 + c_row(r, lane)) * COUT + ch * COUTC + ni * 32 + l31] = accw[ch][r];
+        } else {
 #pragma unroll
-            for (int q = 0; q < S; ++q) v += sred[((w0 + q) * 32 + (m & 31)) * 33 + (n & 31)];
-            slot[i] = v;
+            for (int r = 0; r < 16; ++r) sred[(wave * 32 + c_row(r, lane)) * 33 + l31] = accw[ch][r];
+            __syncthreads();
+            for (int i = t; i < CIN * COUTC; i += 256) {
+                const int m = i / COUTC, n = i - m * COUTC;
+                const int w0 = ((m >> 5) * CW + (n >> 5)) * S;   // the first of the S waves of tile (m / 32, n / 32) of the chunk
+                float v = 0.f;
+#pragma unroll
+                for (int q = 0; q < S; ++q) v += sred[((w0 + q) * 32 + (m & 31)) * 33 + (n & 31)];
+                slot[(size_t)m * COUT + ch * COUTC + n] = v;
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
     if constexpr (RSUM) {
         float* sR = sX;                                          // [4 waves][2][32]
@@ -3620,11 +3640,12 @@ template <int CI, int CO> static int fused_occupancy() {
 static unsigned fused_grid(long rows, int cin, int cout) {
     static const int on = env_int("GSPN_BWD_FUSED", 1);
     if (!on) return 0;
-    if (!((cin == 32 || cin == 64) && (cout == 32 || cout == 64))) return 0;
+    if (!((cin == 32 || cin == 64) && (cout == 32 || cout == 64 || cout == 128))) return 0;
     const int tr = 128 / (cin / 32);
     if (rows < 65536 || rows % tr || rows % 128) return 0;        // (short layers: their launches are latency chains, two kernels overlap better)
     static const int bpc_env = env_int("GSPN_BWD_FUSED_BPC", 0);
-    int bpc = cin == 32 ? (cout == 32 ? fused_occupancy<1, 1>() : fused_occupancy<1, 2>()) : (cout == 32 ? fused_occupancy<2, 1>() : fused_occupancy<2, 2>());
+    int bpc = cin == 32 ? (cout == 32 ? fused_occupancy<1, 1>() : (cout == 64 ? fused_occupancy<1, 2>() : fused_occupancy<1, 4>()))
+                        : (cout == 32 ? fused_occupancy<2, 1>() : (cout == 64 ? fused_occupancy<2, 2>() : fused_occupancy<2, 4>()));
     if (bpc_env > 0) bpc = bpc_env > 4 ? 4 : bpc_env;
     // never more workgroups than 128-row tiles: the BN-reduction buffer (gspn_rsum_part_floats) holds one row per such tile at most
     const long ntiles = rows / 128, cap = (long)GSPN_PLAN_CUS * bpc;
@@ -3669,8 +3690,10 @@ extern "C" int gspn_mlp_bwd_fused(long rows, int cin, int cout, const gspn_dy_ar
     } while (0)
     if (cin == 32 && cout == 32) BF_GO(1, 1);
     else if (cin == 32 && cout == 64) BF_GO(1, 2);
-    else if (cin == 64 && cout == 32) BF_GO(2, 1);
-    else BF_GO(2, 2);
+    else if (cin == 32) BF_GO(1, 4);
+    else if (cout == 32) BF_GO(2, 1);
+    else if (cout == 64) BF_GO(2, 2);
+    else BF_GO(2, 4);
 #undef BF_GO
     if (nparts_out) *nparts_out = (int)g;
     DwJob j = dw_job(rows, cin, cout, (long)g, PP, nullptr, nullptr, nullptr, nullptr, 0.f, 0, 0, dW);

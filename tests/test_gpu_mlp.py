@@ -301,7 +301,9 @@ def test_early_coefficients_equal_the_two_product_pass(rows, cin, chans, ns, mon
                                                (131072, 6, [32, 32, 64], 32),         # 32 <- 32 (SA1's second layer)
                                                (65536 + 128, 16, [32, 64, 32, 64], None),   # 64 <- 32 and 32 <- 64; rows not a multiple of the grid
                                                (262144, 67, [64, 64, 64], None),      # FP3 at the bench's row count
-                                               (65536, 12, [64, 64], 32), (65536, 12, [32, 32], 32), (65536 + 128, 12, [48, 64, 32], 32)])   # pooled tops
+                                               (65536, 12, [64, 64], 32), (65536, 12, [32, 32], 32), (65536 + 128, 12, [48, 64, 32], 32),    # pooled tops
+                                               (65536, 12, [64, 128], 32), (65536 + 256, 12, [32, 128, 64], None),                          # cout = 128: two chunks of 64 columns
+                                               (131072, 67, [64, 64, 128], 32)])                                                           # SA2 at the bench's row count
 def test_both_backward_passes_in_one_launch_equal_the_two_pass_form(rows, cin, chans, ns, monkeypatch):
     """gspn_mlp_bwd_fused (dW and dX of a layer from one staged dY tile, the previous layer's BN reductions in its epilogue) against
     pass A + pass B: dX takes the same products in the same order (equal to rounding of the dY form), dW sums the rows in another
