@@ -38,6 +38,7 @@ SIGNATURES = {
     "gspn_fps_cells": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
     "gspn_farthestpointsampling_cells": [_I, _I, _I, _P, _P, _P, _P],
     "gspn_fps_cells_prepass": [_I, _I, _P, _P, _P],
+    "gspn_fps_cells_prepass_order": [_I, _I, _P, _P, _P, _P],
     "gspn_fps_cells_sample": [_I, _I, _I, _P, _P, _P, _P],
     "gspn_fps_multi_prepass": [_I, _I, _I, _P, _P, _P],
     "gspn_fps_multi_sample": [_I, _I, _I, _I, _P, _P, _P, _P],
@@ -124,7 +125,7 @@ SPECIAL = {
     "gspn_inverse_lists_work_ints": ([_I, _I, _I], _L),
 }
 
-ABI_VERSION = 5         # == GSPN_ABI_VERSION of include/gspn_hip.h this binding was written against
+ABI_VERSION = 6         # == GSPN_ABI_VERSION of include/gspn_hip.h this binding was written against
 
 _lib = None
 

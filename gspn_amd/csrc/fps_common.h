@@ -46,4 +46,4 @@ __host__ __device__ __forceinline__ int fps_tie_rank_inv(unsigned r) { return (i
 // (consecutive runs of the 12-bit Morton voxel order), reference tie rank ascending inside a cell.
 //   perm (b,n) i32: sorted position -> original index (the buffer doubles as the key scratch of the counting sort)
 //   sxyz (b,n,3) f32: coordinates in sorted order
-int gspn_fps_prepass_cells(int b, int n, int ncell, int csz, const float* inp, int* perm, float* sxyz, hipStream_t st);
+int gspn_fps_prepass_cells(int b, int n, int ncell, int csz, const float* inp, int* perm, float* sxyz, hipStream_t st, int* vorder = nullptr);

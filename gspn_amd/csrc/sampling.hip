@@ -601,7 +601,7 @@ static int launch_fps_resident(int b, int n, int m, const float* inp, int* out, 
 // ============================================================================================
 __device__ __forceinline__ unsigned spread4(unsigned v) { return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4) | ((v & 8u) << 6); }
 
-__global__ __launch_bounds__(1024) void fps_bin_kernel(int n, const float* __restrict__ inp, unsigned* __restrict__ keys) {
+__global__ __launch_bounds__(1024) void fps_bin_kernel(int n, const float* __restrict__ inp, unsigned* __restrict__ keys, int* __restrict__ vorder) {
     __shared__ int hist[4096];
     __shared__ float red[6][16];
     __shared__ int wsum[16];
@@ -658,6 +658,7 @@ __global__ __launch_bounds__(1024) void fps_bin_kernel(int n, const float* __res
     for (int k = t; k < n; k += 1024) {
         const int pos = atomicAdd(&hist[voxel(k)], 1);
         out[pos] = fps_tie_rank(k);
+        if (vorder) vorder[(size_t)blockIdx.x * n + pos] = k;      // the scene in 16^3-voxel Morton order (three_nn's scan order)
     }
 }
 
@@ -693,9 +694,9 @@ __global__ void fps_cellsort_kernel(int n, int csz, const float* __restrict__ in
     }
 }
 
-int gspn_fps_prepass_cells(int b, int n, int ncell, int csz, const float* inp, int* perm, float* sxyz, hipStream_t st) {
+int gspn_fps_prepass_cells(int b, int n, int ncell, int csz, const float* inp, int* perm, float* sxyz, hipStream_t st, int* vorder) {
     if (csz > 2048 || (long long)ncell * csz < n || b > 65535) return GSPN_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(fps_bin_kernel, dim3(b), dim3(1024), 0, st, n, inp, reinterpret_cast<unsigned*>(perm));
+    hipLaunchKernelGGL(fps_bin_kernel, dim3(b), dim3(1024), 0, st, n, inp, reinterpret_cast<unsigned*>(perm), vorder);
     const dim3 g2(ncell, b);
     if (csz <= 128) hipLaunchKernelGGL(fps_cellsort_kernel<128>, g2, dim3(64), 0, st, n, csz, inp, perm, sxyz);
     else if (csz <= 256) hipLaunchKernelGGL(fps_cellsort_kernel<256>, g2, dim3(128), 0, st, n, csz, inp, perm, sxyz);
@@ -751,6 +752,17 @@ extern "C" int gspn_fps_cells_prepass(int b, int n, const float* inp, void* ws, 
     int* perm = reinterpret_cast<int*>(ws);
     float* sxyz = reinterpret_cast<float*>(perm + (size_t)b * n);
     return gspn_fps_prepass_cells(b, n, 16, (n + 15) / 16, inp, perm, sxyz, (hipStream_t)stream);
+}
+// the same pre-pass, also leaving the scene in its 16^3-voxel Morton order: vorder (b, n) int32, original point indices (the order inside
+// a voxel is arbitrary).  A finer spatial order than the 16 cells of `ws` -- what gspn_threenn_ordered wants for its `order`.
+extern "C" int gspn_fps_cells_prepass_order(int b, int n, const float* inp, void* ws, int* vorder, void* stream) {
+    if (b < 0 || n <= 0) return GSPN_ERR_ARG;
+    if (b == 0) return 0;
+    if (!inp || !ws || !vorder) return GSPN_ERR_ARG;
+    if (n > GSPN_FPS_RESIDENT_MAX || b > 65535) return GSPN_ERR_UNSUPPORTED;
+    int* perm = reinterpret_cast<int*>(ws);
+    float* sxyz = reinterpret_cast<float*>(perm + (size_t)b * n);
+    return gspn_fps_prepass_cells(b, n, 16, (n + 15) / 16, inp, perm, sxyz, (hipStream_t)stream, vorder);
 }
 // ... and the sampling kernel on a workspace the pre-pass has filled for the same (b, n, inp)
 extern "C" int gspn_fps_cells_sample(int b, int n, int m, const float* inp, const void* ws, int* out, void* stream) {

@@ -18,6 +18,7 @@ PROFILE_MIN_N = 0          # only launches with at least this many points per sc
 # 'resident': always the plain on-chip kernel; 'cells_torch': cell kernel on a torch-side pre-sort (tests: arbitrary partitions)
 FPS_MODE = os.environ.get("GSPN_FPS_MODE", "cells")
 FPS_CELLS_MIN_N = int(os.environ.get("GSPN_FPS_CELLS_MIN_N", "8192"))
+VOXEL_ORDER = os.environ.get("GSPN_FPS_VOXEL_ORDER", "1") != "0"      # return_order: the 16^3-voxel Morton order of the pre-pass (finer than its 16 cells)
 # workgroups (CUs) per scene for n > 32768 (0 = the library's choice); any n goes multi-CU when FPS_MULTI_FORCE is set (tests)
 FPS_MULTI_G = int(os.environ.get("GSPN_FPS_MULTI_G", "0"))
 FPS_MULTI_FORCE = False
@@ -100,10 +101,16 @@ def farthest_point_sample(npoint, inp, return_order=False):
                     L.check_async(block=True)
         elif FPS_MODE == "cells" and FPS_CELLS_MIN_N <= n:
             ws = torch.empty(int(lib.gspn_fps_cells_ws_bytes(b, n)) // 4, dtype=torch.float32, device=inp.device)
-            L.check(lib.gspn_fps_cells_prepass(b, n, L.ptr(inp), L.ptr(ws), L.stream()), "farthest_point_sample(cells pre-pass)")
+            if return_order and VOXEL_ORDER:
+                # the scene in 16^3-voxel Morton order, written by the pre-pass's counting sort on its way (4 bytes per point)
+                order = torch.empty((b, n), dtype=torch.int32, device=inp.device)
+                L.check(lib.gspn_fps_cells_prepass_order(b, n, L.ptr(inp), L.ptr(ws), L.ptr(order), L.stream()), "farthest_point_sample(cells pre-pass)")
+            else:
+                L.check(lib.gspn_fps_cells_prepass(b, n, L.ptr(inp), L.ptr(ws), L.stream()), "farthest_point_sample(cells pre-pass)")
             tic()
             L.check(lib.gspn_fps_cells_sample(b, n, npoint, L.ptr(inp), L.ptr(ws), L.ptr(out), L.stream()), "farthest_point_sample(cells)")
-            order = ws[:b * n].view(torch.int32).view(b, n)          # perm: sorted position -> original index (first b*n words of ws)
+            if order is None:
+                order = ws[:b * n].view(torch.int32).view(b, n)      # perm: sorted position -> original index (first b*n words of ws): 16 cells
         elif FPS_MODE == "cells_torch" and 64 <= n:
             tic()
             sxyz, perm, csz = _cell_prepass(inp)

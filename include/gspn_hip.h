@@ -33,7 +33,7 @@ extern "C" {
  * compares it with gspn_abi_version() of the library it loaded (gspn_amd/_lib.py raises on a mismatch: a stale .so fails loudly).
  *   1: round 1.   2: round 2 (gspn_fps_background removed, ~30 entry points added, finalize / workspace layouts changed).
  *   3: round 3 (gspn_sa_rel_shift, gspn_bn_apply, gspn_mlp_gemm_*, gspn_small_geometry, status word of the multi-CU FPS checked). */
-#define GSPN_ABI_VERSION 5
+#define GSPN_ABI_VERSION 6
 int gspn_dist_policy(void);
 int gspn_abi_version(void);
 
@@ -59,6 +59,9 @@ int gspn_farthestpointsampling_cells(int b, int n, int m, const float* inp, void
 /* The two halves of gspn_farthestpointsampling_cells on the same workspace: the spatial pre-pass (counting sort into 16 cells + rank
  * sort inside each cell) and the sampling kernel proper.  Calling them one after the other on one stream equals the combined call. */
 int gspn_fps_cells_prepass(int b, int n, const float* inp, void* ws, void* stream);
+/* the same, also leaving the scene's points in 16^3-voxel Morton order in vorder (b, n) int32 (original indices; arbitrary order inside
+ * a voxel): a finer spatial order than the 16 cells of ws, for gspn_threenn_ordered. */
+int gspn_fps_cells_prepass_order(int b, int n, const float* inp, void* ws, int* vorder, void* stream);
 int gspn_fps_cells_sample(int b, int n, int m, const float* inp, const void* ws, int* out, void* stream);
 
 /* Scenes that do not fit one CU (n > 32768; tf_sampling_g.cu:137-141 is the reference's any-n path, data_prep.py:64-83 its caller
