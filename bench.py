@@ -46,6 +46,23 @@ def synth(b, n, seed0):
     return xyz, col
 
 
+def _stdout_discipline(rank, done=False):
+    """The contract is ONE JSON line on stdout.  RCCL prints a version banner through C stdio when its first communicator comes up; with
+    stdout redirected that text sits in the C buffer until the process exits -- AFTER rank 0's line (seen at world size 1 with
+    --force-collective: the line was the first of six).  Ranks other than 0 send their file descriptor 1 to /dev/null; rank 0 flushes the C
+    buffers (so the banner precedes the line) and closes the tap once the line is out."""
+    import ctypes
+    try:
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+        if rank != 0 or done:
+            fd = os.open(os.devnull, os.O_WRONLY)
+            os.dup2(fd, 1)
+            os.close(fd)
+    except Exception:
+        pass
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -90,6 +107,7 @@ def main():
         mlp_mod.SYNC_BN = True
         args.no_graph = True                      # collectives inside the layers: not captured
     rank, local, world = parallel.init_from_env(force=args.force_collective)
+    _stdout_discipline(rank)
     FORCE_COLL = bool(args.force_collective)
     COLL_IN_GRAPH = bool(args.collective_in_graph) and (world > 1 or FORCE_COLL)
     if world != args.gpus:
@@ -442,7 +460,9 @@ def main():
             res.update(run_legs_in_child(args))
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(xyz_np0, col_np0)
+        _stdout_discipline(rank)                                    # whatever the C side buffered so far comes out BEFORE the line
         print(json.dumps(res), flush=True)
+        _stdout_discipline(rank, done=True)                         # ... and nothing after it
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
@@ -604,7 +624,7 @@ def _ev_time(fn, warm=3, reps=20):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     try:
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
             for _ in range(reps):
                 fn()
         g.replay()

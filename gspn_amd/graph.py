@@ -27,7 +27,12 @@ class CapturedStep:
                 fn()
         cur.wait_stream(side)
         torch.cuda.synchronize()
-        with torch.cuda.graph(self.graph, pool=pool):
+        # capture_error_mode "thread_local": only THIS thread is held to the capture rules.  Under the default ("global") any other thread
+        # that touches the runtime while the capture is open fails with hipErrorStreamCaptureUnsupported -- and the process-group watchdog
+        # of torch.distributed polls the events of earlier collectives from its own thread: with RCCL initialised the capture of the
+        # step killed the process about once in thirty runs ("operation not permitted when stream is capturing" out of
+        # ProcessGroupNCCL::Watchdog; tests/test_gpu_collective.py, r03).
+        with torch.cuda.graph(self.graph, pool=pool, capture_error_mode="thread_local"):
             self.result = fn()
 
     def pool(self):
