@@ -160,12 +160,20 @@ def main():
         # every geometry stream is TESTED to run beside the layers' stream, beside the other geometry streams and -- when a process
         # group exists -- not to hold up a collective issued on the layers' stream (GeometryStream: hardware-queue round-robin)
         probes = []
+        agree = None
         if dist.is_initialized():
             dummy = torch.zeros(1024, device=dev)
             probes.append(lambda: dist.all_reduce(dummy))
+            flag = torch.zeros(1, device=dev)
+
+            def agree(ok):              # the verdict of an attempt is timing-based: all ranks take the same one (same number of collectives everywhere)
+                flag.fill_(1.0 if ok else 0.0)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                return bool(flag.item() > 0.5)
         geo = []
         for _ in range(DEPTH):          # (default priority: a high-priority geometry queue starves the layers, 3.7 -> 8.1 ms per step)
-            geo.append(GeometryStream(dev, priority=GEO_PRIO, beside=[torch.cuda.current_stream()] + [g_.stream for g_ in geo], probes=probes))
+            geo.append(GeometryStream(dev, priority=GEO_PRIO, beside=[torch.cuda.current_stream()] + [g_.stream for g_ in geo], probes=probes,
+                                      agree=agree))
     use_graph = geo is not None and not args.no_graph
     pend = {}                   # step index -> PendingGeometry
     done = {}                   # step index -> event after its layers + optimiser step

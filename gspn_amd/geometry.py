@@ -175,10 +175,13 @@ class GeometryStream:
     """A side HIP stream for coordinate-only work.  submit(fn, *tensors) runs fn on it after the tensors'
     producer (the caller's current stream) and returns a PendingGeometry."""
 
-    def __init__(self, device=None, priority=0, beside=None, probes=(), attempts=12):
+    def __init__(self, device=None, priority=0, beside=None, probes=(), attempts=12, agree=None):
         """beside: streams this one must run CONCURRENTLY with (default: the caller's current stream, i.e. the one the layers run on);
         probes: callables that enqueue work on the caller's current stream which must not queue up behind this stream either (e.g. a
-        collective that the communication library runs on a stream of its own).
+        collective that the communication library runs on a stream of its own).  Every probe runs in EVERY attempt (no short-circuit).
+        agree: with several ranks and a collective among the probes every rank must run the same number of attempts -- the verdict of an
+        attempt is timing-based and could differ between ranks, which would leave them with different numbers of collectives issued.
+        agree(ok) -> bool makes it common (e.g. an all-reduce MIN of the flag); it is called once per attempt on every rank.
         HIP hands its hardware queues to streams round-robin in creation order, so which queue a new stream lands on depends on every
         stream anybody created before -- torch's capture streams, and RCCL's: with a process group initialised, the geometry stream of
         round 2 landed on the LAYERS' queue and every step paid +1.1 ms (r03, rocprofv3 queue ids).  So the stream is not trusted, it
@@ -193,7 +196,11 @@ class GeometryStream:
             with torch.cuda.stream(st):
                 torch.zeros(1, device=st.device)        # first use binds the stream to its hardware queue
             self.tried += 1
-            ok = all(runs_beside(b, st) for b in beside) and all(runs_beside(st, cur, work=p) for p in probes)
+            ok = all(runs_beside(b, st) for b in beside)
+            for p in probes:                                 # (all of them, whatever the verdict so far: the same collectives on every rank)
+                ok = runs_beside(st, cur, work=p) and ok
+            if agree is not None:
+                ok = bool(agree(ok))
             if ok:
                 self.stream = st
                 break
