@@ -16,6 +16,12 @@ def init_from_env(backend=None, force=False):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal of the N > 1 control flow on a box with ONE GPU (r03): GSPN_FORCE_DEVICE=0 GSPN_DIST_BACKEND=gloo puts every rank on
+    # that device with gloo moving the bucket through the host -- slow, but the ranks run the real step, the real stream tests and the
+    # real sequence of collectives (RCCL refuses two ranks on one device)
+    backend = backend or os.environ.get("GSPN_DIST_BACKEND") or None
+    if "GSPN_FORCE_DEVICE" in os.environ:
+        local = int(os.environ["GSPN_FORCE_DEVICE"])
     if torch.cuda.is_available():
         torch.cuda.set_device(local)
     if (world > 1 or force) and not dist.is_initialized():

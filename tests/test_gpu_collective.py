@@ -131,3 +131,28 @@ def test_rccl_path_at_world_1_equals_the_no_collective_step():
     # the captured form: either it works and is bit-equal too, or the build refuses to capture a collective (then the error is shown)
     if "in_graph_error" not in res:
         assert res["in_graph_bit_equal"] is True
+
+
+def test_two_ranks_rehearsal_on_one_gpu_over_gloo():
+    """The N > 1 control flow of bench.py on a box with ONE GPU: two ranks launched by torch.distributed.run exactly as the driver launches
+    them, both on device 0, gloo carrying the bucket through the host (RCCL refuses two ranks on one device).  Slow, but the ranks run the
+    real step, the real stream tests (every probe collective and the agreed verdict on every rank) and the real per-step sequence of
+    collectives; a mismatch would hang (hence the timeout).  The JSON line must be the LAST line of stdout and report both ranks."""
+    import json
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.update(GSPN_DIST_BACKEND="gloo", GSPN_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-extra"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    line = json.loads(lines[-1])                        # the line is the last thing on stdout
+    assert line["n_gpus"] == 2 and line["steps"] == 6 and line["scaling"] == "weak"
+    assert line["config"]["global_batch"] == 16 and line["value"] > 0
+    assert line["collective"]["world"] == 2
