@@ -191,22 +191,30 @@ class GeometryStream:
         beside = [cur] if beside is None else list(beside)
         self.stream = None
         self.tried = 0
+        fallback = None
         for _ in range(max(1, attempts)):
             st = torch.cuda.Stream(device=device, priority=priority)
             with torch.cuda.stream(st):
                 torch.zeros(1, device=st.device)        # first use binds the stream to its hardware queue
             self.tried += 1
             ok = all(runs_beside(b, st) for b in beside)
+            beside_ok = ok
             for p in probes:                                 # (all of them, whatever the verdict so far: the same collectives on every rank)
-                ok = runs_beside(st, cur, work=p) and ok
+                if agree is not None:
+                    agree(True)                              # a collective of its own: the ranks enter the probe together (a rank that waits
+                                                             # for a late peer inside the probe would blame the stream for the skew)
+                ok = runs_beside(st, cur, work=p, cycles=6000000) and ok
             if agree is not None:
                 ok = bool(agree(ok))
             if ok:
                 self.stream = st
                 break
             _parked.append(st)
+            if beside_ok and fallback is None:
+                fallback = st                            # runs beside the layers at least (only a probe objected)
         if self.stream is None:                          # fewer free hardware queues than streams that must run side by side
-            self.stream = _parked.pop()
+            self.stream = fallback if fallback is not None else _parked[-1]
+            _parked.remove(self.stream)
             self.shares_queue = True
         else:
             self.shares_queue = False
