@@ -3478,7 +3478,12 @@ __global__ __launch_bounds__(256) void bwd_fused_kernel(int rows, gspn_dy_args a
             for (int i = 0; i < PX; ++i) rx[i] = *reinterpret_cast<const float4*>(xb + (size_t)(RX * i) * ldxp * 4 + ox);
         }
     };
-    auto commit = [&](int ch) {
+    // prepare(): dY of the fetched chunk, in registers.  It runs BEFORE the epilogue's stores are issued: hipcc waits with vmcnt(0) for a load
+    // whenever loads and stores are both in flight (on gfx9 they share the counter and count as out of order), so a wait for the prefetched
+    // tile placed after the stores -- at the top of the next tile, where the values are needed -- also waits for stores issued a moment ago:
+    // their whole latency, every tile.  Consumed before the stores, the prefetch waits for nothing but itself.
+    float vdy[PY][4];
+    auto prepare = [&](int ch) {
         const int kc = ch * COUTC + kqy;
         const float4 q_sc = *reinterpret_cast<const float4*>(s_chan + kc), q_ns = *reinterpret_cast<const float4*>(s_chan + COUT + kc);
         const float4 q_a = *reinterpret_cast<const float4*>(s_chan + 2 * COUT + kc), q_b = *reinterpret_cast<const float4*>(s_chan + 3 * COUT + kc);
@@ -3499,16 +3504,27 @@ __global__ __launch_bounds__(256) void bwd_fused_kernel(int rows, gspn_dy_args a
             } else {
                 zv[0] = rz[i].x; zv[1] = rz[i].y; zv[2] = rz[i].z; zv[3] = rz[i].w;
             }
-            float* d = sdY + kqy * LD + ary + RY * i;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
 #if GSPN_FUSED_ABL & 4
-                d[j * LD] = yv[j] + zv[j];
+                vdy[i][j] = yv[j] + zv[j];
 #else
                 const float dyh = yv[j] * sc[j] > ns[j] ? zv[j] : 0.f;                                   // relu_open: the forward's own mask
-                d[j * LD] = __builtin_fmaf(cA[j], dyh, __builtin_fmaf(cB[j], yv[j], cC[j]));
+                vdy[i][j] = __builtin_fmaf(cA[j], dyh, __builtin_fmaf(cB[j], yv[j], cC[j]));
 #endif
             }
+        }
+        if (NCH == 1 || ch == 0) {
+#pragma unroll
+            for (int i = 0; i < PX; ++i) asm volatile("" : "+v"(rx[i].x), "+v"(rx[i].y), "+v"(rx[i].z), "+v"(rx[i].w));      // (y_p is consumed here too: its wait belongs in front of the stores)
+        }
+    };
+    auto commit = [&](int ch) {
+#pragma unroll
+        for (int i = 0; i < PY; ++i) {
+            float* d = sdY + kqy * LD + ary + RY * i;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d[j * LD] = vdy[i][j];
         }
         if (NCH == 1 || ch == 0) {
 #pragma unroll
@@ -3546,6 +3562,7 @@ __global__ __launch_bounds__(256) void bwd_fused_kernel(int rows, gspn_dy_args a
         for (int r = 0; r < 16; ++r) accw[c][r] = 0.f;
     fetch(bx, 0);
     __syncthreads();                                             // the constants and W^T
+    prepare(0);
     for (int tile = bx; tile < ntiles; tile += grid) {
         f32x16 acc;
 #pragma unroll
@@ -3559,7 +3576,10 @@ __global__ __launch_bounds__(256) void bwd_fused_kernel(int rows, gspn_dy_args a
             else if (!(GSPN_FUSED_ABL & 32) && tile + grid < ntiles) fetch(tile + grid, 0);
             lds_product<COUTC / 2, 2 * LD * 4, 2 * LDW * 4, false, (GSPN_FUSED_ABL & 1)>(acc, ax_x, bx_x + ch * COUTC * LDW * 4, 0.f, 0.f);
             lds_product<KW / 2, 8, 8, true, (GSPN_FUSED_ABL & 2)>(accw[ch], ax_w, bx_w, w_sc, w_sh);
-            if constexpr (ch + 1 < NCH) __syncthreads();         // (the chunk's dY is consumed: the next chunk may overwrite it)
+            if constexpr (ch + 1 < NCH) {
+                prepare(ch + 1);
+                __syncthreads();                                 // (the chunk's dY is consumed: the next chunk may overwrite it)
+            }
         });
         if constexpr (RSUM && !(GSPN_FUSED_ABL & 16)) {
 #pragma unroll
@@ -3575,6 +3595,7 @@ __global__ __launch_bounds__(256) void bwd_fused_kernel(int rows, gspn_dy_args a
                 }
             }
         }
+        if (tile + grid < ntiles) prepare(0);                   // the next tile's values, before this tile's stores (see prepare)
         if (!(GSPN_FUSED_ABL & 8) || acc[0] == 1.2345f) {
             // (opaque per tile: otherwise hipcc hoists the 16 (lane offset + row * pitch) sums out of the tile loop as 64-bit pairs)
             unsigned lxx = lo_x;
