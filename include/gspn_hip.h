@@ -363,12 +363,15 @@ int gspn_mlp_bwd_data_ex(long rows, int cin, int cout, const gspn_dy_args* a, co
                          const float* work, float* dW,
                          const float* Yp, int ldyp, const float* scale_p, const float* shift_p, const float* mean_p, const float* var_p,
                          float eps_p, float* part, int* nparts_out, void* stream);
-/* Pass A and pass B of one layer in ONE launch (r03): with known coefficients (a->cA/cB/cC final) and a dense upstream gradient
- * (a->dZ) or the gradient of a max-pool over groups of 32 rows (a->dZ NULL, a->dPool / a->pool_arg, a->ns == 32), dW (cin, cout) = relu(Xp*in_scale + in_shift)^T . dY and dX (rows, ldx >= cin) = dY . W^T come from the same staged dY tile;
- * Xp (rows, ldxp) is the previous layer's raw output, in_scale / in_shift its forward scale / shift.  part (optional, with that layer's
- * mean_p / var_p): its BN reductions, exactly what gspn_mlp_bwd_data_ex leaves (*nparts_out rows for gspn_mlp_bwd_coef).  work: the
- * gspn_mlp_bwd_work_bytes(rows, cin, cout) buffer.  GSPN_ERR_UNSUPPORTED outside cin in {32, 64}, cout in {32, 64, 128}, rows >= 65536 a multiple of 128,
- * 16-byte aligned pitches (GSPN_BWD_FUSED=0: always): run gspn_mlp_bwd_wgrad_known + gspn_mlp_bwd_data_ex then. */
+/* Pass A and pass B of one layer in ONE launch (r03).  With known coefficients (a->cA/cB/cC final) and either a dense upstream gradient
+ * (a->dZ) or the gradient of a max-pool over groups of 32 rows (a->dZ NULL, a->dPool / a->pool_arg, a->ns == 32),
+ *     dW (cin, cout)        = relu(Xp*in_scale + in_shift)^T . dY
+ *     dX (rows, ldx >= cin) = dY . W^T
+ * come from the same staged dY tile.  Xp (rows, ldxp) is the previous layer's raw output, in_scale / in_shift its forward scale / shift.
+ * part (optional, with that layer's mean_p / var_p): its BN reductions, exactly what gspn_mlp_bwd_data_ex leaves (*nparts_out rows for
+ * gspn_mlp_bwd_coef).  work: the gspn_mlp_bwd_work_bytes(rows, cin, cout) buffer.
+ * GSPN_ERR_UNSUPPORTED outside cin in {32, 64}, cout in {32, 64, 128}, rows >= 65536 a multiple of 128, 16-byte aligned pitches
+ * (GSPN_BWD_FUSED=0: always): run gspn_mlp_bwd_wgrad_known + gspn_mlp_bwd_data_ex then. */
 long gspn_mlp_bwd_fused_work_bytes(long rows, int cin, int cout);
 int gspn_mlp_bwd_fused(long rows, int cin, int cout, const gspn_dy_args* a, const float* W, const float* Xp, int ldxp, const float* in_scale,
                        const float* in_shift, float* dX, int ldx, float* work, float* dW, const float* mean_p, const float* var_p,
