@@ -3687,6 +3687,7 @@ extern "C" int gspn_mlp_bwd_fused(long rows, int cin, int cout, const gspn_dy_ar
     if (rows <= 0 || cin <= 0 || cout <= 0 || !a || !a->Y || !a->scale || !a->shift || !W || !Xp || !dX || !work || !dW || ldxp < cin || ldx < cin)
         return GSPN_ERR_ARG;
     if (part && (!mean_p || !var_p || !nparts_out)) return GSPN_ERR_ARG;
+    if (a->ldy < cout || (a->dZ && a->ldz < cout)) return GSPN_ERR_ARG;
     const unsigned g = fused_grid(rows, cin, cout);
     const bool pooled = a->dZ == nullptr;
     if (!g || !a->cA || !a->cB || !a->cC || !in_scale || !in_shift) return GSPN_ERR_UNSUPPORTED;
