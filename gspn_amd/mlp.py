@@ -38,8 +38,8 @@ FUSE_DW = os.environ.get("GSPN_FUSE_DW", "1") != "0"
 # pass A and pass B of a layer in one launch where the library has the kernel for the shape (gspn_mlp_bwd_fused: both products from one staged
 # dY tile); the library's own switch is GSPN_BWD_FUSED
 FUSED_BWD = os.environ.get("GSPN_FUSED_BWD", "1") != "0"
-# the top layer of a stack with a dense upstream gradient takes its BN reductions in a streaming pre-pass (gspn_dense_rsum) from this many rows on
 POOLTOP_FUSED = os.environ.get("GSPN_POOLTOP_FUSED", "1") != "0"       # the pooled (nsample = 32) top layer through the fused launch as well
+# the top layer of a stack with a dense upstream gradient takes its BN reductions in a streaming pre-pass (gspn_dense_rsum) from this many rows on
 DENSE_TOP_RSUM = os.environ.get("GSPN_DENSE_TOP_RSUM", "1") != "0"
 DENSE_TOP_MIN_ROWS = int(os.environ.get("GSPN_DENSE_TOP_MIN_ROWS", "65536"))
 _side_streams = {}
