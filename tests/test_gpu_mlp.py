@@ -442,3 +442,91 @@ def test_pad_rows():
     out = torch.full((1000, 4), 7.0, device="cuda")
     L.check(L.lib().gspn_pad_rows(1000, 3, 4, L.ptr(x), L.ptr(out), L.stream()), "pad_rows")
     assert torch.equal(out[:, :3], x) and (out[:, 3] == 0).all()
+
+
+@pytest.mark.parametrize("cin,cout,pooled", [(64, 64, False), (32, 32, False), (32, 64, True), (64, 128, False), (64, 32, True), (32, 128, True)])
+def test_fused_backward_entry_point_with_padded_pitches(cin, cout, pooled):
+    """gspn_mlp_bwd_fused through the C ABI alone, every pitch LARGER than its channel count (the Python host only ever passes tight
+    tensors): dX, dW and the BN-reduction rows against a float64 evaluation of the same formulas on the device --
+    dY = cA*[relu open]*dz + cB*y + cC, dW = relu(Xp*s + t)^T . dY, dX = dY . W^T, (sum dyh, sum dyh*xhat) of the previous layer"""
+    import ctypes
+    from gspn_amd import _lib as L
+    lib = L.lib()
+    dev = torch.device("cuda", 0)
+    rows = 65536 + 128
+    g = torch.Generator(device=dev).manual_seed(cin * 1000 + cout)
+    ldy, ldz, ldxp, ldx = cout + 4, cout + 8, cin + 12, cin + 4
+    Yb = torch.randn(rows, ldy, device=dev, generator=g); Y = Yb[:, :cout]
+    Xb = torch.randn(rows, ldxp, device=dev, generator=g); Xp = Xb[:, :cin]
+    W = torch.randn(cin, cout, device=dev, generator=g) * 0.1
+    vec = lambda c, lo, hi: torch.rand(c, device=dev, generator=g) * (hi - lo) + lo
+    scale, shift = vec(cout, 0.5, 1.5), vec(cout, -0.3, 0.3)
+    cA, cB, cC = vec(cout, 0.5, 1.5), vec(cout, -0.01, 0.01), vec(cout, -0.01, 0.01)
+    isc, ish = vec(cin, 0.5, 1.5), vec(cin, -0.3, 0.3)
+    pmean, pvar = vec(cin, -0.2, 0.2), vec(cin, 0.5, 1.5)
+    a = L.DyArgs()
+    a.Y, a.ldy = Yb.data_ptr(), ldy
+    a.scale, a.shift, a.cA, a.cB, a.cC = scale.data_ptr(), shift.data_ptr(), cA.data_ptr(), cB.data_ptr(), cC.data_ptr()
+    if pooled:
+        ns = 32
+        dP = torch.randn(rows // ns, cout, device=dev, generator=g)
+        arg = torch.randint(0, ns, (rows // ns, cout), device=dev, dtype=torch.int32, generator=g)
+        a.dZ, a.ldz, a.dPool, a.pool_arg, a.ns = None, 0, dP.data_ptr(), arg.data_ptr(), ns
+        dz = torch.zeros(rows // ns, ns, cout, device=dev, dtype=torch.float64)
+        dz.scatter_(1, arg.long().unsqueeze(1), dP.double().unsqueeze(1))
+        dz = dz.view(rows, cout)
+    else:
+        Zb = torch.randn(rows, ldz, device=dev, generator=g)
+        a.dZ, a.ldz, a.dPool, a.pool_arg, a.ns = Zb.data_ptr(), ldz, None, None, 0
+        dz = Zb[:, :cout].double()
+    dXb = torch.full((rows, ldx), 7.0, device=dev)
+    dW = torch.empty(cin, cout, device=dev)
+    work = torch.empty(int(lib.gspn_mlp_bwd_work_bytes(rows, cin, cout)) // 4 + 4, device=dev)
+    part = torch.empty(int(lib.gspn_rsum_part_floats(rows, cin)), device=dev)
+    npart = ctypes.c_int(0)
+    L.check(lib.gspn_mlp_bwd_fused(rows, cin, cout, ctypes.byref(a), L.ptr(W), L.ptr(Xb), ldxp, L.ptr(isc), L.ptr(ish), L.ptr(dXb), ldx, L.ptr(work),
+                                   L.ptr(dW), L.ptr(pmean), L.ptr(pvar), 1e-3, L.ptr(part), ctypes.byref(npart), L.stream()), "fused")
+    torch.cuda.synchronize()
+    # float64 on the device; the ReLU masks are taken with the float32 expressions the kernels use (two roundings), so no element sits
+    # on the other side of a kink
+    open_y = (Y * scale + shift) > 0
+    dyh = torch.where(open_y, dz, torch.zeros_like(dz))
+    dY = cA.double() * dyh + cB.double() * Y.double() + cC.double()
+    xa = torch.relu(Xp * isc + ish).double()
+    rdW = xa.t() @ dY
+    rdX = dY @ W.double().t()
+    assert rel_err(dW, rdW) < 2e-5
+    assert rel_err(dXb[:, :cin], rdX) < 2e-5
+    assert bool((dXb[:, cin:] == 7.0).all())                       # the padding columns of dX are not touched
+    open_x = (Xp * isc + ish) > 0
+    dxh = torch.where(open_x, rdX, torch.zeros_like(rdX))
+    xhat = (Xp.double() - pmean.double()) / torch.sqrt(pvar.double() + 1e-3)
+    sums = part[:npart.value * 2 * cin].view(npart.value, 2, cin).double().sum(0)
+    r0, r1 = dxh.sum(0), (dxh * xhat).sum(0)
+    assert float((sums[0] - r0).abs().max()) <= 2e-5 * max(float(dxh.abs().sum(0).max()), 1e-9)
+    assert float((sums[1] - r1).abs().max()) <= 2e-5 * max(float((dxh * xhat).abs().sum(0).max()), 1e-9)
+
+
+@pytest.mark.parametrize("rows,c", [(70000, 64), (4096 + 3, 192), (100, 8), (65536, 1024)])
+def test_dense_rsum_entry_point_against_float64(rows, c):
+    """gspn_dense_rsum through the C ABI with padded pitches: (sum dyh, sum dyh*xhat) over the rows, dyh = [relu open] * dz"""
+    import ctypes
+    from gspn_amd import _lib as L
+    lib = L.lib()
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(rows + c)
+    ldz, ldy = c + 4, c + 8
+    Zb = torch.randn(rows, ldz, device=dev, generator=g); Yb = torch.randn(rows, ldy, device=dev, generator=g)
+    scale = torch.rand(c, device=dev, generator=g) + 0.5; shift = torch.randn(c, device=dev, generator=g) * 0.3
+    mean = torch.randn(c, device=dev, generator=g) * 0.2; var = torch.rand(c, device=dev, generator=g) + 0.5
+    part = torch.empty(int(lib.gspn_rsum_part_floats(rows, c)), device=dev)
+    npart = ctypes.c_int(0)
+    L.check(lib.gspn_dense_rsum(rows, c, L.ptr(Zb), ldz, L.ptr(Yb), ldy, L.ptr(scale), L.ptr(shift), L.ptr(mean), L.ptr(var), 1e-3, L.ptr(part),
+                                ctypes.byref(npart), L.stream()), "dense_rsum")
+    torch.cuda.synchronize()
+    Y, Z = Yb[:, :c], Zb[:, :c]
+    dyh = torch.where((Y * scale + shift) > 0, Z.double(), torch.zeros(1, device=dev, dtype=torch.float64))
+    xhat = (Y.double() - mean.double()) / torch.sqrt(var.double() + 1e-3)
+    sums = part[:npart.value * 2 * c].view(npart.value, 2, c).double().sum(0)
+    assert float((sums[0] - dyh.sum(0)).abs().max()) <= 2e-5 * float(dyh.abs().sum(0).max())
+    assert float((sums[1] - (dyh * xhat).sum(0)).abs().max()) <= 2e-5 * float((dyh * xhat).abs().sum(0).max())
