@@ -378,3 +378,24 @@ def test_knn_direct_random_shapes():
         rv, ri = O.knn_point(k, x1, x2)
         np.testing.assert_array_equal(i.cpu().numpy(), ri, err_msg="trial %d n=%d m=%d k=%d" % (trial, n, m, k))
         np.testing.assert_array_equal(v.cpu().numpy(), rv)
+
+
+def test_fps_prepass_voxel_order_is_a_permutation_in_voxel_order():
+    """gspn_fps_cells_prepass_order: the scan order handed to three_nn is a permutation of every scene's points, sorted by the 16^3-voxel
+    Morton id of the pre-pass (non-decreasing along the order; the order inside a voxel is arbitrary), and FPS itself is unaffected"""
+    from gspn_amd.tf_sampling import farthest_point_sample
+    xyz = D.batch("U", 3, 20000, 11)
+    t = dev(xyz)
+    idx, order = farthest_point_sample(512, t, return_order=True)
+    np.testing.assert_array_equal(idx.cpu().numpy(), O.farthest_point_sample(512, xyz, mt=True))
+    order = order.cpu().numpy()
+    spread = lambda v: (v & 1) | ((v & 2) << 2) | ((v & 4) << 4) | ((v & 8) << 6)
+    for b in range(3):
+        np.testing.assert_array_equal(np.sort(order[b]), np.arange(20000))
+        p = xyz[b]
+        lo, hi = p.min(0), p.max(0)
+        inv = np.where(hi > lo, np.float32(16.0) / (hi - lo), np.float32(0.0)).astype(np.float32)
+        q = np.clip(((p - lo) * inv).astype(np.int32), 0, 15)
+        vox = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
+        along = vox[order[b]]
+        assert (np.diff(along) >= 0).all()
