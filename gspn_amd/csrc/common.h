@@ -11,6 +11,9 @@
 #endif
 
 #define GSPN_WAVE 64
+#ifndef GSPN_GEOM_CLAIM_LDS_DEFAULT
+#define GSPN_GEOM_CLAIM_LDS_DEFAULT 4
+#endif
 
 // Squared distance exactly as the nvcc-built reference kernels evaluate
 //   (x2-x1)*(x2-x1)+(y2-y1)*(y2-y1)+(z2-z1)*(z2-z1)          (tf_sampling_g.cu:142, tf_grouping_g.cu:27)
@@ -83,6 +86,26 @@ __device__ __forceinline__ int lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u,
 static inline int gspn_launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
+}
+
+// Straggler experiment: a geometry kernel that leaves part of its CU's 160 KiB of LDS free lets a workgroup of the
+// layers' persistent grids land on that CU, where it shares the SIMDs with the geometry waves and finishes last.  GSPN_GEOM_CLAIM_LDS is a
+// bit mask (1 = fps_cell_kernel, 2 = fps_small_kernel, 4 = csr_build_lds_kernel, 8 = fps_resident_kernel) of kernels that then ask for
+// the whole CU's LDS.  Read once.  Returns the dynamic LDS size to launch with (>= dyn), or dyn if the bit is not set / on any error.
+#include <stdlib.h>
+static inline int gspn_claim_lds_mask() {
+    static const int v = getenv("GSPN_GEOM_CLAIM_LDS") ? atoi(getenv("GSPN_GEOM_CLAIM_LDS")) : GSPN_GEOM_CLAIM_LDS_DEFAULT;
+    return v;
+}
+static inline size_t gspn_claim_lds(int bit, const void* fn, size_t dyn) {
+    if (!(gspn_claim_lds_mask() & bit)) return dyn;
+    hipFuncAttributes a;
+    if (hipFuncGetAttributes(&a, fn) != hipSuccess) return dyn;
+    const size_t full = (size_t)160 * 1024;
+    if (a.sharedSizeBytes + dyn >= full) return dyn;
+    const size_t want = full - a.sharedSizeBytes;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want) != hipSuccess) { (void)hipGetLastError(); return dyn; }
+    return want;
 }
 
 // CUs the persistent / statically partitioned kernels plan for.  MI355X has 256 (8 XCDs x 32; workgroups go round-robin to the XCDs);

@@ -611,7 +611,8 @@ extern "C" int gspn_inverse_lists(int b, int L, int n, const int* idx, int* work
             if (ea != hipSuccess) return (int)ea;
             attr_done = true;
         }
-        hipLaunchKernelGGL(csr_build_lds_kernel, dim3(b), dim3(1024), sizeof(int) * (size_t)n, st, L, n, idx, offsets, tmp);
+        const size_t lds = gspn_claim_lds(4, reinterpret_cast<const void*>(&csr_build_lds_kernel), sizeof(int) * (size_t)n);
+        hipLaunchKernelGGL(csr_build_lds_kernel, dim3(b), dim3(1024), lds, st, L, n, idx, offsets, tmp);
         if (total > 0) hipLaunchKernelGGL(csr_sort_kernel, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, st, nwaves, L, n, offsets, tmp, order);
         return gspn_launch_status();
     }

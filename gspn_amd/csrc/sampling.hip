@@ -708,12 +708,13 @@ int gspn_fps_prepass_cells(int b, int n, int ncell, int csz, const float* inp, i
 
 template <int P, bool ZLDS>
 static int launch_fps_cell(int b, int n, int m, int csz, const float* sxyz, const int* perm, const float* inp0, int stride0, int* out, hipStream_t st) {
-    const size_t lds = 4096 + (ZLDS ? (size_t)P * FPS_T * sizeof(float) : 0);
+    size_t lds = 4096 + (ZLDS ? (size_t)P * FPS_T * sizeof(float) : 0);
     if (ZLDS) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fps_cell_kernel<P, ZLDS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
+    lds = gspn_claim_lds(1, reinterpret_cast<const void*>(&fps_cell_kernel<P, ZLDS>), lds);
     hipLaunchKernelGGL((fps_cell_kernel<P, ZLDS>), dim3(b), dim3(FPS_T), lds, st, n, m, csz, sxyz, perm, inp0, stride0, out);
     return gspn_launch_status();
 }
@@ -848,7 +849,8 @@ __global__ __launch_bounds__(256) void fps_small_kernel(int n, int m, const floa
 }
 template <int C>
 static int launch_fps_small(int b, int n, int m, const float* inp, int* out, hipStream_t st) {
-    hipLaunchKernelGGL((fps_small_kernel<C>), dim3(b), dim3(256), 0, st, n, m, inp, out);
+    const size_t lds = gspn_claim_lds(2, reinterpret_cast<const void*>(&fps_small_kernel<C>), 0);
+    hipLaunchKernelGGL((fps_small_kernel<C>), dim3(b), dim3(256), lds, st, n, m, inp, out);
     return gspn_launch_status();
 }
 

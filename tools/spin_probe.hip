@@ -48,6 +48,16 @@ extern "C" __global__ void loop_valu_barrier(long long iters, float* out) {
     for (long long it = 0; it < iters; ++it) { for (int i = 0; i < 64; ++i) a = a * b + 0.5f; __syncthreads(); }
     if (a == 1.2345f) out[0] = a;
 }
+// r04: the busy 1024-thread VALU loop of loop_valu, HOLDING the CU's whole LDS -- no workgroup of the layers can be
+// co-scheduled on its CU.  If co-residency (a layer workgroup sharing SIMD issue with the busy waves and finishing last) is what a busy
+// neighbour costs, this one is nearly free where loop_valu costs +0.85 ms per step.
+extern "C" __global__ void loop_valu_lds(long long iters, float* out) {
+    extern __shared__ float lds[];
+    if (threadIdx.x == 0) lds[0] = 1.f;
+    float a = threadIdx.x, b = 1.0001f;
+    for (long long it = 0; it < iters; ++it) { for (int i = 0; i < 64; ++i) a = a * b + 0.5f; }
+    if (a == 1.2345f) out[0] = a + lds[0];
+}
 // occupancy-only side kernels: hold a CU's LDS (or all of its vector registers) while doing nothing
 extern "C" __global__ void hold_lds(long long cycles, float* out) {
     extern __shared__ float lds[];
@@ -72,7 +82,8 @@ extern "C" __global__ void spin_valu_one_xcd(long long cycles, float* out) {
 extern "C" int launch_spin(int which, int blocks, int threads, long long cycles, float* out, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (which == 11) { hipLaunchKernelGGL(spin_valu_one_xcd, dim3(blocks), dim3(threads), 0, st, cycles, out); return (int)hipGetLastError(); }
-    if (which == 9) { hipFuncSetAttribute(reinterpret_cast<const void*>(&hold_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 131072); hipLaunchKernelGGL(hold_lds, dim3(blocks), dim3(threads), 131072, st, cycles, out); }
+    if (which == 12) { hipFuncSetAttribute(reinterpret_cast<const void*>(&loop_valu_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 163840); hipLaunchKernelGGL(loop_valu_lds, dim3(blocks), dim3(threads), 163840, st, cycles, out); }
+    else if (which == 9) { hipFuncSetAttribute(reinterpret_cast<const void*>(&hold_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 131072); hipLaunchKernelGGL(hold_lds, dim3(blocks), dim3(threads), 131072, st, cycles, out); }
     else if (which == 10) hipLaunchKernelGGL(hold_vgpr, dim3(blocks), dim3(threads), 0, st, cycles, out);
     else if (which == 6) hipLaunchKernelGGL(loop_valu_yield<0>, dim3(blocks), dim3(threads), 0, st, cycles, out);
     else if (which == 7) hipLaunchKernelGGL(loop_valu_yield<1>, dim3(blocks), dim3(threads), 0, st, cycles, out);
