@@ -1,0 +1,150 @@
+// csr_gather.h -- the gather-form gradients of grouping and interpolation (gspn_sa_group_concat_grad_csr, gspn_fp_concat_grad_csr) on
+// sixteen lanes per target row (r04).
+//
+//   out[s][j][0 : c) = sum over e in [offsets[s][j], offsets[s][j+1]), ASCENDING e, of  wt(e) * src[s][row(order[s][e])][col0 : col0 + c)
+//
+// with row(p) = p, wt = 1 for the grouping (tf_grouping_g.cu:66-83; any fixed order is as faithful as the reference's atomicAdd) and
+// row(p) = p / 3, wt = weight[s][p] for the interpolation -- ascending (i, t): the order of the reference's sequential loop
+// (tf_interpolate.cpp:131-153), so the sums are bit-identical to it.
+//
+// Round 3's kernels gave every target a whole wave, lane = channel: one 256-byte row per load instruction, four in flight, every list
+// entry's index fetched by all 64 lanes -- 7-12 % of the wave cycles issued an instruction, the rest waited on a chain of dependent
+// loads (profiles/r03_sq_pmc_by_kernel.txt).  Here a target owns one DPP row of 16 lanes, a lane owns 4 * CPL channels (float4 loads), so
+// a wave walks FOUR lists at once; the 16 lanes fetch the next 16 list entries (and their weights) with one coalesced load each and
+// hand them round with row_newbcast DPP moves -- no LDS, no per-entry index load -- and up to 8 row loads per lane are in flight
+// before the first is consumed.  The accumulation order per target is unchanged: ascending e, one rounding per product and per sum
+// (the translation unit is built -ffp-contract=off).
+// Targets are dealt to the workgroups so that XCD x (= blockIdx % 8) takes the x-th eighth of the (scene, target) space -- with eight
+// scenes, one scene per XCD: every re-read of a source row (3 per row for the interpolation) finds the row in that XCD's L2 or not
+// at all, instead of all eight L2s streaming all scenes.
+#pragma once
+#include <type_traits>
+
+#include "common.h"
+
+template <int K>
+__device__ __forceinline__ int row_bcast_i32(int v) {          // lane K of every 16-lane row to all lanes of that row
+    return __builtin_amdgcn_update_dpp(v, v, 0x150 + K, 0xF, 0xF, false);
+}
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+struct CsrCopy {                      // the skip-link columns of fp_concat's gradient are a plain slice of grad_out: trailing workgroups copy it
+    const float* g; float* dst; int ld, c0, c1; long total;
+};
+
+template <int CPL, bool WEIGHTED>
+__global__ __launch_bounds__(256) void csr_gather16_kernel(int nt, int L, long src_scene_floats, int ld, int col0, const float* __restrict__ src,
+                                                           const int* __restrict__ order, const int* __restrict__ offsets,
+                                                           const float* __restrict__ weight, float* __restrict__ out, long ntot, long part,
+                                                           unsigned gather_blocks, CsrCopy cp) {
+    constexpr int U = CPL == 1 ? 8 : (CPL == 2 ? 4 : 2);          // list entries whose row loads are issued together (8 float4 per lane in flight)
+    if (blockIdx.x >= gather_blocks) {
+        const long nthreads = (long)(gridDim.x - gather_blocks) * 256;
+        for (long i = (long)(blockIdx.x - gather_blocks) * 256 + threadIdx.x; i < cp.total; i += nthreads) {
+            const long row = i / cp.c1;
+            const int l = (int)(i - row * cp.c1);
+            cp.dst[i] = cp.g[row * cp.ld + cp.c0 + l];
+        }
+        return;
+    }
+    const int q = threadIdx.x & 15, sub = threadIdx.x >> 4;
+    const long lt = (long)(blockIdx.x >> 3) * 16 + sub;
+    const long tg = (long)(blockIdx.x & 7) * part + lt;
+    if (lt >= part || tg >= ntot) return;                         // (whole 16-lane rows leave together: the DPP moves below stay inside live rows)
+    const int s = (int)(tg / nt), j = (int)(tg - (long)s * nt);
+    const int* off = offsets + (size_t)s * (nt + 1);
+    const int e0 = off[j], e1 = off[j + 1];
+    const int* ord = order + (size_t)s * L;
+    const float* w = WEIGHTED ? weight + (size_t)s * L : nullptr;
+    const char* gs = reinterpret_cast<const char*>(src + (size_t)s * src_scene_floats + col0 + 4 * q);
+    float4 acc[CPL];
+#pragma unroll
+    for (int h = 0; h < CPL; ++h) acc[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // this lane's entry of the first 16: byte offset of its source row, its weight
+    int ob = 0;
+    float wt = 1.f;
+    if (e0 + q < e1) {
+        const int p = ord[e0 + q];
+        ob = (WEIGHTED ? p / 3 : p) * (ld * 4);
+        if (WEIGHTED) wt = w[p];
+    }
+    for (int eb = e0; eb < e1; eb += 16) {
+        const int cnt = min(16, e1 - eb);
+        int obn = 0;
+        float wtn = 1.f;
+        const int men = eb + 16 + q;
+        int pn = 0;
+        if (men < e1) pn = ord[men];                              // the next 16 entries' indices: in flight under this round's row loads
+        static_for<0, 16 / U>([&](auto gi) {
+            constexpr int K0 = decltype(gi)::value * U;
+            if (K0 < cnt) {                                      // (uniform per 16-lane row)
+                const int ob0 = row_bcast_i32<K0>(ob);
+                float4 v[U][CPL];
+                float ws[U];
+                static_for<0, U>([&](auto ui) {
+                    constexpr int u = decltype(ui)::value, K = K0 + u;
+                    int o = row_bcast_i32<K>(ob);
+                    ws[u] = __int_as_float(row_bcast_i32<K>(__float_as_int(wt)));
+                    o = K < cnt ? o : ob0;                       // past the list's end: re-read the group's first row (a cache hit), not added
+#pragma unroll
+                    for (int h = 0; h < CPL; ++h) v[u][h] = *reinterpret_cast<const float4*>(gs + (size_t)(unsigned)o + 256 * h);
+                });
+                static_for<0, U>([&](auto ui) {
+                    constexpr int u = decltype(ui)::value, K = K0 + u;
+                    if (K < cnt) {
+#pragma unroll
+                        for (int h = 0; h < CPL; ++h) {
+                            if (WEIGHTED) {
+                                acc[h].x += v[u][h].x * ws[u]; acc[h].y += v[u][h].y * ws[u]; acc[h].z += v[u][h].z * ws[u]; acc[h].w += v[u][h].w * ws[u];
+                            } else {
+                                acc[h].x += v[u][h].x; acc[h].y += v[u][h].y; acc[h].z += v[u][h].z; acc[h].w += v[u][h].w;
+                            }
+                        }
+                    }
+                });
+            }
+        });
+        if (men < e1) {
+            obn = (WEIGHTED ? pn / 3 : pn) * (ld * 4);
+            if (WEIGHTED) wtn = w[pn];
+        }
+        ob = obn;
+        wt = wtn;
+    }
+    float* o = out + (size_t)tg * (64 * CPL) + 4 * q;
+#pragma unroll
+    for (int h = 0; h < CPL; ++h) *reinterpret_cast<float4*>(o + 64 * h) = acc[h];
+}
+
+// c == 64 * CPL, 16-byte aligned rows, byte offsets inside a scene's source below 2^31; returns GSPN_ERR_UNSUPPORTED otherwise (the caller
+// then takes the wave-per-target kernel)
+static int csr_gather16(bool weighted, int b, int nt, int L, long src_rows_per_scene, int c, int ld, int col0, const float* src, const int* order,
+                        const int* offsets, const float* weight, float* out, const CsrCopy& cp, hipStream_t st) {
+    static const bool off = getenv("GSPN_CSR_GATHER16") && atoi(getenv("GSPN_CSR_GATHER16")) == 0;      // comparison switch, read once
+    if (off) return GSPN_ERR_UNSUPPORTED;
+    if (c != 64 && c != 128 && c != 256) return GSPN_ERR_UNSUPPORTED;
+    if ((ld & 3) || (col0 & 3) || ((uintptr_t)src % 16) || ((uintptr_t)out % 16)) return GSPN_ERR_UNSUPPORTED;
+    if (src_rows_per_scene * (long)ld * 4 >= (1L << 31)) return GSPN_ERR_UNSUPPORTED;
+    const long ntot = (long)b * nt;
+    const long part = ((ntot + 7) / 8 + 15) / 16 * 16;            // targets per XCD slice, whole workgroups
+    const long gb = 8 * (part / 16);
+    long cb = 0;
+    if (cp.total > 0) {
+        cb = (cp.total + 256 * 16 - 1) / (256 * 16);               // ~16 elements per thread
+        if (cb > 2048) cb = 2048;
+    }
+    if (gb + cb > 0x7FFFFFFFl) return GSPN_ERR_UNSUPPORTED;
+    const dim3 grid((unsigned)(gb + cb));
+    const long ssf = src_rows_per_scene * (long)ld;
+#define CSR_GO(CPL_, W_) hipLaunchKernelGGL((csr_gather16_kernel<CPL_, W_>), grid, dim3(256), 0, st, nt, L, ssf, ld, col0, src, order, offsets, weight, out, ntot, part, (unsigned)gb, cp)
+    if (weighted) { if (c == 64) CSR_GO(1, true); else if (c == 128) CSR_GO(2, true); else CSR_GO(4, true); }
+    else { if (c == 64) CSR_GO(1, false); else if (c == 128) CSR_GO(2, false); else CSR_GO(4, false); }
+#undef CSR_GO
+    return gspn_launch_status();
+}

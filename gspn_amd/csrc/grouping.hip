@@ -6,6 +6,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "csr_gather.h"
 
 // ============================================================================================
 // Ball query (reference: tf_grouping_g.cu:6-39)
@@ -348,6 +349,11 @@ extern "C" int gspn_sa_group_concat_grad_csr(int b, int n, int c, int m, int nsa
                                              const float* grad_out, float* grad_points, void* stream) {
     if (b < 0 || n <= 0 || c <= 0 || m < 0 || nsample < 0 || ld_out < (xyz_first ? 3 : 0) + c || !order || !offsets) return GSPN_ERR_ARG;
     if (b == 0) return 0;
+    if (!xyz_first && grad_out && grad_points) {                     // sixteen lanes per data point (csr_gather.h); same sums, same order
+        const CsrCopy cp{nullptr, nullptr, 0, 0, 0, 0};
+        const int rc = csr_gather16(false, b, n, m * nsample, (long)m * nsample, c, ld_out, 0, grad_out, order, offsets, nullptr, grad_points, cp, (hipStream_t)stream);
+        if (rc != GSPN_ERR_UNSUPPORTED) return rc;
+    }
     const long nwaves = (long)b * n * ((c + 63) / 64);
     const long blocks = (nwaves + 3) / 4;
     if (blocks > 0x7FFFFFFFl) return GSPN_ERR_UNSUPPORTED;

@@ -7,6 +7,7 @@
 #include <stdint.h>
 
 #include "common.h"
+#include "csr_gather.h"
 
 // ============================================================================================
 // three_nn (tf_interpolate.cpp:60-103): for each dense point j the 3 smallest squared distances
@@ -466,8 +467,13 @@ extern "C" int gspn_fp_concat_grad_csr(int b, int n, int m, int c2, int c1, int 
                                        const float* weight, float* grad_points2, float* grad_points1, void* stream) {
     if (b < 0 || n < 0 || m <= 0 || c2 <= 0 || c1 < 0 || ld < c2 + c1 || !order || !offsets || !weight) return GSPN_ERR_ARG;
     if (b == 0 || n == 0) return 0;
-    const long nwaves2 = (long)b * m * ((c2 + 63) / 64);
     const long copy_total = grad_points1 ? (long)b * n * c1 : 0;
+    if (grad_points2) {                                              // sixteen lanes per sparse point (csr_gather.h); same sums, same order
+        const CsrCopy cp{grad_out, grad_points1, ld, c2, c1, copy_total};
+        const int rc = csr_gather16(true, b, m, 3 * n, n, c2, ld, 0, grad_out, order, offsets, weight, grad_points2, cp, (hipStream_t)stream);
+        if (rc != GSPN_ERR_UNSUPPORTED) return rc;
+    }
+    const long nwaves2 = (long)b * m * ((c2 + 63) / 64);
     long copy_waves = (copy_total + 64 * 16 - 1) / (64 * 16);          // ~16 elements per lane
     if (copy_waves > 8192) copy_waves = 8192;
     const long blocks = (nwaves2 + copy_waves + 3) / 4;

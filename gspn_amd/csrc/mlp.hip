@@ -2789,6 +2789,119 @@ __global__ __launch_bounds__(256) void preagg_fwd_kernel(long rows, int cout, Pr
         stats[(size_t)blockIdx.x * 2 * cout + j] = v;                // [block][2][cout]: sum, sum of squares
     }
 }
+// r04: the same computation on 16-lane DPP rows.  An output row is 64 * HPR channels = HPR DPP rows of 16 lanes x float4; a group of HPR
+// DPP rows walks blocks of 16 consecutive output rows: lane q FETCHES everything row r0 + q needs (its T source rows' byte offsets, their
+// weights, its side columns -- coalesced loads, issued one block ahead) and the 16 lanes hand those values round with row_newbcast DPP
+// moves, so that the gathered float4 loads of U rows x T sources are all in flight before the first is used.  Round 3's kernel had every
+// lane of a row fetch that row's index itself and two rows in flight: 18 % of its wave cycles issued an instruction (r03_sq_pmc_by_kernel).
+// Y is bit-identical (same expression per element); the column sums are accumulated in a different (fixed) order.
+template <int K>
+__device__ __forceinline__ int pa_bcast(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x150 + K, 0xF, 0xF, false); }
+template <int I, int N, class F>
+__device__ __forceinline__ void pa_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        pa_static_for<I + 1, N>(f);
+    }
+}
+template <int T, int HPR>
+__global__ __launch_bounds__(256) void preagg_fwd16_kernel(long rows, PreaggSrc ps, const float* __restrict__ Ws, const float* __restrict__ bias,
+                                                           float* __restrict__ Y, float* __restrict__ stats) {
+    constexpr int COUT = 64 * HPR;
+    constexpr int NG = 16 / HPR;                     // row groups per workgroup
+    constexpr int U = T == 1 ? 8 : 4;                // output rows whose gathered loads are issued together (16 / 8: no faster, measured)
+    extern __shared__ float pa_sh[];                 // [2][NG][COUT]
+    const int lane16 = threadIdx.x & 15, drow = threadIdx.x >> 4;
+    const int grp = drow / HPR, half = drow % HPR;
+    const int q = half * 16 + lane16;                // this lane's float4 of a row
+    float4 wsd[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) wsd[k] = k < ps.side_n ? *reinterpret_cast<const float4*>(Ws + (size_t)k * COUT + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 bq = bias ? *reinterpret_cast<const float4*>(bias + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    // XCD x = blockIdx % 8 takes the x-th eighth of the rows (one scene's slice of F stays in that XCD's L2), in blocks of 16 * NG rows
+    const int nx = (gridDim.x % 8 == 0 && rows >= 8L * 256) ? 8 : 1;
+    const long part = ((rows + nx - 1) / nx + 15) / 16 * 16;
+    const long p0 = (long)(blockIdx.x % nx) * part, p1 = min(rows, p0 + part);
+    const long stride = (long)(gridDim.x / nx) * (16 * NG);
+    const char* Fb = reinterpret_cast<const char*>(ps.F) + 16 * q;
+    int ob[T], obn[T];
+    float wt[T], wtn[T], sd[4], sdn[4];
+    auto fetch = [&](long r0, int (&o)[T], float (&w)[T], float (&sv)[4]) {      // what row r0 + lane16 needs (clamped: unconditional loads)
+        long rc = r0 + lane16;
+        rc = rc < p1 ? rc : p1 - 1;
+        const long base = ps.per_scene_rows > 0 ? (rc / ps.per_scene_rows) * (long)ps.per_scene_src : 0;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            o[t] = (int)(base + ps.idx[rc * T + t]) * (COUT * 4);
+            w[t] = ps.w ? ps.w[rc * T + t] : 1.f;
+        }
+        if (ps.side_n > 0 && ps.side_ld == 4) {
+            const float4 v = *reinterpret_cast<const float4*>(ps.side + (size_t)rc * 4);
+            sv[0] = v.x; sv[1] = v.y; sv[2] = v.z; sv[3] = v.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sv[k] = k < ps.side_n ? ps.side[(size_t)rc * ps.side_ld + k] : 0.f;
+        }
+    };
+    long r0 = p0 + (long)(blockIdx.x / nx) * (16 * NG) + 16 * grp;
+    if (r0 < p1) fetch(r0, ob, wt, sd);
+    for (; r0 < p1; r0 += stride) {
+        const long rn = r0 + stride;
+        if (rn < p1) fetch(rn, obn, wtn, sdn);                              // the next block's indices: in flight under this block's gathers
+        const int cnt = (int)min(16L, p1 - r0);
+        pa_static_for<0, 16 / U>([&](auto gi) {
+            constexpr int K0 = decltype(gi)::value * U;
+            if (K0 < cnt) {
+                float4 f[U][T];
+                float wv[U][T], sv[U][4];
+                pa_static_for<0, U>([&](auto ui) {
+                    constexpr int u = decltype(ui)::value, K = K0 + u;
+#pragma unroll
+                    for (int t = 0; t < T; ++t) {
+                        const int o = pa_bcast<K>(ob[t]);                   // (rows past the end re-read the clamped last row; masked at the store)
+                        f[u][t] = *reinterpret_cast<const float4*>(Fb + (size_t)(unsigned)o);
+                        wv[u][t] = __int_as_float(pa_bcast<K>(__float_as_int(wt[t])));
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) sv[u][k] = __int_as_float(pa_bcast<K>(__float_as_int(sd[k])));
+                });
+                pa_static_for<0, U>([&](auto ui) {
+                    constexpr int u = decltype(ui)::value, K = K0 + u;
+                    if (K < cnt) {
+                        float4 y;
+                        if (T == 1 && !ps.w) y = f[u][0];
+                        else {
+                            y = make_float4(f[u][0].x * wv[u][0], f[u][0].y * wv[u][0], f[u][0].z * wv[u][0], f[u][0].w * wv[u][0]);
+#pragma unroll
+                            for (int t = 1; t < T; ++t) { y.x += f[u][t].x * wv[u][t]; y.y += f[u][t].y * wv[u][t]; y.z += f[u][t].z * wv[u][t]; y.w += f[u][t].w * wv[u][t]; }
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { y.x += sv[u][k] * wsd[k].x; y.y += sv[u][k] * wsd[k].y; y.z += sv[u][k] * wsd[k].z; y.w += sv[u][k] * wsd[k].w; }
+                        y.x += bq.x; y.y += bq.y; y.z += bq.z; y.w += bq.w;
+                        *reinterpret_cast<float4*>(Y + (size_t)(r0 + K) * COUT + 4 * q) = y;
+                        s1.x += y.x; s1.y += y.y; s1.z += y.z; s1.w += y.w;
+                        s2.x += y.x * y.x; s2.y += y.y * y.y; s2.z += y.z * y.z; s2.w += y.w * y.w;
+                    }
+                });
+            }
+        });
+#pragma unroll
+        for (int t = 0; t < T; ++t) { ob[t] = obn[t]; wt[t] = wtn[t]; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sd[k] = sdn[k];
+    }
+    if (!stats) return;
+    *reinterpret_cast<float4*>(pa_sh + ((size_t)0 * NG + grp) * COUT + 4 * q) = s1;
+    *reinterpret_cast<float4*>(pa_sh + ((size_t)1 * NG + grp) * COUT + 4 * q) = s2;
+    __syncthreads();
+    for (int j = threadIdx.x; j < 2 * COUT; j += 256) {
+        const int h = j / COUT, c = j - h * COUT;
+        float v = 0.f;
+        for (int k = 0; k < NG; ++k) v += pa_sh[((size_t)h * NG + k) * COUT + c];
+        stats[(size_t)blockIdx.x * 2 * COUT + j] = v;                // [block][2][cout]: sum, sum of squares
+    }
+}
 static bool preagg_shape_ok(int cout) { return cout >= 4 && cout <= 1024 && (cout & 3) == 0 && ((cout >> 2) & ((cout >> 2) - 1)) == 0; }
 extern "C" int gspn_preagg_ok(int cout) { return preagg_shape_ok(cout) ? 1 : 0; }
 // workgroups (= partial statistics rows) of gspn_preagg_fwd: every thread gets about four rows, 2048 workgroups at most
@@ -2810,6 +2923,19 @@ extern "C" int gspn_preagg_fwd(long rows, int cout, int T, const float* F, const
     const PreaggSrc ps{F, idx, w, per_scene_rows, per_scene_src, side, side_ld, side_n};
     const unsigned nb = preagg_fwd_blocks(rows, cout);   // = the number of partial rows: gspn_bn_finalize_parts(..., gspn_preagg_fwd_parts(rows, cout), ...)
     const size_t sh = sizeof(float) * 2 * 256 * 4;       // 2 * rpi * cout floats, rpi * cout = 1024
+    static const int rows16 = env_int("GSPN_PREAGG_FWD16", 1);          // (A/B hook: 0 = round 3's kernel)
+    const long fsrc_bytes = (long)(per_scene_rows > 0 ? ((rows + per_scene_rows - 1) / per_scene_rows) * (long)per_scene_src : 0) * cout * 4;
+    if (rows16 && (cout == 64 || cout == 128 || cout == 256) && fsrc_bytes < (1L << 31) && (side_n == 0 || side_ld != 4 || ((uintptr_t)side % 16) == 0)
+        && (per_scene_rows > 0 || true)) {
+        // (T = 1: idx are global source rows; their byte offsets must stay below 2^31 as well -- the caller's F has at most rows source rows)
+        if (per_scene_rows > 0 || rows * (long)cout * 4 < (1L << 31)) {
+#define PA16_GO(T_, H_) hipLaunchKernelGGL((preagg_fwd16_kernel<T_, H_>), dim3(nb), dim3(256), sh, (hipStream_t)stream, rows, ps, Wside, bias, Y, stats)
+            if (T == 1) { if (cout == 64) PA16_GO(1, 1); else if (cout == 128) PA16_GO(1, 2); else PA16_GO(1, 4); }
+            else { if (cout == 64) PA16_GO(3, 1); else if (cout == 128) PA16_GO(3, 2); else PA16_GO(3, 4); }
+#undef PA16_GO
+            return gspn_launch_status();
+        }
+    }
     static const int uu = env_int("GSPN_PREAGG_U", 2);
 #define PA_GO(T_, U_) hipLaunchKernelGGL((preagg_fwd_kernel<T_, U_>), dim3(nb), dim3(256), sh, (hipStream_t)stream, rows, cout, ps, Wside, bias, Y, stats)
     if (T == 1) { if (uu == 1) PA_GO(1, 1); else if (uu == 2) PA_GO(1, 2); else PA_GO(1, 4); }
