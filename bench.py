@@ -40,8 +40,16 @@ NPOINTS = 32768
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def synth(b, n, seed0):
-    xyz = np.stack([np.random.default_rng(seed0 + i).random((n, 3), dtype=np.float32) for i in range(b)])
+DATA_KIND = "U"            # U = uniform in the unit cube (primary), S = room surfaces at metre scale, D = U with 10 % duplicated points
+
+
+def synth(b, n, seed0, kind=None):
+    kind = kind or DATA_KIND
+    if kind == "U":
+        xyz = np.stack([np.random.default_rng(seed0 + i).random((n, 3), dtype=np.float32) for i in range(b)])
+    else:
+        from gspn_amd import synth as _synth            # cloud_s: faces of an 8 x 6 x 3 m room + 20 boxes; cloud_d: dataset.py:100-105's duplicates
+        xyz = _synth.batch(kind, b, n, seed0)
     col = np.stack([np.random.default_rng(10_000 + seed0 + i).random((n, 3), dtype=np.float32) for i in range(b)])
     return xyz, col
 
@@ -70,6 +78,10 @@ def main():
     # warm-up also run below the settled clock: 2.03 ms per step over 20 steps against 1.98 over 60-100)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--data", choices=["U", "S", "D"], default="U", help="synthetic cloud kind of SURVEY 8(d): U uniform unit cube (the headline), "
+                    "S ScanNet-like room surfaces at metre scale, D uniform with 10 %% duplicated points (dataset.py:100-105)")
+    ap.add_argument("--kind-leg", action="store_true", help="(internal) a short run on --data whose line carries the ball-query leg only: the "
+                    "default run spawns one per non-headline kind and folds the figures into `data_kinds`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="geometry inline on the main stream instead of prefetched on a side stream")
     ap.add_argument("--no-graph", action="store_true", help="enqueue the layers kernel by kernel instead of replaying a captured hipGraph")
@@ -84,6 +96,8 @@ def main():
                     "issuing it after the replay (diagnostic: the default placement is after the graph)")
     args = ap.parse_args()
 
+    global DATA_KIND
+    DATA_KIND = args.data
     if args.legs_only:
         return legs_main(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -375,8 +389,16 @@ def main():
     state["t_wait"] = 0.0
     t0 = time.perf_counter()
     stamps = [] if os.environ.get("GSPN_BENCH_STEP_TIMES") == "1" else None      # (diagnostic: host clock after every step, the host trails the GPU by <= 2 steps)
-    for _ in range(args.steps):
+    # SURVEY 8(d) asks for the MEDIAN step: one timing event per step on the layers' stream (created before the timed region; recording an
+    # event that nobody waits for costs the stream nothing -- DESIGN 4.6), read after the final synchronisation
+    step_ev = None
+    if os.environ.get("GSPN_BENCH_NO_STEP_EVENTS") != "1":
+        step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+        step_ev[0].record()
+    for si in range(args.steps):
         step()
+        if step_ev is not None:
+            step_ev[si + 1].record()
         if tf_sampling.PROFILE is not None:
             drain_events()
         if stamps is not None:
@@ -390,6 +412,10 @@ def main():
                                                                for j in range(0, len(stamps), w))), file=sys.stderr)
         d = sorted(((stamps[j] - (stamps[j - 1] if j else t0)) * 1e3, j) for j in range(len(stamps)))[-3:]
         print("longest steps (ms, index): %s" % " ".join("%.2f@%d" % x for x in d), file=sys.stderr)
+    step_median_ms = None
+    if step_ev is not None:
+        per = [step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps)]
+        step_median_ms = float(np.median(per))             # GPU time between the ends of consecutive steps on the layers' stream
     if tf_sampling.PROFILE is not None:
         drain_events(final=True)
     tf_sampling.PROFILE = None
@@ -407,7 +433,7 @@ def main():
     fps_avg_ms = float(np.mean(fps_ms)) if fps_ms else float("nan")
     achieved = alg_bytes / (fps_avg_ms * 1e-3) / 1e9
     traffic = None
-    pmc = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r02_fps_pmc.json", "r01_fps_pmc.json")) if os.path.exists(q)), None)
+    pmc = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r04_fps_pmc.json", "r03_fps_pmc.json", "r02_fps_pmc.json", "r01_fps_pmc.json")) if os.path.exists(q)), None)
     if pmc:
         try:
             pj = json.load(open(pmc))
@@ -430,11 +456,14 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
+            "median_ms_per_step": step_median_ms,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic" if not LAYERS_ONLY else "DIAGNOSTIC RUN, NOT A RESULT: geometry skipped (GSPN_BENCH_LAYERS_ONLY)",
+            "data": ("synthetic (%s)" % {"U": "U: xyz ~ U[0,1)^3, SURVEY 8(d)'s primary kind", "S": "S: ScanNet-like room surfaces, 8 x 6 x 3 m + 20 boxes, metre scale",
+                                         "D": "D: uniform with the last 10 % of the points duplicates of earlier ones"}[DATA_KIND])
+                    if not LAYERS_ONLY else "DIAGNOSTIC RUN, NOT A RESULT: geometry skipped (GSPN_BENCH_LAYERS_ONLY)",
             "config": {"workload": "BASELINE configs[2]: batch 8 x 32768-pt scenes per GPU, 3-level SA + 3-level FP (three_nn/interpolate) fwd+bwd, "
                                    "pn2_fea_extractor layer spec, BN training mode, Adam step", "scenes_per_gpu": SCENES_PER_GPU,
                        "schedule": "geometry inline" if args.no_overlap else (("geometry of batches k+2, k+3 submitted together every other step on two side streams under the layers of batches k, k+1"
@@ -456,12 +485,15 @@ def main():
         }
         if coll is not None:
             res["collective"] = coll
-        if world == 1 and not LAYERS_ONLY and not args.no_extra:
+        if world == 1 and not LAYERS_ONLY and (not args.no_extra or args.kind_leg):
             torch.cuda.synchronize()
             try:
                 res["roofline_ball_query"] = ball_query_roofline(bq_prof, batches, G if use_graph else None)
             except Exception as e:                                  # the extra legs never take the headline line down with them
                 res["roofline_ball_query"] = {"error": repr(e)}
+        if world == 1 and not LAYERS_ONLY and not args.no_extra and not args.kind_leg:
+            # the same step on the other cloud kinds of SURVEY 8(d) (north_star names ScanNet scenes): short runs in child processes
+            res["data_kinds"] = data_kinds_legs(res)
             # The remaining legs (per-kernel rooflines of the layers and of the stand-alone ops, the other configs, the reference's own
             # harness shapes) run in a CHILD process: whatever happens there -- an exception, a crash, a hang -- the headline line above
             # is printed.  (r03: a graph capture inside one of these legs segfaulted and the run printed nothing at all.)
@@ -474,6 +506,31 @@ def main():
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+
+
+def data_kinds_legs(res_u, kinds=("S", "D"), timeout=600):
+    """U / S / D side by side: step time, FPS of SA level 1 (us per pick), ball query per SA level (sum_visited, time).  The headline kind's
+    figures are copied from this run's own line; the others come from `bench.py --data K --kind-leg` children (40 timed steps)."""
+    import subprocess
+
+    def pick(r):
+        bq = r.get("roofline_ball_query", {})
+        return {"ms_per_step": r["ms_per_step"], "scenes_per_s": r["value"], "steps": r["steps"],
+                "fps_sa1": {k: r["roofline"].get(k) for k in ("avg_launch_ms", "us_per_pick", "frac")},
+                "ball_query": [{k: lv.get(k) for k in ("level", "radius", "avg_launch_ms", "sum_visited", "upper_bound_bytes", "algorithmic_bytes_per_launch", "frac", "kernel")}
+                               for lv in bq.get("levels", [])] if isinstance(bq, dict) else bq}
+    out = {DATA_KIND: pick(res_u)}
+    for k in kinds:
+        if k == DATA_KIND:
+            continue
+        cmd = [sys.executable, os.path.abspath(__file__), "--data", k, "--kind-leg", "--no-cpu-baseline", "--steps", "40", "--warmup", "5"]
+        try:
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+            lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            out[k] = pick(json.loads(lines[-1])) if (r.returncode == 0 and lines) else {"error": "child exited with code %d" % r.returncode, "stderr_tail": r.stderr[-400:]}
+        except Exception as e:
+            out[k] = {"error": repr(e)}
+    return out
 
 
 def run_legs_in_child(args, timeout=900):

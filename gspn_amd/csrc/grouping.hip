@@ -27,7 +27,9 @@
 #define BQ_WAVES 4
 #define BQ_UNROLL 4
 
-__global__ __launch_bounds__(BQ_WAVES * 64) void ball_query_kernel(int b, int n, int m, float thresh, int nsample,
+// n_scan < n: only the first n_scan data points are scanned here; a query that has not found nsample points by then is left OPEN --
+// its hits so far in row[0 .. cnt), cnt (< nsample) in pts_cnt, no padding -- for ball_query_cont_kernel to resume at n_scan.
+__global__ __launch_bounds__(BQ_WAVES * 64) void ball_query_kernel(int b, int n, int m, int n_scan, float thresh, int nsample,
                                                                   const float* __restrict__ xyz1, const float* __restrict__ xyz2,
                                                                   int* __restrict__ idx, int* __restrict__ pts_cnt) {
     const int lane = threadIdx.x & 63;
@@ -42,13 +44,13 @@ __global__ __launch_bounds__(BQ_WAVES * 64) void ball_query_kernel(int b, int n,
     const float qx = qp[0], qy = qp[1], qz = qp[2];
 
     int cnt = 0, first = 0;
-    for (int base = 0; base < n && cnt < nsample; base += 64 * BQ_UNROLL) {
+    for (int base = 0; base < n_scan && cnt < nsample; base += 64 * BQ_UNROLL) {
         float s[BQ_UNROLL];
 #pragma unroll
         for (int u = 0; u < BQ_UNROLL; ++u) {
             const int k = base + u * 64 + lane;
             float px = 0.f, py = 0.f, pz = 0.f;
-            if (k < n) {
+            if (k < n_scan) {
                 px = data[k * 3 + 0];
                 py = data[k * 3 + 1];
                 pz = data[k * 3 + 2];
@@ -58,7 +60,7 @@ __global__ __launch_bounds__(BQ_WAVES * 64) void ball_query_kernel(int b, int n,
 #pragma unroll
         for (int u = 0; u < BQ_UNROLL; ++u) {
             const int k = base + u * 64 + lane;
-            const bool hit = (k < n) && (s[u] < thresh);
+            const bool hit = (k < n_scan) && (s[u] < thresh);
             const unsigned long long mask = __ballot(hit);
             if (mask != 0ull && cnt < nsample) {
                 if (cnt == 0) first = base + u * 64 + __builtin_ctzll(mask);
@@ -69,9 +71,132 @@ __global__ __launch_bounds__(BQ_WAVES * 64) void ball_query_kernel(int b, int n,
         }
     }
     cnt = cnt < nsample ? cnt : nsample;
+    if (n_scan < n && cnt < nsample) {                           // open: the continuation kernel pads and finishes it
+        if (lane == 0) pts_cnt[(size_t)scene * m + j] = cnt;
+        return;
+    }
     // :29-32 -- unfilled slots repeat the first hit; rows without a hit are zero-filled
     for (int l = cnt + lane; l < nsample; l += 64) row[l] = first;
     if (lane == 0) pts_cnt[(size_t)scene * m + j] = cnt;         // :37
+}
+
+// The rest of the scan for the queries the prefix left open -- the regime of sparse clouds: on SURVEY 8(d)'s room scenes a 0.2 m ball
+// around a centre on a wall holds fewer than nsample points, so the reference's scan (and a wave per query re-reading the scene from
+// L2: 225 us at 8 x 32768 <- 2048) runs to the end of the cloud for 57 % of the queries.  Here a wave owns BQM_QW queries (their
+// coordinates, counts and first hits one per lane, fetched with v_readlane) and walks the cloud in steps of 512 points, 8 per lane
+// (six 16-byte loads of the AoS cloud, the next step in flight): 3 readlanes + 56 vector instructions per (query, 512 points), the
+// cloud read once per BQM_QW queries.  Hits are appended in ascending k exactly as the serial scan appends them (eight ballots give
+// every hit its slot).  A wave whose queries are all complete -- every wave, on dense clouds -- leaves after one load.
+// Measured (tools/ball_bench.py, 8 x 32768 <- 2048, r = 0.2): S 225 -> 170 us, U 25.9 -> 28.2 us with the 8192-point prefix.  What was
+// tried on the way (r04): tiles of 1024 points staged in LDS for 64 queries of a workgroup -- 4.6 us per tile of load latency + two
+// barriers that nothing hides (129 us with the tests compiled out); 8 or 16 queries per wave -- a wave issues one instruction per ~5
+// cycles, so the serial chain of its queries sets the time (16: 205 us, 8: 167, 4: 156 with a 4096-point prefix).
+#ifndef BQM_WAVES
+#define BQM_WAVES 4
+#endif
+#ifndef BQM_QW
+#define BQM_QW 4
+#endif
+__global__ __launch_bounds__(BQM_WAVES * 64) void ball_query_cont_kernel(int b, int n, int m, int n0, float thresh, int nsample,
+                                                                        const float* __restrict__ xyz1, const float* __restrict__ xyz2,
+                                                                        int* __restrict__ idx, int* __restrict__ pts_cnt) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int scene = blockIdx.x % b;
+    const int j0 = ((blockIdx.x / b) * BQM_WAVES + wave) * BQM_QW;
+    const float* data = xyz1 + (size_t)scene * n * 3;
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    int cnt = nsample, first = 0;
+    if (lane < BQM_QW && j0 + lane < m) {
+        const size_t qi = (size_t)scene * m + j0 + lane;
+        qx = xyz2[qi * 3 + 0]; qy = xyz2[qi * 3 + 1]; qz = xyz2[qi * 3 + 2];
+        cnt = pts_cnt[qi];
+        if (cnt > 0 && cnt < nsample) first = idx[qi * nsample];
+    }
+    const unsigned open0 = (unsigned)__ballot(lane < BQM_QW && cnt < nsample);
+    unsigned live = open0;
+    if (open0 == 0u) return;                                      // nothing open in this wave: the usual case on dense clouds
+    // a lane's 4 consecutive points of a 256-point sub-tile are 48 consecutive bytes of the AoS cloud: three 16-byte loads when the scene
+    // starts on a 16-byte boundary (n % 4 == 0 or scene 0), twelve 4-byte loads otherwise; the next sub-tile is in flight while this one
+    // is tested.  No LDS, no barrier: the waves drift apart instead of hammering the same cache lines in step.
+    const bool vec = (((uintptr_t)data) & 15) == 0;
+    // a step = 512 points: lane l holds points k0 + 4l .. + 3 (chunk 0) and k0 + 256 + 4l .. + 3 (chunk 1); the next step's 24 floats
+    // are in flight while this step is tested (a wave's steps are a serial chain: 56 of them for 28672 points)
+    float4 nb[2][3];                                              // per chunk the 12 floats as they lie in memory: (x0 y0 z0 x1) (y1 z1 x2 y2) (z2 x3 y3 z3)
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+            const int k = k0 + 256 * ch + 4 * lane;
+            if (vec && k + 3 < n) {
+                const float4* p = reinterpret_cast<const float4*>(data + (size_t)k * 3);
+                nb[ch][0] = p[0]; nb[ch][1] = p[1]; nb[ch][2] = p[2];
+            } else {
+                float v[12];
+#pragma unroll
+                for (int e = 0; e < 12; ++e) v[e] = (k + e / 3 < n) ? data[(size_t)k * 3 + e] : INFINITY;      // (a point at infinity is never a hit)
+                nb[ch][0] = make_float4(v[0], v[1], v[2], v[3]); nb[ch][1] = make_float4(v[4], v[5], v[6], v[7]); nb[ch][2] = make_float4(v[8], v[9], v[10], v[11]);
+            }
+        }
+    };
+    fetch(n0);
+    for (int base = n0; base < n && live != 0u; base += 512) {
+        float4 px[2], py[2], pz[2];
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+            px[ch] = make_float4(nb[ch][0].x, nb[ch][0].w, nb[ch][1].z, nb[ch][2].y);
+            py[ch] = make_float4(nb[ch][0].y, nb[ch][1].x, nb[ch][1].w, nb[ch][2].z);
+            pz[ch] = make_float4(nb[ch][0].z, nb[ch][1].y, nb[ch][2].x, nb[ch][2].w);
+        }
+        if (base + 512 < n) fetch(base + 512);
+        for (unsigned mk = live; mk != 0u; mk &= mk - 1u) {
+            const int q = __builtin_ctz(mk);
+            const float ax = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qx), q)), ay = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qy), q)),
+                        az = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qz), q));
+            bool h[2][4];
+            unsigned long long mm[2][4];
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch) {
+                h[ch][0] = dist2_cuda(ax - px[ch].x, ay - py[ch].x, az - pz[ch].x) < thresh;       // (x2-x1): query minus data, :27
+                h[ch][1] = dist2_cuda(ax - px[ch].y, ay - py[ch].y, az - pz[ch].y) < thresh;
+                h[ch][2] = dist2_cuda(ax - px[ch].z, ay - py[ch].z, az - pz[ch].z) < thresh;
+                h[ch][3] = dist2_cuda(ax - px[ch].w, ay - py[ch].w, az - pz[ch].w) < thresh;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) mm[ch][u] = __ballot(h[ch][u]);
+            }
+            const unsigned long long any0 = (mm[0][0] | mm[0][1]) | (mm[0][2] | mm[0][3]), any1 = (mm[1][0] | mm[1][1]) | (mm[1][2] | mm[1][3]);
+            if ((any0 | any1) == 0ull) continue;
+            int c = __builtin_amdgcn_readlane(cnt, q);
+            int* row = idx + ((size_t)scene * m + j0 + q) * nsample;
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch) {                      // chunk 0's points all precede chunk 1's
+                const unsigned long long any = ch == 0 ? any0 : any1;
+                if (any == 0ull) continue;
+                const int kb = base + 256 * ch + 4 * lane;
+                int pos = c;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) pos += __builtin_amdgcn_mbcnt_hi((unsigned)(mm[ch][u] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mm[ch][u], 0u));
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (h[ch][u]) { if (pos < nsample) row[pos] = kb + u; ++pos; }          // :33, ascending k
+                if (c == 0) {
+                    const int fl = __builtin_ctzll(any);
+                    const int u0 = ((mm[ch][0] >> fl) & 1ull) ? 0 : (((mm[ch][1] >> fl) & 1ull) ? 1 : (((mm[ch][2] >> fl) & 1ull) ? 2 : 3));
+                    if (lane == q) first = base + 256 * ch + 4 * fl + u0;
+                }
+                c += __builtin_popcountll(mm[ch][0]) + __builtin_popcountll(mm[ch][1]) + __builtin_popcountll(mm[ch][2]) + __builtin_popcountll(mm[ch][3]);
+            }
+            if (lane == q) cnt = c;
+            if (c >= nsample) live &= ~(1u << q);
+        }
+    }
+    for (unsigned mk = open0; mk != 0u; mk &= mk - 1u) {
+        const int q = __builtin_ctz(mk);
+        int c = __builtin_amdgcn_readlane(cnt, q);
+        c = c < nsample ? c : nsample;
+        const int f = __builtin_amdgcn_readlane(first, q);
+        int* row = idx + ((size_t)scene * m + j0 + q) * nsample;
+        for (int l = c + lane; l < nsample; l += 64) row[l] = f;   // :29-32
+        if (lane == 0) pts_cnt[(size_t)scene * m + j0 + q] = c;    // :37
+    }
 }
 
 static float ball_threshold(float radius) {
@@ -166,8 +291,18 @@ extern "C" int gspn_queryballpoint(int b, int n, int m, float radius, int nsampl
     if (b == 0 || m == 0) return 0;
     const long long blocks = (long long)b * ((m + BQ_WAVES - 1) / BQ_WAVES);
     if (blocks > 0x7FFFFFFFll || (long long)n * 3 > 0x7FFFFFFFll) return GSPN_ERR_UNSUPPORTED;
+    // clouds longer than the prefix: wave-per-query scan of the first BQ_PREFIX points (all of a dense cloud's queries end there), then
+    // the register-blocked continuation for whatever is still open (GSPN_BALL_PREFIX=0: one pass over the whole cloud, round 3's form)
+    static const int prefix = getenv("GSPN_BALL_PREFIX") ? atoi(getenv("GSPN_BALL_PREFIX")) : 8192;
+    const int n_scan = (prefix > 0 && n > prefix) ? (prefix + 255) / 256 * 256 : n;
     hipLaunchKernelGGL(ball_query_kernel, dim3((unsigned)blocks), dim3(BQ_WAVES * 64), 0, (hipStream_t)stream,
-                       b, n, m, ball_threshold(radius), nsample, xyz1, xyz2, idx, pts_cnt);
+                       b, n, m, n_scan, ball_threshold(radius), nsample, xyz1, xyz2, idx, pts_cnt);
+    if (n_scan < n) {
+        const int per_wg = BQM_WAVES * BQM_QW;
+        const long long cblocks = (long long)b * ((m + per_wg - 1) / per_wg);
+        hipLaunchKernelGGL(ball_query_cont_kernel, dim3((unsigned)cblocks), dim3(BQM_WAVES * 64), 0, (hipStream_t)stream,
+                           b, n, m, n_scan, ball_threshold(radius), nsample, xyz1, xyz2, idx, pts_cnt);
+    }
     return gspn_launch_status();
 }
 
@@ -568,7 +703,7 @@ __global__ __launch_bounds__(1024) void csr_build_lds_kernel(int L, int n, const
 // one WAVE per value: rank sort of its group (the positions are distinct, so rank = number of smaller entries), tmp -> order.
 // Groups of up to 64 entries (the usual case: a handful to a few dozen) never touch memory again -- one entry per lane, compared through
 // v_readlane; longer groups count against the group re-read from L2.
-__global__ __launch_bounds__(256) void csr_sort_kernel(long nwaves, int L, int n, const int* __restrict__ offsets, const int* __restrict__ tmp,
+__global__ __launch_bounds__(256) void csr_sort_kernel(long nwaves, int L, int n, const int* __restrict__ offsets, int* __restrict__ tmp,
                                                        int* __restrict__ order) {
     const int lane = threadIdx.x & 63;
     const long w = blockIdx.x * 4L + (threadIdx.x >> 6);
@@ -587,12 +722,53 @@ __global__ __launch_bounds__(256) void csr_sort_kernel(long nwaves, int L, int n
         if (lane < cnt) dst[rank] = v;
         return;
     }
-    for (int i = lane; i < cnt; i += 64) {
-        const int v = src[i];
-        int rank = 0;
-        for (int j = 0; j < cnt; ++j) rank += (src[j] < v) ? 1 : 0;
-        dst[rank] = v;
+    // Longer groups (clustered clouds: a sparse point that is the nearest neighbour of thousands of dense points -- on SURVEY 8d's room
+    // scenes one group in ten is longer than 64 and the longest hold a few thousand positions; round 3's count-the-smaller-entries
+    // loop was quadratic there: 420 us per launch): a stable LSD radix sort by the wave, 6 bits per pass.  The 64 bins of a pass live
+    // in LDS, one per lane; a tile's 64 entries find their stable rank among the entries with the same digit with six ballots (no
+    // loop over digits), so a pass costs ~40 instructions per 64 entries.  The passes ping-pong between the two buffers the caller
+    // already provides (tmp and order); an even number of passes ends with a copy.
+    __shared__ int s_bins[4][64];
+    int* bins = s_bins[threadIdx.x >> 6];
+    int* bufA = const_cast<int*>(src);
+    int* bufB = dst;
+    const int nbits = 32 - __builtin_clz((unsigned)(L > 1 ? L - 1 : 1));
+    const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    for (int shift = 0; shift < nbits; shift += 6) {
+        bins[lane] = 0;
+        for (int i0 = 0; i0 < cnt; i0 += 64) {
+            const int i = i0 + lane;
+            if (i < cnt) atomicAdd(&bins[(bufA[i] >> shift) & 63], 1);
+        }
+        // exclusive scan of the 64 bins (one per lane)
+        const int c = bins[lane];
+        int incl = c;
+#pragma unroll
+        for (int sft = 1; sft < 64; sft <<= 1) { const int u = __shfl_up(incl, sft, 64); if (lane >= sft) incl += u; }
+        bins[lane] = incl - c;
+        for (int i0 = 0; i0 < cnt; i0 += 64) {
+            const int i = i0 + lane;
+            const bool valid = i < cnt;
+            const int v = valid ? bufA[i] : 0;
+            const int d = (v >> shift) & 63;
+            unsigned long long eq = __ballot(valid);
+#pragma unroll
+            for (int bit = 0; bit < 6; ++bit) {
+                const unsigned long long m = __ballot((d >> bit) & 1);
+                eq &= ((d >> bit) & 1) ? m : ~m;
+            }
+            if (valid) {
+                const int base = bins[d];
+                const int rank = __builtin_popcountll(eq & lt);
+                bufB[base + rank] = v;
+                if ((eq >> lane) == 1ull) bins[d] = base + __builtin_popcountll(eq);      // the highest lane of the digit moves its cursor on
+            }
+        }
+        __threadfence_block();                        // this pass's stores are complete before other lanes of the wave read them back
+        int* t = bufA; bufA = bufB; bufB = t;
     }
+    if (bufA != dst)                                                                      // (bufA holds the sorted group after the last swap)
+        for (int i = lane; i < cnt; i += 64) dst[i] = bufA[i];
 }
 // work: b*n ints (counts, then cursors) followed by b*L ints (the unsorted groups)
 extern "C" long gspn_inverse_lists_work_ints(int b, int L, int n) {

@@ -263,3 +263,53 @@ def test_config5_scene_size_through_the_extractor():
     assert torch.isfinite(runs[0][0]).all() and torch.equal(runs[0][0], runs[1][0])
     for nm, g in runs[0][1].items():
         assert torch.isfinite(g).all() and torch.equal(g, runs[1][1][nm]), nm
+
+
+# ---- the clustered regime (SURVEY 8d's S clouds: room surfaces at metre scale, what north_star's "ScanNet scenes" look like) ----
+@pytest.fixture(scope="module")
+def rooms():
+    xyz = D.batch("S", B, N)
+    return xyz, torch.from_numpy(xyz).cuda()
+
+
+def test_ball_query_sparse_regime_continuation_index_exact(rooms):
+    """r04: on room scenes most balls hold fewer than nsample points, the reference's scan runs to the end of the cloud and the prefix
+    kernel hands the open queries to ball_query_cont_kernel (grouping.hip) -- index-exact against the oracle, counts included, at the
+    model's three radii (model_rpointnet.py:224-231), and with a prefix that ends inside the cloud at every level"""
+    from gspn_amd.tf_grouping import query_ball_point
+    from gspn_amd.tf_sampling import farthest_point_sample, gather_point
+    xyz, t = rooms
+    cur_np, cur = xyz, t
+    for m, radius in ((2048, 0.2), (512, 0.4), (128, 0.8)):
+        new_xyz = gather_point(cur, farthest_point_sample(m, cur))
+        idx, cnt = query_ball_point(radius, 32, cur, new_xyz)
+        ridx, rcnt = O.query_ball_point(radius, 32, cur_np, new_xyz.cpu().numpy(), mt=True)
+        np.testing.assert_array_equal(cnt.cpu().numpy(), rcnt)
+        np.testing.assert_array_equal(idx.cpu().numpy(), ridx)
+        if m == 2048:
+            assert float((cnt < 32).float().mean()) > 0.3          # the regime this test is about: open queries that scan all n points
+        cur_np, cur = new_xyz.cpu().numpy(), new_xyz
+
+
+def test_inverse_lists_long_groups_on_clustered_clouds(rooms):
+    """r04: a sparse point inside a dense cluster is the nearest neighbour of thousands of dense points -- groups far longer than a wave
+    take csr_sort_kernel's radix path (round 3's quadratic loop needed 420 us per launch here); result = stable argsort + bincount"""
+    from gspn_amd.fea_extractor import pn2_geometry
+    from gspn_amd.geometry import inverse_lists
+    _, t = rooms
+    G = pn2_geometry(t)
+    idx2d = G["fp"][2].idx.reshape(B, -1)
+    n = 2048
+    order, offsets = inverse_lists(idx2d, n)
+    cnt = torch.stack([torch.bincount(idx2d[s].long(), minlength=n) for s in range(B)])
+    assert int(cnt.max()) > 256                                     # long groups exist (1291 on these seeds)
+    ref = torch.argsort(idx2d.long(), dim=1, stable=True).int()
+    off_ref = torch.cat([torch.zeros(B, 1, dtype=torch.long, device=t.device), cnt.cumsum(1)], 1).int()
+    assert torch.equal(order, ref) and torch.equal(offsets, off_ref)
+    # an adversarial case: every position of a scene in ONE group, and two groups split down the middle
+    L = 5000
+    one = torch.zeros(2, L, dtype=torch.int32, device=t.device)
+    one[1, L // 2:] = 7
+    order, offsets = inverse_lists(one, 16)
+    assert torch.equal(order, torch.arange(L, dtype=torch.int32, device=t.device).repeat(2, 1))
+    assert offsets[0].tolist() == [0] + [L] * 16 and offsets[1].tolist() == [0] + [L // 2] * 7 + [L] * 9

@@ -1,24 +1,27 @@
-"""ball query: wave-per-query over the L2-resident scene (default) vs LDS-staged tiles shared by a workgroup; same output required"""
+"""ball query: wave-per-query over the L2-resident scene vs LDS-staged tiles shared by a workgroup, on U / S / D clouds at the
+model's radii (model_rpointnet.py:224-231); same output required.  Graph-timed (20 launches between two HIP events)."""
 import sys, numpy as np, torch
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import bench
 from gspn_amd import _lib as L
+from gspn_amd import synth
 from gspn_amd.tf_sampling import farthest_point_sample, gather_point
 lib = L.lib()
-for (n, m, r, ns) in [(32768, 2048, 0.2, 32), (32768, 1024, 0.1, 32), (2048, 512, 0.4, 32), (32768, 256, 1.5, 512)]:
-    xyz_np, _ = bench.synth(8, n, 0)
-    xyz = torch.from_numpy(xyz_np).cuda()
-    q = gather_point(xyz, farthest_point_sample(m, xyz))
-    out = []
-    for name, fn in (("l2-wave", lib.gspn_queryballpoint), ("lds-tile", lib.gspn_queryballpoint_lds)):
-        idx = torch.empty(8, m, ns, dtype=torch.int32, device="cuda"); cnt = torch.empty(8, m, dtype=torch.int32, device="cuda")
-        run = lambda: L.check(fn(8, n, m, r, ns, L.ptr(xyz), L.ptr(q), L.ptr(idx), L.ptr(cnt), L.stream()), name)
-        for _ in range(3): run()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(20): run()
-        e1.record(); torch.cuda.synchronize()
-        out.append((name, e0.elapsed_time(e1) / 20 * 1e3, idx.clone(), cnt.clone()))
-    same = torch.equal(out[0][2], out[1][2]) and torch.equal(out[0][3], out[1][3])
-    print("n=%d m=%d r=%.2f ns=%d : %s %.1f us | %s %.1f us | identical %s" % (n, m, r, ns, out[0][0], out[0][1], out[1][0], out[1][1], same), flush=True)
+kinds = sys.argv[1:] or ["U", "S", "D"]
+for kind in kinds:
+    xyz = torch.from_numpy(synth.batch(kind, 8, 32768, 0)).cuda()
+    cur = xyz
+    for (m, r, ns) in [(2048, 0.2, 32), (512, 0.4, 32), (128, 0.8, 32)]:
+        n = cur.shape[1]
+        q = gather_point(cur, farthest_point_sample(m, cur))
+        out = []
+        for name, fn in (("l2-wave", lib.gspn_queryballpoint), ("lds-tile", lib.gspn_queryballpoint_lds)) + ((("auto", lib.gspn_queryballpoint_auto),) if hasattr(lib, "gspn_queryballpoint_auto") else ()):
+            idx = torch.empty(8, m, ns, dtype=torch.int32, device="cuda"); cnt = torch.empty(8, m, dtype=torch.int32, device="cuda")
+            run = lambda: L.check(fn(8, n, m, r, ns, L.ptr(cur), L.ptr(q), L.ptr(idx), L.ptr(cnt), L.stream()), name)
+            us = bench._ev_time(run) * 1e3
+            out.append((name, us, idx.clone(), cnt.clone()))
+        same = all(torch.equal(out[0][2], o[2]) and torch.equal(out[0][3], o[3]) for o in out[1:])
+        full = float((out[0][3] < ns).float().mean())
+        print("%s n=%5d m=%4d r=%.1f ns=%d (%.0f%% of the queries find < ns points: full scan) : %s | identical %s" % (
+            kind, n, m, r, ns, 100 * full, "  ".join("%s %.1f us" % (o[0], o[1]) for o in out), same), flush=True)
+        cur = q
