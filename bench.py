@@ -714,9 +714,9 @@ def _ev_time(fn, warm=3, reps=20):
 def _pmc_ops():
     """memory-side bytes per launch of the stand-alone ops (tools/pmc_ops.sh -> profiles/r03_ops_pmc.json: separate --pmc FETCH_SIZE /
     WRITE_SIZE passes over tools/ops_only.py, FETCH_SIZE doubled per MI355X_MICROARCH.md), keyed like the entries below"""
-    q = os.path.join(ROOT, "profiles", "r03_ops_pmc.json")
+    q = next((f for f in (os.path.join(ROOT, "profiles", n_) for n_ in ("r04_ops_pmc.json", "r03_ops_pmc.json")) if os.path.exists(f)), None)
     try:
-        return json.load(open(q)).get("ops", {}) if os.path.exists(q) else {}
+        return json.load(open(q)).get("ops", {}) if q else {}
     except Exception:
         return {}
 
@@ -728,6 +728,7 @@ def ops_roofline(xyz, geo, dev, timer=None):
     calls replayed from a hipGraph on an idle chip) -- an EFFECTIVE rate: these working sets (<= 134 MB, mostly <= 4 MB) live in L2 / Infinity Cache, so the
     fraction of the 8 TB/s HBM peak can exceed what HBM could deliver; `traffic` is the PMC memory-side byte count per launch and
     `bound_by` names what actually limits the kernel."""
+    from gspn_amd.invlists import inverse_lists
     from gspn_amd.pointnet_util import fp_concat
     from gspn_amd.tf_grouping import group_point
     from gspn_amd.tf_interpolate import three_interpolate, three_nn
@@ -768,9 +769,18 @@ def ops_roofline(xyz, geo, dev, timer=None):
         add("three_interpolate", "%dx%d<-%d, c=%d" % (b, n, m, c2), 1.0 * b * n * (24 + 16 * c2), lambda: three_interpolate(p2, fpg.idx, fpg.weight),
             "memory: one coalesced (n, c) write, three L2-resident row reads per point", "three_interpolate_%d" % n)
         gp2 = torch.empty_like(p2)
-        add("three_interpolate_grad", "%dx%d->%d, c=%d (scatter-add, hardware fp32 atomics)" % (b, n, m, c2), 1.0 * b * n * (24 + 16 * c2),
+        # the op API's gradient (tf_interpolate.py, r04): a gather through the inverse lists of idx (cached on the index tensor), sums in the
+        # reference's own order, bit-exact vs oracle/_ref; the lists' one-off build is its own entry below
+        add("three_interpolate_grad (op API: gather over cached inverse lists)", "%dx%d->%d, c=%d" % (b, n, m, c2), 1.0 * b * n * (24 + 16 * c2),
+            lambda: L.check(lib.gspn_fp_concat_grad_csr(b, n, m, c2, 0, c2, L.ptr(go), L.ptr(fpg.order), L.ptr(fpg.offsets), L.ptr(fpg.weight), L.ptr(gp2), None,
+                                                        L.stream()), "three_interpolate_grad(csr)"),
+            "dependent-load latency of the inverse-list walk (16 lanes per sparse point, 8 rows in flight)", "three_interpolate_grad_csr_%d" % n)
+        add("three_interpolate_grad (C-ABI drop-in symbol: scatter-add, hardware fp32 atomics)", "%dx%d->%d, c=%d" % (b, n, m, c2), 1.0 * b * n * (24 + 16 * c2),
             lambda: L.check(lib.gspn_threeinterpolate_grad(b, n, c2, m, L.ptr(go), L.ptr(fpg.idx), L.ptr(fpg.weight), L.ptr(gp2), L.stream()), "three_interpolate_grad"),
             "L2 atomic throughput: 3*c atomic adds per dense point onto m*c addresses", "three_interpolate_grad_%d" % n)
+        idx2d = fpg.idx.reshape(b, 3 * n)
+        add("inverse_lists (once per index tensor)", "%d x %d positions -> %d lists" % (b, 3 * n, m), 1.0 * b * (3 * n * 12 + 4 * m),
+            lambda: inverse_lists(idx2d, m), "one workgroup per scene (LDS histogram + cursors), then a per-list sort", "inverse_lists_%d" % n)
         ld2 = (c2 + c1 + 3) // 4 * 4
         g2 = torch.randn(b * n, ld2, device=dev, generator=gen)
         add("fp_concat (interpolate + concat, fused)", "%dx%d<-%d, c2=%d c1=%d" % (b, n, m, c2, c1), 1.0 * b * n * (24 + 16 * c2 + 8 * c1), lambda: fp_concat(p2, fpg.idx, fpg.weight, p1, fpg.order, fpg.offsets),
@@ -789,7 +799,11 @@ def ops_roofline(xyz, geo, dev, timer=None):
             "memory: the (m, ns, c) write; gathered rows are L2 hits" if c >= 64 else "write coalescing: 12-byte rows", "group_point_%d" % n)
         go = torch.randn(b, m, ns, c, device=dev, generator=gen)
         gpts = torch.empty(b, n, c, device=dev)
-        add("group_point_grad", "(%d,%d) -> %dx%d, c=%d (scatter-add, hardware fp32 atomics)" % (m, ns, b, n, c), 1.0 * b * m * ns * (4 + 8 * c),
+        sord, soff = (sa.order, sa.offsets) if sa.order is not None else inverse_lists(sa.idx.reshape(b, m * ns), n)
+        add("group_point_grad (op API: gather over cached inverse lists)", "(%d,%d) -> %dx%d, c=%d" % (m, ns, b, n, c), 1.0 * b * m * ns * (4 + 8 * c),
+            lambda: L.check(lib.gspn_sa_group_concat_grad_csr(b, n, c, m, ns, L.ptr(sord), L.ptr(soff), 0, c, L.ptr(go), L.ptr(gpts), L.stream()), "group_point_grad(csr)"),
+            "dependent-load latency of the inverse-list walk; every gradient row read once", "group_point_grad_csr_%d" % n)
+        add("group_point_grad (C-ABI drop-in symbol: scatter-add, hardware fp32 atomics)", "(%d,%d) -> %dx%d, c=%d" % (m, ns, b, n, c), 1.0 * b * m * ns * (4 + 8 * c),
             lambda: L.check(lib.gspn_grouppoint_grad(b, n, c, m, ns, L.ptr(go), L.ptr(sa.idx), L.ptr(gpts), L.stream()), "group_point_grad"),
             "L2 atomic throughput", "group_point_grad_%d" % n)
     fidx = geo["sa"][0].idx[:, :, 0].contiguous()

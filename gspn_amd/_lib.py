@@ -67,6 +67,7 @@ SIGNATURES = {
     "gspn_fp_concat_grad_csr": [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     "gspn_nmdistance": [_I, _I, _P, _I, _P, _P, _P, _P, _P, _P],
     "gspn_nmdistance_grad": [_I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P],
+    "gspn_nmdistance_grad_csr": [_I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "gspn_sa_group_concat": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P],
     "gspn_pad_rows": [_L, _I, _I, _P, _P, _P],
     "gspn_sa_group_concat_grad": [_I, _I, _I, _I, _I, _P, _I, _I, _P, _P, _P],
@@ -125,7 +126,7 @@ SPECIAL = {
     "gspn_inverse_lists_work_ints": ([_I, _I, _I], _L),
 }
 
-ABI_VERSION = 6         # == GSPN_ABI_VERSION of include/gspn_hip.h this binding was written against
+ABI_VERSION = 7         # == GSPN_ABI_VERSION of include/gspn_hip.h this binding was written against
 
 _lib = None
 

@@ -34,6 +34,9 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
+#ifndef GSPN_CSR_U1
+#define GSPN_CSR_U1 8
+#endif
 struct CsrCopy {                      // the skip-link columns of fp_concat's gradient are a plain slice of grad_out: trailing workgroups copy it
     const float* g; float* dst; int ld, c0, c1; long total;
 };
@@ -43,7 +46,7 @@ __global__ __launch_bounds__(256) void csr_gather16_kernel(int nt, int L, long s
                                                            const int* __restrict__ order, const int* __restrict__ offsets,
                                                            const float* __restrict__ weight, float* __restrict__ out, long ntot, long part,
                                                            unsigned gather_blocks, CsrCopy cp) {
-    constexpr int U = CPL == 1 ? 8 : (CPL == 2 ? 4 : 2);          // list entries whose row loads are issued together (8 float4 per lane in flight)
+    constexpr int U = CPL == 1 ? GSPN_CSR_U1 : (CPL == 2 ? GSPN_CSR_U1 / 2 : GSPN_CSR_U1 / 4);          // list entries whose row loads are issued together
     if (blockIdx.x >= gather_blocks) {
         const long nthreads = (long)(gridDim.x - gather_blocks) * 256;
         for (long i = (long)(blockIdx.x - gather_blocks) * 256 + threadIdx.x; i < cp.total; i += nthreads) {

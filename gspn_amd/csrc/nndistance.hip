@@ -152,3 +152,64 @@ extern "C" int gspn_nmdistance_grad(int b, int n, const float* xyz1, int m, cons
     hipLaunchKernelGGL(nm_distance_grad_kernel, dim3(grid_for(t2, 256)), dim3(256), 0, st, t2, m, xyz2, n, xyz1, grad_dist2, idx2, grad_xyz2, grad_xyz1);
     return gspn_launch_status();
 }
+
+// The same gradient as a GATHER, for clouds beyond the LDS kernel: the caller supplies the inverse lists of idx1 over cloud 2's points
+// (order1 (b, n): positions of idx1 sorted by value, ties ascending; offsets1 (b, m + 1)) and of idx2 over cloud 1's points (order2 (b, m),
+// offsets2 (b, n + 1)) -- gspn_inverse_lists.  One thread per point adds its terms in exactly the order of the reference's SEQUENTIAL CPU
+// twin (tf_nndistance.cpp:126-163: first the loop over cloud 1 -- own term of grad1, scatter into grad2 --, then the loop over cloud 2):
+//   grad1[i] = own1(i), then  -= t2(j) for the j with idx2[j] == i, ascending j;     grad2[j] = -t1(i) for the i with idx1[i] == j, ascending i, then += own2(j)
+// Bit-identical to the oracle's restatement of that loop; no memset, no atomics (the CUDA kernel's atomicAdd, tf_nndistance_g.cu:145-150, has no order).
+__global__ void nm_distance_grad_csr_kernel(long total1, long total, int n, const float* __restrict__ xyz1, int m, const float* __restrict__ xyz2,
+                                            const float* __restrict__ gd1, const int* __restrict__ idx1, const float* __restrict__ gd2,
+                                            const int* __restrict__ idx2, const int* __restrict__ order1, const int* __restrict__ offsets1,
+                                            const int* __restrict__ order2, const int* __restrict__ offsets2, float* __restrict__ grad1,
+                                            float* __restrict__ grad2) {
+    for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        if (t < total1) {                            // a point of cloud 1
+            const long c = t / n;
+            const int i = (int)(t - c * n);
+            const float* p1 = xyz1 + t * 3;
+            const float* q = xyz2 + ((size_t)c * m + idx1[t]) * 3;
+            const float g = gd1[t] * 2;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+            a0 += g * (p1[0] - q[0]); a1 += g * (p1[1] - q[1]); a2 += g * (p1[2] - q[2]);
+            const int* off = offsets2 + c * (n + 1);
+            for (int e = off[i]; e < off[i + 1]; ++e) {
+                const int j = order2[c * m + e];
+                const float* p2 = xyz2 + ((size_t)c * m + j) * 3;
+                const float h = gd2[c * m + j] * 2;
+                a0 -= h * (p2[0] - p1[0]); a1 -= h * (p2[1] - p1[1]); a2 -= h * (p2[2] - p1[2]);
+            }
+            grad1[t * 3 + 0] = a0; grad1[t * 3 + 1] = a1; grad1[t * 3 + 2] = a2;
+        } else {                                     // a point of cloud 2
+            const long u = t - total1;
+            const long c = u / m;
+            const int j = (int)(u - c * m);
+            const float* p2 = xyz2 + u * 3;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+            const int* off = offsets1 + c * (m + 1);
+            for (int e = off[j]; e < off[j + 1]; ++e) {
+                const int i = order1[c * n + e];
+                const float* p1 = xyz1 + ((size_t)c * n + i) * 3;
+                const float g = gd1[c * n + i] * 2;
+                a0 -= g * (p1[0] - p2[0]); a1 -= g * (p1[1] - p2[1]); a2 -= g * (p1[2] - p2[2]);
+            }
+            const float* q = xyz1 + ((size_t)c * n + idx2[u]) * 3;
+            const float h = gd2[u] * 2;
+            a0 += h * (p2[0] - q[0]); a1 += h * (p2[1] - q[1]); a2 += h * (p2[2] - q[2]);
+            grad2[u * 3 + 0] = a0; grad2[u * 3 + 1] = a1; grad2[u * 3 + 2] = a2;
+        }
+    }
+}
+extern "C" int gspn_nmdistance_grad_csr(int b, int n, const float* xyz1, int m, const float* xyz2, const float* grad_dist1, const int* idx1,
+                                        const float* grad_dist2, const int* idx2, const int* order1, const int* offsets1, const int* order2,
+                                        const int* offsets2, float* grad_xyz1, float* grad_xyz2, void* stream) {
+    if (b < 0 || n <= 0 || m <= 0) return GSPN_ERR_ARG;
+    if (b == 0) return 0;
+    if (!xyz1 || !xyz2 || !grad_dist1 || !idx1 || !grad_dist2 || !idx2 || !order1 || !offsets1 || !order2 || !offsets2 || !grad_xyz1 || !grad_xyz2) return GSPN_ERR_ARG;
+    const long t1 = (long)b * n, tot = t1 + (long)b * m;
+    hipLaunchKernelGGL(nm_distance_grad_csr_kernel, dim3(grid_for(tot, 256)), dim3(256), 0, (hipStream_t)stream, t1, tot, n, xyz1, m, xyz2, grad_dist1, idx1,
+                       grad_dist2, idx2, order1, offsets1, order2, offsets2, grad_xyz1, grad_xyz2);
+    return gspn_launch_status();
+}
+

@@ -18,6 +18,7 @@ import os
 import torch
 
 from . import _lib as L
+from .invlists import inverse_lists  # noqa: F401  (re-exported: tools and tests import it from here)
 from .tf_grouping import knn_point, query_ball_point
 from .tf_interpolate import three_nn
 from .tf_sampling import farthest_point_sample, gather_point
@@ -38,19 +39,6 @@ class SAGeometry:
 
     def tensors(self):
         return [t for t in (self.new_xyz, self.idx, self.pts_cnt, self.order, self.offsets, self.rel, self.gidx, self.scan_order) if t is not None]
-
-
-def inverse_lists(idx2d, n):
-    """idx2d (b, L) int32 with values in [0, n) -> order (b, L) int32 (positions sorted by value, ties ascending), offsets (b, n+1) int32
-    -- a stable sort + searchsorted, done by gspn_inverse_lists (count / scan / fill / per-value sort) in four small kernels."""
-    idx2d = L.need(idx2d, torch.int32, 2, "idx")
-    b, ln = idx2d.shape
-    order = torch.empty((b, ln), dtype=torch.int32, device=idx2d.device)
-    offsets = torch.empty((b, n + 1), dtype=torch.int32, device=idx2d.device)
-    work = torch.empty(int(L.lib().gspn_inverse_lists_work_ints(b, ln, int(n))), dtype=torch.int32, device=idx2d.device)
-    with torch.cuda.device(idx2d.device):
-        L.check(L.lib().gspn_inverse_lists(b, ln, int(n), L.ptr(idx2d), L.ptr(work), L.ptr(order), L.ptr(offsets), L.stream()), "inverse_lists")
-    return order, offsets
 
 
 class FPGeometry:

@@ -2,6 +2,7 @@
 import torch
 
 from . import _lib as L
+from . import invlists
 
 # bench.py sets this to a list to collect (start_event, end_event, b, n, m, radius, nsample) around every ball-query launch, recorded
 # on the stream the kernel is launched on
@@ -102,6 +103,7 @@ class _GroupPoint(torch.autograd.Function):
         with torch.cuda.device(points.device):
             L.check(L.lib().gspn_grouppoint(b, n, c, m, ns, L.ptr(points), L.ptr(idx), L.ptr(out), L.stream()), "group_point")
         ctx.save_for_backward(idx)
+        ctx.idx_obj = idx                    # the caller's tensor OBJECT: the inverse lists of the gradient are cached on it (invlists.py)
         ctx.n = n
         return out
 
@@ -114,7 +116,14 @@ class _GroupPoint(torch.autograd.Function):
         c = grad_out.shape[3]
         g = torch.empty((b, ctx.n, c), dtype=torch.float32, device=grad_out.device)
         with torch.cuda.device(grad_out.device):
-            L.check(L.lib().gspn_grouppoint_grad(b, ctx.n, c, m, ns, L.ptr(grad_out), L.ptr(idx), L.ptr(g), L.stream()), "group_point_grad")
+            if invlists.ATOMIC_GRADS or m * ns == 0:
+                L.check(L.lib().gspn_grouppoint_grad(b, ctx.n, c, m, ns, L.ptr(grad_out), L.ptr(idx), L.ptr(g), L.stream()), "group_point_grad")
+            else:
+                # a gather through the inverse lists of idx (fixed order: ascending grouped position; the reference's atomicAdd,
+                # tf_grouping_g.cu:66-83, defines none): no atomics, no zero fill, every gradient row read once
+                order, offsets = invlists.cached_inverse_lists(ctx.idx_obj if ctx.idx_obj._version == idx._version else idx, ctx.n)
+                L.check(L.lib().gspn_sa_group_concat_grad_csr(b, ctx.n, c, m, ns, L.ptr(order), L.ptr(offsets), 0, c, L.ptr(grad_out), L.ptr(g),
+                                                              L.stream()), "group_point_grad(csr)")
         return g, None
 
 

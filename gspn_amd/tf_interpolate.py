@@ -2,6 +2,7 @@
 import torch
 
 from . import _lib as L
+from . import invlists
 
 
 def three_nn(xyz1, xyz2, order=None):
@@ -40,6 +41,7 @@ class _ThreeInterpolate(torch.autograd.Function):
         with torch.cuda.device(points.device):
             L.check(L.lib().gspn_threeinterpolate(b, m, c, n, L.ptr(points), L.ptr(idx), L.ptr(weight), L.ptr(out), L.stream()), "three_interpolate")
         ctx.save_for_backward(idx, weight)
+        ctx.idx_obj = idx                    # the caller's tensor OBJECT: the inverse lists of the gradient are cached on it (invlists.py)
         ctx.m = m
         return out
 
@@ -51,8 +53,15 @@ class _ThreeInterpolate(torch.autograd.Function):
         b, n, c = grad_out.shape
         g = torch.empty((b, ctx.m, c), dtype=torch.float32, device=grad_out.device)
         with torch.cuda.device(grad_out.device):
-            L.check(L.lib().gspn_threeinterpolate_grad(b, n, c, ctx.m, L.ptr(grad_out), L.ptr(idx), L.ptr(weight), L.ptr(g), L.stream()),
-                    "three_interpolate_grad")
+            if invlists.ATOMIC_GRADS or n == 0:
+                L.check(L.lib().gspn_threeinterpolate_grad(b, n, c, ctx.m, L.ptr(grad_out), L.ptr(idx), L.ptr(weight), L.ptr(g), L.stream()),
+                        "three_interpolate_grad")
+            else:
+                # a gather through the inverse lists of idx: contributions added in ascending (j, t) -- the order of the reference's own
+                # sequential loop (tf_interpolate.cpp:131-153), bit for bit; no atomics, no zero fill
+                order, offsets = invlists.cached_inverse_lists(ctx.idx_obj if ctx.idx_obj._version == idx._version else idx, ctx.m)
+                L.check(L.lib().gspn_fp_concat_grad_csr(b, n, ctx.m, c, 0, c, L.ptr(grad_out), L.ptr(order), L.ptr(offsets), L.ptr(weight), L.ptr(g),
+                                                        None, L.stream()), "three_interpolate_grad(csr)")
         return g, None, None
 
 

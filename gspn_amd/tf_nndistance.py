@@ -2,6 +2,9 @@
 import torch
 
 from . import _lib as L
+from . import invlists
+
+LDS_GRAD_MAX_POINTS = 4096      # NMG_MAX_PTS of csrc/nndistance.hip: up to here one workgroup per cloud keeps both gradients in LDS
 
 
 class _NnDistance(torch.autograd.Function):
@@ -33,8 +36,16 @@ class _NnDistance(torch.autograd.Function):
         g1 = torch.empty((b, n, 3), dtype=torch.float32, device=dev)
         g2 = torch.empty((b, m, 3), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            L.check(L.lib().gspn_nmdistance_grad(b, n, L.ptr(xyz1), m, L.ptr(xyz2), L.ptr(grad_dist1), L.ptr(idx1), L.ptr(grad_dist2), L.ptr(idx2),
-                                                 L.ptr(g1), L.ptr(g2), L.stream()), "nn_distance_grad")
+            if n + m > LDS_GRAD_MAX_POINTS and n > 0 and m > 0 and not invlists.ATOMIC_GRADS:
+                # beyond the one-workgroup-per-cloud kernel: a gather through the inverse lists of both index tensors, terms in the order
+                # of the reference's sequential CPU twin (tf_nndistance.cpp:126-163) -- bit-identical to it, no atomics
+                o1, f1 = invlists.inverse_lists(idx1, m)
+                o2, f2 = invlists.inverse_lists(idx2, n)
+                L.check(L.lib().gspn_nmdistance_grad_csr(b, n, L.ptr(xyz1), m, L.ptr(xyz2), L.ptr(grad_dist1), L.ptr(idx1), L.ptr(grad_dist2), L.ptr(idx2),
+                                                         L.ptr(o1), L.ptr(f1), L.ptr(o2), L.ptr(f2), L.ptr(g1), L.ptr(g2), L.stream()), "nn_distance_grad(csr)")
+            else:
+                L.check(L.lib().gspn_nmdistance_grad(b, n, L.ptr(xyz1), m, L.ptr(xyz2), L.ptr(grad_dist1), L.ptr(idx1), L.ptr(grad_dist2), L.ptr(idx2),
+                                                     L.ptr(g1), L.ptr(g2), L.stream()), "nn_distance_grad")
         return g1, g2
 
 

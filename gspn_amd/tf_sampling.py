@@ -5,6 +5,7 @@ import os
 import torch
 
 from . import _lib as L
+from . import invlists
 
 # bench.py sets this to a list to collect (start_event, end_event, b, n, m) around every FPS launch,
 # recorded on the stream the kernel is launched on (roofline.achieved is measured live from these)
@@ -138,6 +139,7 @@ class _GatherPoint(torch.autograd.Function):
         with torch.cuda.device(inp.device):
             L.check(L.lib().gspn_gatherpoint(b, n, m, L.ptr(inp), L.ptr(idx), L.ptr(out), L.stream()), "gather_point")
         ctx.save_for_backward(idx)
+        ctx.idx_obj = idx                    # the caller's tensor OBJECT: the inverse lists of the gradient are cached on it (invlists.py)
         ctx.n = n
         return out
 
@@ -149,7 +151,14 @@ class _GatherPoint(torch.autograd.Function):
         b, m = idx.shape
         inp_g = torch.empty((b, ctx.n, 3), dtype=torch.float32, device=out_g.device)
         with torch.cuda.device(out_g.device):
-            L.check(L.lib().gspn_scatteraddpoint(b, ctx.n, m, L.ptr(out_g), L.ptr(idx), L.ptr(inp_g), L.stream()), "gather_point_grad")
+            if invlists.ATOMIC_GRADS or m == 0:
+                L.check(L.lib().gspn_scatteraddpoint(b, ctx.n, m, L.ptr(out_g), L.ptr(idx), L.ptr(inp_g), L.stream()), "gather_point_grad")
+            else:
+                # gather through the inverse lists of idx (ascending sample position): deterministic also when a point was sampled
+                # several times (npoint > number of distinct points: tf_sampling_g.cu's atomicAdd leaves that order open)
+                order, offsets = invlists.cached_inverse_lists(ctx.idx_obj if ctx.idx_obj._version == idx._version else idx, ctx.n)
+                L.check(L.lib().gspn_sa_group_concat_grad_csr(b, ctx.n, 3, m, 1, L.ptr(order), L.ptr(offsets), 0, 3, L.ptr(out_g), L.ptr(inp_g),
+                                                              L.stream()), "gather_point_grad(csr)")
         return inp_g, None
 
 

@@ -32,8 +32,11 @@ extern "C" {
  * GSPN_ABI_VERSION is bumped whenever an entry point is added, removed or changes its argument list or workspace layout; a binder
  * compares it with gspn_abi_version() of the library it loaded (gspn_amd/_lib.py raises on a mismatch: a stale .so fails loudly).
  *   1: round 1.   2: round 2 (gspn_fps_background removed, ~30 entry points added, finalize / workspace layouts changed).
- *   3: round 3 (gspn_sa_rel_shift, gspn_bn_apply, gspn_mlp_gemm_*, gspn_small_geometry, status word of the multi-CU FPS checked). */
-#define GSPN_ABI_VERSION 6
+ *   3: round 3 (gspn_sa_rel_shift, gspn_bn_apply, gspn_mlp_gemm_*, status word of the multi-CU FPS checked).
+ *   4: round 3 (gspn_mlp_bwd_fused, gspn_mlp_bwd_fused_work_bytes).   5: round 3 (gspn_dense_rsum; the fused launch's pooled form).
+ *   6: round 3 (gspn_fps_cells_prepass_order, gspn_bn_colsum / gspn_bn_apply_grad of tf_util's stand-alone batch norm).
+ *   7: round 4 (gspn_nmdistance_grad_csr; gspn_queryballpoint now launches a prefix scan + a continuation kernel -- same output). */
+#define GSPN_ABI_VERSION 7
 int gspn_dist_policy(void);
 int gspn_abi_version(void);
 
@@ -175,6 +178,12 @@ int gspn_nmdistance(int b, int n, const float* xyz, int m, const float* xyz2, fl
  * both gradients are zeroed here first. */
 int gspn_nmdistance_grad(int b, int n, const float* xyz1, int m, const float* xyz2, const float* grad_dist1, const int* idx1,
                          const float* grad_dist2, const int* idx2, float* grad_xyz1, float* grad_xyz2, void* stream);
+/* The same gradient as a gather through inverse lists (gspn_inverse_lists of idx1 over cloud 2's m points: order1 (b,n), offsets1 (b,m+1);
+ * of idx2 over cloud 1's n points: order2 (b,m), offsets2 (b,n+1)): terms added in the order of the reference's sequential CPU twin
+ * (tf_nndistance.cpp:126-163) -- bit-identical to it, no memset, no atomics.  Any cloud size. */
+int gspn_nmdistance_grad_csr(int b, int n, const float* xyz1, int m, const float* xyz2, const float* grad_dist1, const int* idx1,
+                             const float* grad_dist2, const int* idx2, const int* order1, const int* offsets1, const int* order2,
+                             const int* offsets2, float* grad_xyz1, float* grad_xyz2, void* stream);
 
 /* ---------------- utils/pointnet_util.py composition helpers --------------------------- */
 
