@@ -89,6 +89,7 @@ SIGNATURES = {
     "gspn_mlp_bwd_fused": [_L, _I, _I, _c.POINTER(DyArgs), _P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _F, _P, _c.POINTER(_I), _P],
     "gspn_bn_finalize": [_L, _I, _P, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P],
     "gspn_bn_finalize_parts": [_L, _I, _P, _I, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P],
+    "gspn_bn_finalize_parts_pivot": [_L, _I, _P, _I, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P, _P],
     "gspn_bnrelu_maxpool": [_L, _I, _I, _P, _I, _P, _P, _P, _P, _P],
     "gspn_bnrelu_apply": [_L, _I, _P, _I, _P, _P, _P, _I, _P],
     "gspn_bn_colsum": [_L, _I, _P, _I, _P, _I, _P, _P, _F, _P, _c.POINTER(_I), _P],
@@ -161,6 +162,11 @@ def lib():
 
 def check(rc, what):
     if rc == 0:
+        # every launch through the binding is also a check point for the status words of earlier multi-CU FPS launches (the
+        # consumers of a failed launch -- gather_point, the ball query, the layers -- used to run on its zero-filled output unnoticed
+        # until the next farthest_point_sample call).  Free when nothing is pending; skipped inside a stream capture (no event queries there).
+        if _async_status and not torch.cuda.is_current_stream_capturing():
+            check_async(block=len(_async_status) > 64)          # (and the list cannot grow without bound)
         return
     if rc == -1:
         raise ValueError("%s: invalid argument (rejected like the reference's OP_REQUIRES)" % what)

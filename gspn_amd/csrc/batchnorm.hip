@@ -34,8 +34,11 @@ __global__ __launch_bounds__(BNC_T) void bn_colsum_kernel(long rows, int c, int 
                     a1 = __builtin_fmaf(dz, __builtin_fmaf(X[r * ldx + col], rs, mr), a1);      // dz * xhat (as pass B's epilogue forms it)
                 }
             } else {
+                // mean != NULL here: a PIVOT row -- the sums are of (x - pivot) and its square, so that var = E[d^2] - E[d]^2 does not
+                // cancel when |mean| >> std (x = 100 + 1e-3 * noise lost every digit of the variance before)
+                const float pv = mean ? mean[col] : 0.f;
                 for (long r = r0 + rlane; r < r1; r += rl) {
-                    const float x = X[r * ldx + col];
+                    const float x = X[r * ldx + col] - pv;
                     a0 += x;
                     a1 = __builtin_fmaf(x, x, a1);
                 }
@@ -63,7 +66,8 @@ extern "C" long gspn_bn_colsum_part_floats(long rows, int c) {
     return bnc_parts(rows) * 2 * c;
 }
 // part [nparts][2][c] <- per-workgroup column sums over the rows of X (rows, ldx >= c):
-//   dZ == NULL : (sum x, sum x^2)                      -- the input of gspn_bn_finalize_parts
+//   dZ == NULL : (sum x, sum x^2), or with mean != NULL (a pivot row, e.g. X's own first row) (sum (x - pivot), sum (x - pivot)^2)
+//                                                      -- the input of gspn_bn_finalize_parts[_pivot]
 //   dZ != NULL : (sum dz, sum dz * xhat), xhat = (x - mean) * rsqrt(var + eps)   -- the input of gspn_mlp_bwd_coef
 extern "C" int gspn_bn_colsum(long rows, int c, const float* X, int ldx, const float* dZ, int ldz, const float* mean, const float* var, float eps,
                               float* part, int* nparts_out, void* stream) {

@@ -767,13 +767,28 @@ static inline bool vec_ok(const void* p, int ld) { return (ld % 4 == 0) && (((ui
 // batch, the next batch in flight during the current batch's MFMAs.  The waits carry the operand registers as "+v" so that no use can
 // move above them; LDS returns in order, so `lgkmcnt(8)` with the next batch's eight reads behind it covers the current one whatever
 // else the compiler has in flight.
+// The compiler does not track LDS operations issued from inline asm: correctness rests on the read's destination staying in ITS register
+// until the tied wait ("=&v": early clobber, never shared with an input; the "+v" ties pin the value across the wait).  GSPN_FUSED_ASM=0
+// (a build flag: GSPN_EXTRA_HIPCC_FLAGS=-DGSPN_FUSED_ASM=0) replaces the asm by plain LDS loads the compiler schedules and waits for
+// itself -- slower (ds_read2 pairs, one base register per pair), the reference point when a ROCm bump needs checking.
+#ifndef GSPN_FUSED_ASM
+#define GSPN_FUSED_ASM 1
+#endif
 template <int OFF> __device__ __forceinline__ void lds_rd(float& v, unsigned addr) {
     static_assert(OFF >= 0 && OFF < 65536, "ds_read_b32 offset field");
-    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+#if GSPN_FUSED_ASM
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=&v"(v) : "v"(addr), "n"(OFF) : "memory");
+#else
+    v = *reinterpret_cast<const __attribute__((address_space(3))) float*>((uintptr_t)(addr + OFF));
+#endif
 }
 __device__ __forceinline__ unsigned lds_addr(const float* p) { return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float*)p; }
+#if GSPN_FUSED_ASM
 #define LDS_WAIT(N_, A_, B_)                                                                                                             \
     asm volatile("s_waitcnt lgkmcnt(" #N_ ")" : "+v"(A_[0]), "+v"(A_[1]), "+v"(A_[2]), "+v"(A_[3]), "+v"(B_[0]), "+v"(B_[1]), "+v"(B_[2]), "+v"(B_[3]) :: "memory")
+#else
+#define LDS_WAIT(N_, A_, B_) ((void)0)
+#endif
 // wait until at most CNT LDS operations are outstanding; the N registers of `v` are tied to the wait
 template <int CNT, int N> __device__ __forceinline__ void lds_wait_n(float (&v)[N]) {
     static_assert(N == 4 || N == 8 || N == 16, "operand batch");
@@ -1073,7 +1088,10 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 __global__ __launch_bounds__(256) void bn_finalize_kernel(long rows, int c, const float* __restrict__ stats, int nparts, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float eps, float decay, int is_training,
                                                           float* __restrict__ moving_mean, float* __restrict__ moving_var,
-                                                          float* __restrict__ mean, float* __restrict__ var, float* __restrict__ scale, float* __restrict__ shift) {
+                                                          float* __restrict__ mean, float* __restrict__ var, float* __restrict__ scale, float* __restrict__ shift,
+                                                          const float* __restrict__ pivot) {
+    // pivot (optional): the partial sums are of (x - pivot[j]) and its square (gspn_bn_colsum with a pivot row: no cancellation in
+    // E[x^2] - mean^2 when |mean| >> std); the mean is shifted back here, the variance needs no correction
     __shared__ double sh2[2][4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int j = blockIdx.x;
@@ -1090,6 +1108,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(long rows, int c, cons
         mu = a0 / (double)rows;
         v = a1 / (double)rows - mu * mu;                   // biased variance (tf.nn.moments)
         if (v < 0.0) v = 0.0;
+        if (pivot) mu += (double)pivot[j];
     } else {
         mu = moving_mean[j];
         v = moving_var[j];
@@ -1108,15 +1127,20 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(long rows, int c, cons
     shift[j] = be - (float)mu * inv;                                     // beta - mean*inv
 }
 // the same for column sums that did not come from gspn_mlp_fwd: nparts partial rows [nparts][2][c]
-extern "C" int gspn_bn_finalize_parts(long rows, int c, const float* stats, int nparts, const float* gamma, const float* beta, float eps, float decay,
-                                      int is_training, float* moving_mean, float* moving_var, float* mean, float* var, float* scale, float* shift,
-                                      void* stream) {
+extern "C" int gspn_bn_finalize_parts_pivot(long rows, int c, const float* stats, int nparts, const float* gamma, const float* beta, float eps, float decay,
+                                            int is_training, float* moving_mean, float* moving_var, float* mean, float* var, float* scale, float* shift,
+                                            const float* pivot, void* stream) {
     if (rows <= 0 || c <= 0 || !mean || !var || !scale || !shift || nparts < 0) return GSPN_ERR_ARG;
     if (is_training && !stats) return GSPN_ERR_ARG;
     if (!is_training && (!moving_mean || !moving_var)) return GSPN_ERR_ARG;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(c), dim3(256), 0, (hipStream_t)stream, rows, c, stats, nparts, gamma, beta,
-                       eps, decay, is_training, moving_mean, moving_var, mean, var, scale, shift);
+                       eps, decay, is_training, moving_mean, moving_var, mean, var, scale, shift, pivot);
     return gspn_launch_status();
+}
+extern "C" int gspn_bn_finalize_parts(long rows, int c, const float* stats, int nparts, const float* gamma, const float* beta, float eps, float decay,
+                                      int is_training, float* moving_mean, float* moving_var, float* mean, float* var, float* scale, float* shift,
+                                      void* stream) {
+    return gspn_bn_finalize_parts_pivot(rows, c, stats, nparts, gamma, beta, eps, decay, is_training, moving_mean, moving_var, mean, var, scale, shift, nullptr, stream);
 }
 extern "C" int gspn_bn_finalize(long rows, int c, const float* stats, const float* gamma, const float* beta, float eps, float decay,
                                 int is_training, float* moving_mean, float* moving_var, float* mean, float* var,
@@ -1125,7 +1149,7 @@ extern "C" int gspn_bn_finalize(long rows, int c, const float* stats, const floa
     if (is_training && !stats) return GSPN_ERR_ARG;
     if (!is_training && (!moving_mean || !moving_var)) return GSPN_ERR_ARG;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(c), dim3(256), 0, (hipStream_t)stream, rows, c, stats, (int)fwd_blocks(rows, c), gamma, beta,
-                       eps, decay, is_training, moving_mean, moving_var, mean, var, scale, shift);
+                       eps, decay, is_training, moving_mean, moving_var, mean, var, scale, shift, (const float*)nullptr);
     return gspn_launch_status();
 }
 
@@ -3532,8 +3556,9 @@ static bool bwd_lean_try(long rows, int cin, int cout, const gspn_dy_args* a, co
 //                                                                               operand), B = dY; accumulated over ALL tiles of the workgroup
 // and the epilogue of dX takes the previous layer's BN reductions (sum dyh, sum dyh*xhat) with y_p read back from LDS instead of HBM.
 // Each workgroup leaves one partial dW tile set (slot = workgroup) for the usual fixed-order reduction (wgrad_dw_kernel, plain) and one
-// partial row of BN reductions: results do not depend on scheduling.  Shapes: dense dZ, known coefficients, cin and cout in {32, 64},
-// rows a multiple of the tile (128 / (cin/32)), 16-byte aligned pitches; cout = 128 runs as two chunks of 64 columns.
+// partial row of BN reductions: results do not depend on scheduling.  Shapes (fused_grid() is the authority): known coefficients; a dense
+// dZ or the gradient of a max-pool over groups of 32 rows (POOL32); cin in {32, 64}, cout in {32, 64, 128} -- 128 as two chunks of 64
+// columns --; rows >= 65536 and a multiple of the tile (128 / (cin/32)); 16-byte aligned pitches.
 // ============================================================================================
 #ifndef GSPN_FUSED_ABL
 #define GSPN_FUSED_ABL 0

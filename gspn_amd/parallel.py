@@ -27,6 +27,8 @@ def init_from_env(backend=None, force=False):
     if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if "MASTER_PORT" not in os.environ:
+            if world > 1:            # every rank would pick a port of its own and the rendezvous would hang until its timeout
+                raise RuntimeError("init_from_env: WORLD_SIZE > 1 needs MASTER_PORT (torch.distributed.run sets it; a manual launch must)")
             import socket
             with socket.socket() as sk:
                 sk.bind(("127.0.0.1", 0))

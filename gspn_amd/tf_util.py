@@ -206,9 +206,11 @@ class _BatchNormRows(torch.autograd.Function):
             part, npart = None, ctypes.c_int(0)
             if is_training:
                 part = torch.empty(int(lib.gspn_bn_colsum_part_floats(rows, c)), dtype=torch.float32, device=dev)
-                L.check(lib.gspn_bn_colsum(rows, c, L.ptr(x), c, None, 0, None, None, BN_EPS, L.ptr(part), ctypes.byref(npart), st), "bn_colsum")
-            L.check(lib.gspn_bn_finalize_parts(rows, c, L.ptr(part), npart.value, L.ptr(gamma), L.ptr(beta), BN_EPS, float(decay), int(is_training),
-                                               L.ptr(mm), L.ptr(mv), L.ptr(mean), L.ptr(var), L.ptr(scale), L.ptr(shift), st), "bn_finalize")
+                # sums about a pivot -- x's own first row -- so that E[d^2] - E[d]^2 keeps its digits when |mean| >> std
+                L.check(lib.gspn_bn_colsum(rows, c, L.ptr(x), c, None, 0, L.ptr(x), None, BN_EPS, L.ptr(part), ctypes.byref(npart), st), "bn_colsum")
+            L.check(lib.gspn_bn_finalize_parts_pivot(rows, c, L.ptr(part), npart.value, L.ptr(gamma), L.ptr(beta), BN_EPS, float(decay), int(is_training),
+                                                     L.ptr(mm), L.ptr(mv), L.ptr(mean), L.ptr(var), L.ptr(scale), L.ptr(shift),
+                                                     L.ptr(x) if is_training else None, st), "bn_finalize")
             L.check(lib.gspn_bn_apply(rows, c, L.ptr(x), c, L.ptr(scale), L.ptr(shift), 0, L.ptr(out), c, st), "bn_apply")
         ctx.save_for_backward(x, gamma, mean, var, scale)
         ctx.is_training = bool(is_training)

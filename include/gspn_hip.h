@@ -35,7 +35,7 @@ extern "C" {
  *   3: round 3 (gspn_sa_rel_shift, gspn_bn_apply, gspn_mlp_gemm_*, status word of the multi-CU FPS checked).
  *   4: round 3 (gspn_mlp_bwd_fused, gspn_mlp_bwd_fused_work_bytes).   5: round 3 (gspn_dense_rsum; the fused launch's pooled form).
  *   6: round 3 (gspn_fps_cells_prepass_order, gspn_bn_colsum / gspn_bn_apply_grad of tf_util's stand-alone batch norm).
- *   7: round 4 (gspn_nmdistance_grad_csr; gspn_queryballpoint now launches a prefix scan + a continuation kernel -- same output). */
+ *   7: round 4 (gspn_nmdistance_grad_csr, gspn_bn_finalize_parts_pivot; gspn_queryballpoint now launches a prefix scan + a continuation kernel -- same output). */
 #define GSPN_ABI_VERSION 7
 int gspn_dist_policy(void);
 int gspn_abi_version(void);
@@ -250,6 +250,10 @@ int gspn_bn_finalize(long rows, int c, const float* stats, const float* gamma, c
 int gspn_bn_finalize_parts(long rows, int c, const float* stats, int nparts, const float* gamma, const float* beta, float eps, float decay,
                            int is_training, float* moving_mean, float* moving_var, float* mean, float* var, float* scale, float* shift,
                            void* stream);
+/* the same with the partial sums taken about a pivot row (gspn_bn_colsum(dZ = NULL, mean = pivot)): mean = pivot + sum/rows; pivot may be NULL */
+int gspn_bn_finalize_parts_pivot(long rows, int c, const float* stats, int nparts, const float* gamma, const float* beta, float eps, float decay,
+                                 int is_training, float* moving_mean, float* moving_var, float* mean, float* var, float* scale, float* shift,
+                                 const float* pivot, void* stream);
 
 /* out(groups,c) = max over the ns rows of each group of relu(Y*scale+shift)   (tf.reduce_max,
  * pointnet_util.py:123-124); arg (groups,c) gets the row offset (0..ns-1) of the first maximum. */

@@ -52,3 +52,24 @@ def test_batch_norm_matches_fp64(shape, training):
     assert rel_err(x.grad, xr.grad) < 1e-4
     assert rel_err(gamma.grad, g64.grad) < 1e-4
     assert rel_err(beta.grad, b64.grad) < 1e-4
+
+
+def test_batch_norm_large_mean_small_spread():
+    """x = 100 + 1e-3 * noise.  Sums of x and x^2 in float32 lose every digit of var = E[x^2] - mean^2 (round 3's kernel gave
+    var = 0, or a negative number for rsqrt); the column sums are now taken about a pivot row, so the variance comes out to 1e-4."""
+    from gspn_amd import tf_util
+    store = tf_util.set_variable_store(tf_util.VariableStore(seed=5))
+    g = torch.Generator().manual_seed(99)
+    rows, c = 200000, 48
+    x64 = 100.0 + 1e-3 * torch.randn(rows, c, generator=g, dtype=torch.float64)
+    x = x64.float().cuda()
+    out = tf_util.batch_norm_for_fc(x, True, 0.0, 'bn')       # decay 0: the moving statistics ARE the batch statistics
+    assert bool(torch.isfinite(out).all())
+    xf = x.double().cpu()                                   # the float32 inputs the kernel saw
+    var = ((xf - xf.mean(0)) ** 2).mean(0)
+    got_var = store.vars["bn/moving_variance"].double().cpu()
+    got_mean = store.vars["bn/moving_mean"].double().cpu()
+    assert float((got_var - var).abs().max() / var.abs().max()) < 1e-4
+    assert float((got_mean - xf.mean(0)).abs().max()) < 1e-4
+    ref = (xf - xf.mean(0)) * torch.rsqrt(var + 1e-3)
+    assert float((out.double().cpu() - ref).abs().max()) < 2e-3      # |xhat| <= ~0.15 here; x*scale + shift rounds at 100 * ulp
