@@ -219,6 +219,199 @@ static int launch_three_nn_wave(int b, int n, int m, const float* xyz1, const fl
     return gspn_launch_status();
 }
 
+// ---- large known clouds: a uniform grid over the known points, built in LDS by every workgroup (r04) ---------------------------------
+// three_nn_kernel tests every known point against every query: 537 M pairs at 8 x 32768 <- 2048, ~12 instructions each even with the
+// cheap rejection test (VALU-bound at 0.86 of peak) -- 0.11 ms of full-chip work per step on the geometry stream.  The three
+// nearest neighbours of a query lie in its own cell's neighbourhood: here a workgroup sorts the scene's known points into G^3 cells
+// (counting sort in LDS: bounding box, histogram, scan, scatter of (x, y, z, k)), a thread per query scans the 3 x 3 x 3 block of cells
+// around its own (nine contiguous runs of the sorted array) and keeps the three smallest (distance, index) pairs -- distance by the
+// reference's own expression (tf_interpolate.cpp:71-74), ties to the lower index, which is what its strict-'<' cascade over ascending
+// k leaves.  EXACT, not approximate: the block is accepted only if the third distance is smaller than the (squared, slightly shrunk)
+// distance from the query to every face of the block that has cells behind it; otherwise the search restarts over all cells that the
+// ball of that radius touches (with fewer than three points found: all cells).  No workspace, same signature.
+#define NNG_T 256
+#define NNG_MAX_G 16
+#define NNG_MAX_M 8192                      // 128 KB of sorted points + the cell table
+struct NNBest { float b1, b2, b3; int i1, i2, i3; };
+__device__ __forceinline__ void nn_insert(NNBest& s, float d, int k) {
+    if (d < s.b3 || (d == s.b3 && k < s.i3)) {
+        if (d < s.b1 || (d == s.b1 && k < s.i1)) { s.b3 = s.b2; s.i3 = s.i2; s.b2 = s.b1; s.i2 = s.i1; s.b1 = d; s.i1 = k; }
+        else if (d < s.b2 || (d == s.b2 && k < s.i2)) { s.b3 = s.b2; s.i3 = s.i2; s.b2 = d; s.i2 = k; }
+        else { s.b3 = d; s.i3 = k; }
+    }
+}
+template <int PPT>                        // known points per thread, held in registers through the three passes of the sort (m <= PPT * NNG_T)
+__global__ __launch_bounds__(NNG_T) void three_nn_grid_kernel(int b, int n, int m, int G, int qpw, const float* __restrict__ xyz1, const float* __restrict__ xyz2,
+                                                              float* __restrict__ dist, int* __restrict__ idx, const int* __restrict__ order) {
+    extern __shared__ __attribute__((aligned(16))) float4 s_pts[];          // [m] known points sorted by cell: (x, y, z, bits of k)
+    const int G3 = G * G * G;
+    int* s_start = reinterpret_cast<int*>(s_pts + m);                       // [G3 + 1]
+    int* s_cur = s_start + G3 + 1;                                          // [G3]
+    __shared__ float s_red[6][NNG_T / 64];
+    __shared__ int s_wsum[NNG_T / 64];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int scene = blockIdx.x % b;                                       // scene <-> XCD affinity
+    const int qb = blockIdx.x / b;
+    const float* sp = xyz2 + (size_t)scene * m * 3;
+    // ---- the thread's known points (k = t + 256 i): loaded once, all loads in flight ----
+    float px[PPT], py[PPT], pz[PPT];
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        const int k = t + NNG_T * i;
+        const int kc = k < m ? k : 0;                                        // clamped, unconditional
+        px[i] = sp[(size_t)kc * 3]; py[i] = sp[(size_t)kc * 3 + 1]; pz[i] = sp[(size_t)kc * 3 + 2];
+    }
+    // ---- bounding box of the known points ----
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int i = 0; i < PPT; ++i)
+        if (t + NNG_T * i < m) {
+            lo[0] = fminf(lo[0], px[i]); hi[0] = fmaxf(hi[0], px[i]);
+            lo[1] = fminf(lo[1], py[i]); hi[1] = fmaxf(hi[1], py[i]);
+            lo[2] = fminf(lo[2], pz[i]); hi[2] = fmaxf(hi[2], pz[i]);
+        }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        for (int sft = 32; sft >= 1; sft >>= 1) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], sft, 64)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], sft, 64)); }
+        if (lane == 0) { s_red[a][wave] = lo[a]; s_red[3 + a][wave] = hi[a]; }
+    }
+    for (int c = t; c < G3; c += NNG_T) s_cur[c] = 0;
+    __syncthreads();
+    float inv[3], h[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = fminf(fminf(s_red[a][0], s_red[a][1]), fminf(s_red[a][2], s_red[a][3]));
+        hi[a] = fmaxf(fmaxf(s_red[3 + a][0], s_red[3 + a][1]), fmaxf(s_red[3 + a][2], s_red[3 + a][3]));
+        const float ext = hi[a] - lo[a];
+        h[a] = ext / (float)G;
+        inv[a] = (ext > 0.f && isfinite(ext)) ? (float)G / ext : 0.f;        // a flat (or non-finite) axis: every point in cell 0 of that axis
+    }
+    auto cell_of = [&](float x, float y, float z, int& cx, int& cy, int& cz) {
+        cx = min(max((int)floorf((x - lo[0]) * inv[0]), 0), G - 1);
+        cy = min(max((int)floorf((y - lo[1]) * inv[1]), 0), G - 1);
+        cz = min(max((int)floorf((z - lo[2]) * inv[2]), 0), G - 1);
+    };
+    // ---- counting sort of the known points by cell ----
+    int pcell[PPT];
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        int cx, cy, cz;
+        cell_of(px[i], py[i], pz[i], cx, cy, cz);
+        pcell[i] = (cz * G + cy) * G + cx;
+        if (t + NNG_T * i < m) atomicAdd(&s_cur[pcell[i]], 1);
+    }
+    __syncthreads();
+    {
+        const int per = (G3 + NNG_T - 1) / NNG_T;                            // consecutive cells per thread
+        int local = 0;
+        for (int c = t * per; c < min((t + 1) * per, G3); ++c) local += s_cur[c];
+        int incl = local;
+#pragma unroll
+        for (int sft = 1; sft < 64; sft <<= 1) { const int u = __shfl_up(incl, sft, 64); if (lane >= sft) incl += u; }
+        if (lane == 63) s_wsum[wave] = incl;
+        __syncthreads();
+        int run = incl - local;
+        for (int w = 0; w < wave; ++w) run += s_wsum[w];
+        for (int c = t * per; c < min((t + 1) * per, G3); ++c) { const int v = s_cur[c]; s_start[c] = run; s_cur[c] = run; run += v; }
+        if (t == NNG_T - 1) s_start[G3] = run;                               // == m
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PPT; ++i)
+        if (t + NNG_T * i < m) s_pts[atomicAdd(&s_cur[pcell[i]], 1)] = make_float4(px[i], py[i], pz[i], __int_as_float(t + NNG_T * i));
+    __syncthreads();
+    // ---- the queries of this workgroup ----
+    for (int u = 0; u < qpw; ++u) {
+        int j = (qb * qpw + u) * NNG_T + t;
+        if (j >= n) break;
+        if (order) j = order[(size_t)scene * n + j];                         // spatially coherent lanes visit the same cells (broadcast reads)
+        const float* q = xyz1 + ((size_t)scene * n + j) * 3;
+        const float qx = q[0], qy = q[1], qz = q[2];
+        // (float)1e40 == +inf (tf_interpolate.cpp:66): any finite distance is smaller; fewer than three known points leave (inf, 0)
+        NNBest s{INFINITY, INFINITY, INFINITY, 0, 0, 0};
+        int c[3];
+        cell_of(qx, qy, qz, c[0], c[1], c[2]);
+        int c0[3], c1[3];
+        float bound = INFINITY;                                              // distance to the nearest face of the block with cells behind it
+        const float qv[3] = {qx, qy, qz};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            c0[a] = max(c[a] - 1, 0);
+            c1[a] = min(c[a] + 1, G - 1);
+            if (c0[a] > 0) bound = fminf(bound, qv[a] - (lo[a] + (float)c0[a] * h[a]));
+            if (c1[a] < G - 1) bound = fminf(bound, (lo[a] + (float)(c1[a] + 1) * h[a]) - qv[a]);
+        }
+        auto scan_block = [&]() {
+            for (int cz = c0[2]; cz <= c1[2]; ++cz)
+                for (int cy = c0[1]; cy <= c1[1]; ++cy) {
+                    const int row = (cz * G + cy) * G;
+                    const int e1 = s_start[row + c1[0] + 1];
+                    int e = s_start[row + c0[0]];
+                    for (; e + 3 < e1; e += 4) {                             // four candidates in flight, one test for "none of them enters"
+                        const float4 p0 = s_pts[e], p1 = s_pts[e + 1], p2 = s_pts[e + 2], p3 = s_pts[e + 3];
+                        const float d0 = dist2_host(p0.x - qx, p0.y - qy, p0.z - qz), d1 = dist2_host(p1.x - qx, p1.y - qy, p1.z - qz);     // :71-74, the reference's expression
+                        const float d2 = dist2_host(p2.x - qx, p2.y - qy, p2.z - qz), d3 = dist2_host(p3.x - qx, p3.y - qy, p3.z - qz);
+                        if (fminf(fminf(d0, d1), fminf(d2, d3)) <= s.b3) {
+                            nn_insert(s, d0, __float_as_int(p0.w)); nn_insert(s, d1, __float_as_int(p1.w));
+                            nn_insert(s, d2, __float_as_int(p2.w)); nn_insert(s, d3, __float_as_int(p3.w));
+                        }
+                    }
+                    for (; e < e1; ++e) {
+                        const float4 p = s_pts[e];
+                        nn_insert(s, dist2_host(p.x - qx, p.y - qy, p.z - qz), __float_as_int(p.w));
+                    }
+                }
+        };
+        scan_block();
+        // accepted iff no point outside the block can be as close as the third one found: its distance along the axis of the face it
+        // lies behind is at least `bound` (cells are assigned with the same lo / inv, one rounding: the 1e-3 shrink covers it many times)
+        const float safe = bound * 0.999f;
+        if (!(s.b3 < safe * safe)) {
+            // restart over every cell the ball of radius sqrt(b3) touches (b3 = +inf: all cells); the true three lie inside it
+            const float r = s.b3 < INFINITY ? sqrtf(s.b3) * 1.001f : INFINITY;
+            s = NNBest{INFINITY, INFINITY, INFINITY, 0, 0, 0};
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                if (r < INFINITY && inv[a] > 0.f) {
+                    c0[a] = min(max((int)floorf((qv[a] - r - lo[a]) * inv[a]) - 1, 0), G - 1);      // (one cell of slack on both sides)
+                    c1[a] = min(max((int)floorf((qv[a] + r - lo[a]) * inv[a]) + 1, 0), G - 1);
+                } else { c0[a] = 0; c1[a] = G - 1; }
+            }
+            scan_block();
+        }
+        float* od = dist + ((size_t)scene * n + j) * 3;
+        int* oi = idx + ((size_t)scene * n + j) * 3;
+        od[0] = s.b1; od[1] = s.b2; od[2] = s.b3;
+        oi[0] = s.i1; oi[1] = s.i2; oi[2] = s.i3;
+    }
+}
+static bool nn_grid_ok(int n, int m) {
+    static const int on = [] { const char* e = getenv("GSPN_NN_CELLS"); return e ? atoi(e) : 1; }();     // (A/B hook: 0 = the all-pairs kernel)
+    return on && m > NN_WAVE_MAX_M && m <= NNG_MAX_M && n >= 1;
+}
+static int launch_three_nn_grid(int b, int n, int m, const float* xyz1, const float* xyz2, float* dist, int* idx, const int* order, hipStream_t st) {
+    static const int ppc = [] { const char* e = getenv("GSPN_NN_CELL_POINTS"); const int v = e ? atoi(e) : 4; return v > 0 ? v : 4; }();       // target points per cell
+    static const int qpw = [] { const char* e = getenv("GSPN_NN_CELL_QPW"); const int v = e ? atoi(e) : 1; return v > 0 ? v : 1; }();          // queries per thread
+    int G = (int)floor(cbrt((double)m / ppc) + 0.5);
+    G = G < 2 ? 2 : (G > NNG_MAX_G ? NNG_MAX_G : G);
+    const size_t dyn = sizeof(float4) * (size_t)m + sizeof(int) * (2 * (size_t)G * G * G + 1);
+    const long long blocks = (long long)b * ((n + NNG_T * qpw - 1) / (NNG_T * qpw));
+    if (blocks > 0x7FFFFFFFll) return GSPN_ERR_UNSUPPORTED;
+#define NNG_GO(PPT_)                                                                                                                              \
+    do {                                                                                                                                          \
+        static size_t attr = 0;                                                                                                                   \
+        if (dyn > attr) {                                                                                                                         \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&three_nn_grid_kernel<PPT_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); \
+            if (e != hipSuccess) return (int)e;                                                                                                   \
+            attr = dyn;                                                                                                                           \
+        }                                                                                                                                         \
+        hipLaunchKernelGGL(three_nn_grid_kernel<PPT_>, dim3((unsigned)blocks), dim3(NNG_T), dyn, st, b, n, m, G, qpw, xyz1, xyz2, dist, idx, order); \
+    } while (0)
+    if (m <= 8 * NNG_T) NNG_GO(8); else if (m <= 16 * NNG_T) NNG_GO(16); else NNG_GO(32);
+#undef NNG_GO
+    return gspn_launch_status();
+}
+
 static unsigned nn_grid(long long blocks) {
     static const long long cap = [] { const char* e = getenv("GSPN_NN_GRID"); const long long v = e ? atoll(e) : 0; return v > 0 ? v : (1ll << 31); }();
     return (unsigned)(blocks < cap ? blocks : cap);
@@ -227,6 +420,7 @@ extern "C" int gspn_threenn(int b, int n, int m, const float* xyz1, const float*
     if (b < 0 || n < 0 || m < 0) return GSPN_ERR_ARG;
     if (b == 0 || n == 0) return 0;
     if (nn_wave_ok(n, m)) return launch_three_nn_wave(b, n, m, xyz1, xyz2, dist, idx, (hipStream_t)stream);
+    if (nn_grid_ok(n, m)) return launch_three_nn_grid(b, n, m, xyz1, xyz2, dist, idx, nullptr, (hipStream_t)stream);
     const long long blocks = (long long)b * ((n + NN_BLOCK * NN_Q - 1) / (NN_BLOCK * NN_Q));
     if (blocks > 0x7FFFFFFFll) return GSPN_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(three_nn_kernel, dim3(nn_grid(blocks)), dim3(NN_BLOCK), 0, (hipStream_t)stream, b, n, m, xyz1, xyz2, dist, idx, (const int*)nullptr, (unsigned)blocks);
@@ -236,6 +430,7 @@ extern "C" int gspn_threenn_ordered(int b, int n, int m, const float* xyz1, cons
     if (b < 0 || n < 0 || m < 0) return GSPN_ERR_ARG;
     if (b == 0 || n == 0) return 0;
     if (nn_wave_ok(n, m)) return launch_three_nn_wave(b, n, m, xyz1, xyz2, dist, idx, (hipStream_t)stream);       // (the result never depends on `order`)
+    if (nn_grid_ok(n, m)) return launch_three_nn_grid(b, n, m, xyz1, xyz2, dist, idx, order, (hipStream_t)stream);
     const long long blocks = (long long)b * ((n + NN_BLOCK * NN_Q - 1) / (NN_BLOCK * NN_Q));
     if (blocks > 0x7FFFFFFFll) return GSPN_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(three_nn_kernel, dim3(nn_grid(blocks)), dim3(NN_BLOCK), 0, (hipStream_t)stream, b, n, m, xyz1, xyz2, dist, idx, order, (unsigned)blocks);

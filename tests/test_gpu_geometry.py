@@ -471,3 +471,46 @@ def test_fps_prepass_voxel_order_is_a_permutation_in_voxel_order():
         vox = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
         along = vox[order[b]]
         assert (np.diff(along) >= 0).all()
+
+
+@pytest.mark.parametrize("case", ["lattice", "plane", "outside", "clusters", "duplicates", "m1025"])
+def test_three_nn_cell_grid_is_exact(case):
+    """r04: known clouds of more than 1024 points go through three_nn_grid_kernel (the known points sorted into cells in LDS, the 3 x 3 x 3
+    block around the query's cell, acceptance by the distance to the block's faces, a restart over the ball's cells otherwise).  Exact
+    against the oracle -- indices and distances bit for bit -- where that logic is stressed: integer lattices (ties everywhere, third
+    distances exactly ON a cell face), a flat axis, queries far outside the known bounding box, tight clusters with empty space between
+    them (restart path, fewer than three points in the block), duplicated points, the smallest cloud that takes this kernel."""
+    from gspn_amd.tf_interpolate import three_nn
+    rng = np.random.default_rng(31)
+    b, n = 2, 3000
+    if case == "lattice":
+        g = np.stack(np.meshgrid(np.arange(13), np.arange(13), np.arange(13), indexing="ij"), -1).reshape(-1, 3).astype(np.float32)     # 2197 points
+        sparse = np.stack([g[rng.permutation(len(g))] for _ in range(b)])
+        dense = rng.integers(-2, 15, size=(b, n, 3)).astype(np.float32)
+        dense[:, ::3] += 0.5                                                  # some queries on cell faces / between lattice points
+    elif case == "plane":
+        sparse = rng.random((b, 1500, 3)).astype(np.float32)
+        sparse[..., 2] = 0.25                                                 # zero extent along z
+        dense = rng.random((b, n, 3)).astype(np.float32)
+    elif case == "outside":
+        sparse = rng.random((b, 2048, 3)).astype(np.float32)
+        dense = (rng.random((b, n, 3)).astype(np.float32) - 0.5) * 40.0       # most queries far outside [0, 1)^3
+    elif case == "clusters":
+        centres = rng.random((b, 6, 3)).astype(np.float32) * 10.0
+        sparse = (centres[:, rng.integers(0, 6, size=2500)] + 0.01 * rng.standard_normal((b, 2500, 3))).astype(np.float32)
+        sparse[:, :2] += 50.0                                                 # two stragglers stretch the bounding box: almost all cells empty
+        dense = (rng.random((b, n, 3)).astype(np.float32)) * 12.0
+    elif case == "duplicates":
+        sparse = D.batch("D", b, 4096, 40)
+        sparse[:, 2000:] = sparse[:, :2096]                                   # every point twice: each nearest neighbour is a tie
+        dense = D.batch("U", b, n, 41)
+    else:
+        sparse = D.batch("U", b, 1025, 50)
+        dense = D.batch("U", b, n, 51)
+    rd, ri = O.three_nn(dense, sparse)
+    d, i = three_nn(dev(dense), dev(sparse))
+    np.testing.assert_array_equal(i.cpu().numpy(), ri)
+    np.testing.assert_array_equal(d.cpu().numpy(), rd)
+    perm = np.stack([rng.permutation(n) for _ in range(b)]).astype(np.int32)
+    d2, i2 = three_nn(dev(dense), dev(sparse), order=dev(perm))                # the result never depends on the scan order
+    assert torch.equal(i2, i) and torch.equal(d2, d)
