@@ -117,10 +117,14 @@ def main():
     from gspn_amd.geometry import GeometryStream
     from gspn_amd.graph import CapturedStep, copy_into
 
+    rank, local, world = parallel.init_from_env(force=args.force_collective)
     if args.sync_bn:
         mlp_mod.SYNC_BN = True
-        args.no_graph = True                      # collectives inside the layers: not captured
-    rank, local, world = parallel.init_from_env(force=args.force_collective)
+        # r04: SyncBN runs on the fused kernels (mlp.SYNC_BN_FUSED: the partial rows of every BN reduction all-reduced between the producing
+        # and the summing kernel), so the step is captured like the default one -- RCCL collectives capture into the hipGraph (tested at world
+        # 1, tests/test_gpu_collective.py); gloo's host-side collectives and the layer-by-layer torch form cannot be captured
+        if (not mlp_mod.SYNC_BN_FUSED or not dist.is_initialized() or dist.get_backend() != "nccl" or os.environ.get("GSPN_SYNC_BN_NO_GRAPH") == "1"):
+            args.no_graph = True
     _stdout_discipline(rank)
     FORCE_COLL = bool(args.force_collective)
     COLL_IN_GRAPH = bool(args.collective_in_graph) and (world > 1 or FORCE_COLL)

@@ -49,6 +49,26 @@ _side_streams = {}
 # batch-normalised stacks run layer by layer: the GEMM kernel of the linear layer, then parallel.sync_bn_relu (two small all-reduces per
 # layer).  Slower than the fused kernels; results equal a single-process run on the concatenated batch (tests/test_cpu_dist.py).
 SYNC_BN = False
+# r04: SyncBN ON the fused kernels.  Every batch-norm reduction of the stack already leaves the kernels as per-workgroup partial rows that a
+# small kernel sums (gspn_bn_finalize*, gspn_mlp_bwd_coef): with equal shards the ranks' partial buffers have the same shape, so ONE
+# all-reduce(SUM) of that buffer between the producing kernel and the summing kernel turns every local sum into the global one; the
+# summing kernel then runs with rows x world.  Same kernels, same hipGraph, two small collectives per layer.  Needs: equal rows on every
+# rank (weak scaling), training-mode BN on every layer, coefficients that come from partial rows everywhere (EARLY_R; the dense top
+# layer's reductions always through gspn_dense_rsum).  SYNC_BN_FUSED = False restores round 2's layer-by-layer torch form.
+SYNC_BN_FUSED = os.environ.get("GSPN_SYNC_BN_FUSED", "1") != "0"
+
+
+def _sync_world(stack_ok=True):
+    """world size over which the fused kernels' BN reductions are all-reduced (1: no SyncBN, or a single rank)"""
+    if not (SYNC_BN and SYNC_BN_FUSED and stack_ok):
+        return 1
+    import torch.distributed as dist
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+
+def _allreduce_sum(t):
+    import torch.distributed as dist
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
 
 # bench.py sets this to a list to collect (kind, rows, cin, cout, start_event, end_event) around every GEMM-kernel launch of the stack
 # ("fwd", "wgrad" = pass A incl. its finalize kernels, "bwd" = pass B (+ the dW reduction riding in it)); None = no events
@@ -123,6 +143,7 @@ class _MlpStack(torch.autograd.Function):
         is_training = bool(spec["is_training"])
         decay = float(spec["decay"])
         pool_ns = spec["pool_ns"]
+        sw = _sync_world(is_training) if spec.get("sync_bn") else 1          # > 1: BN statistics over the global batch (fused SyncBN)
         saved = []
         cur, cur_ld, cin = x, ld, cin0
         in_scale = in_shift = None
@@ -168,10 +189,18 @@ class _MlpStack(torch.autograd.Function):
                 var = torch.empty(cout, dtype=torch.float32, device=dev)
                 scale = torch.empty(cout, dtype=torch.float32, device=dev)
                 shift = torch.empty(cout, dtype=torch.float32, device=dev)
+                if sw > 1 and use_stats:
+                    _allreduce_sum(stats)                # every partial row becomes the sum of the ranks' rows: global column sums
+                rows_bn = rows * sw
                 if lp.bn and pre0 is not None:
-                    L.check(lib.gspn_bn_finalize_parts(rows, cout, L.ptr(stats), nparts0, L.ptr(lp.gamma), L.ptr(lp.beta), BN_EPS, decay,
+                    L.check(lib.gspn_bn_finalize_parts(rows_bn, cout, L.ptr(stats), nparts0, L.ptr(lp.gamma), L.ptr(lp.beta), BN_EPS, decay,
                                                        int(is_training), L.ptr(lp.moving_mean), L.ptr(lp.moving_variance),
                                                        L.ptr(mean), L.ptr(var), L.ptr(scale), L.ptr(shift), st), "bn_finalize")
+                elif lp.bn and sw > 1:
+                    # (gspn_bn_finalize derives the number of partial rows from `rows`: the local count; the statistics divide by the global one)
+                    L.check(lib.gspn_bn_finalize_parts(rows_bn, cout, L.ptr(stats), int(lib.gspn_mlp_fwd_stats_bytes(rows, cout)) // (8 * cout), L.ptr(lp.gamma),
+                                                       L.ptr(lp.beta), BN_EPS, decay, int(is_training), L.ptr(lp.moving_mean), L.ptr(lp.moving_variance),
+                                                       L.ptr(mean), L.ptr(var), L.ptr(scale), L.ptr(shift), st), "bn_finalize(sync)")
                 elif lp.bn:
                     L.check(lib.gspn_bn_finalize(rows, cout, L.ptr(stats), L.ptr(lp.gamma), L.ptr(lp.beta), BN_EPS, decay,
                                                  int(is_training), L.ptr(lp.moving_mean), L.ptr(lp.moving_variance),
@@ -209,6 +238,7 @@ class _MlpStack(torch.autograd.Function):
         if pool_ns:
             ctx.save_for_backward(out)           # the pooled output: where it is 0 no gradient passes the ReLU (POOLTOP_STREAM)
         ctx.spec = spec
+        ctx.sw = sw
         ctx.rows = rows
         ctx.x_needs_grad = x.requires_grad
         return out
@@ -224,6 +254,7 @@ class _MlpStack(torch.autograd.Function):
         is_training = bool(spec["is_training"])
         pool_ns = spec["pool_ns"]
         rows = ctx.rows
+        sw = ctx.sw
         gather = ctx.gather
         d_out = d_out.contiguous()
         dev = d_out.device
@@ -257,20 +288,22 @@ class _MlpStack(torch.autograd.Function):
                     L.check(lib.gspn_pool_rsum(rows // pool_ns, pool_ns, cout, L.ptr(d_out), L.ptr(ctx.arg), L.ptr(y if yarg is None else yarg),
                                                cout if yarg is None else 0, L.ptr(scale), L.ptr(shift),
                                                L.ptr(mean), L.ptr(var), BN_EPS, L.ptr(part), ctypes.byref(npart), st), "pool_rsum")
-                    coef[li] = _coef_from_parts(lib, rows, cout, npart.value, part, mean, var, lp, dev, st)
+                    coef[li] = _coef_from_parts(lib, rows, cout, npart.value, part, mean, var, lp, dev, st, sw)
                 # ---- early coefficients of the top layer of a DENSE stack: one streaming pass over (d_out, Y); worth its launch on the long
                 #      layers only (the two-product pass A of a short layer costs less than the extra dependent kernels) ----
-                if (tr_all and DENSE_TOP_RSUM and lp.bn and dz is not None and li == len(layers) - 1 and li not in coef and li > 0
-                        and rows >= DENSE_TOP_MIN_ROWS):
+                if (tr_all and (DENSE_TOP_RSUM or sw > 1) and lp.bn and dz is not None and li == len(layers) - 1 and li not in coef
+                        and ((li > 0 and rows >= DENSE_TOP_MIN_ROWS) or (sw > 1 and gather0 is None and not (li == 0 and ctx.pre is not None)))):
                     part = torch.empty(int(lib.gspn_rsum_part_floats(rows, cout)), dtype=torch.float32, device=dev)
                     npart = ctypes.c_int(0)
                     try:
                         L.check(lib.gspn_dense_rsum(rows, cout, L.ptr(dz), ldz, L.ptr(y), cout, L.ptr(scale), L.ptr(shift), L.ptr(mean), L.ptr(var),
                                                     BN_EPS, L.ptr(part), ctypes.byref(npart), st), "dense_rsum")
-                        coef[li] = _coef_from_parts(lib, rows, cout, npart.value, part, mean, var, lp, dev, st)
+                        coef[li] = _coef_from_parts(lib, rows, cout, npart.value, part, mean, var, lp, dev, st, sw)
                     except NotImplementedError:
                         pass
                 known = coef.get(li)
+                if sw > 1 and lp.bn and known is None:
+                    raise RuntimeError("mlp_stack (fused SyncBN): layer %d has no early BN coefficients -- its reductions would be per replica" % li)
                 if known is not None:
                     cA, cB, cC, dgamma, dbeta, dbias = known
                 else:
@@ -318,7 +351,7 @@ class _MlpStack(torch.autograd.Function):
                     if fused:
                         _toc(ev, "fused", rows, cin, cout, 4.0 * rows * cin * cout)
                         if want_rsum:
-                            coef[li - 1] = _coef_from_parts(lib, rows, cin, npart.value, part, pmean, pvar, prev, dev, st)
+                            coef[li - 1] = _coef_from_parts(lib, rows, cin, npart.value, part, pmean, pvar, prev, dev, st, sw)
                         g = [dW, dbias]
                         if lp.bn:
                             g += [dbeta, dgamma]
@@ -425,7 +458,7 @@ class _MlpStack(torch.autograd.Function):
                                                          L.ptr(pY), cin, L.ptr(pscale), L.ptr(pshift), L.ptr(pmean), L.ptr(pvar), BN_EPS, L.ptr(part),
                                                          ctypes.byref(npart) if want_rsum else None, st), "mlp_bwd_data_ex")
                         if want_rsum:
-                            coef[li - 1] = _coef_from_parts(lib, rows, cin, npart.value, part, pmean, pvar, prev, dev, st)
+                            coef[li - 1] = _coef_from_parts(lib, rows, cin, npart.value, part, pmean, pvar, prev, dev, st, sw)
                     else:
                         L.check(lib.gspn_mlp_bwd_data_cols(rows, cin, cout, ctypes.byref(a), L.ptr(lp.weights), int(gc[0]), int(gc[1]), L.ptr(dx),
                                                            dx.shape[1], st), "mlp_bwd_data_cols")
@@ -492,17 +525,22 @@ def _preagg_backward(lib, pre, x, lp, a, rows, cout, need_dx, dev, st):
     return dW, dx
 
 
-def _coef_from_parts(lib, rows, c, nparts, part, mean, var, lp, dev, st):
+def _coef_from_parts(lib, rows, c, nparts, part, mean, var, lp, dev, st, sw=1):
     """gspn_mlp_bwd_coef: partial sums [nparts][2][c] of (dyh, dyh*xhat) -> the layer's final BN-backward coefficients and its
-    dgamma / dbeta / dbias, before its pass A runs"""
+    dgamma / dbeta / dbias, before its pass A runs.  sw > 1 (fused SyncBN): the partial rows are all-reduced first, the coefficients are
+    those of the global batch (rows x sw), and dgamma / dbeta / dbias -- global sums then -- are divided by sw so that the gradient
+    bucket's SUM all-reduce restores them (an exact division for power-of-two worlds)."""
     cA = torch.empty(c, dtype=torch.float32, device=dev)
     cB = torch.empty(c, dtype=torch.float32, device=dev)
     cC = torch.empty(c, dtype=torch.float32, device=dev)
-    dgamma = torch.empty(c, dtype=torch.float32, device=dev)
-    dbeta = torch.empty(c, dtype=torch.float32, device=dev)
-    dbias = torch.empty(c, dtype=torch.float32, device=dev)
-    L.check(lib.gspn_mlp_bwd_coef(rows, c, int(nparts), L.ptr(part), L.ptr(mean), L.ptr(var), L.ptr(lp.gamma), BN_EPS,
+    dgb = torch.empty((3, c), dtype=torch.float32, device=dev)
+    dgamma, dbeta, dbias = dgb[0], dgb[1], dgb[2]
+    if sw > 1:
+        _allreduce_sum(part[:int(nparts) * 2 * c])
+    L.check(lib.gspn_mlp_bwd_coef(rows * sw, c, int(nparts), L.ptr(part), L.ptr(mean), L.ptr(var), L.ptr(lp.gamma), BN_EPS,
                                   L.ptr(cA), L.ptr(cB), L.ptr(cC), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dbias), st), "mlp_bwd_coef")
+    if sw > 1:
+        dgb.mul_(1.0 / sw)
     return cA, cB, cC, dgamma, dbeta, dbias
 
 
@@ -579,7 +617,7 @@ def _mlp_stack_sync_bn(x, cin, layers, decay, pool_ns):
 def preagg_ok(layers, is_training, c):
     """can the stack's first layer be pre-aggregated?  (training-mode BN on the first two layers -- the second layer's pass B hands the
     first its BN coefficients --, a kernel-friendly width, enough feature columns for the saved GEMM work to matter)"""
-    return (PREAGG and EARLY_R and not DEFER_DW and not SYNC_BN and is_training and len(layers) >= 2 and layers[0].bn and layers[1].bn
+    return (PREAGG and EARLY_R and not DEFER_DW and not (SYNC_BN and not SYNC_BN_FUSED) and is_training and len(layers) >= 2 and layers[0].bn and layers[1].bn
             and c >= PREAGG_MIN_C and bool(L.lib().gspn_preagg_ok(layers[0].weights.shape[1])))
 
 
@@ -598,8 +636,8 @@ def mlp_stack(x, cin, layers, is_training, bn_decay, pool_ns=None, grad_cols=Non
     if gather is not None:
         if x.shape[1] % 4 or gather["c"] > x.shape[1] or cin != 3 + gather["c"] or len(layers) < 2 or layers[0].weights.shape[1] % 4:
             raise NotImplementedError("mlp_stack(gather=): needs 16-byte feature rows, >= 2 layers and a first layer of 4k output channels")
-        if SYNC_BN:
-            raise NotImplementedError("mlp_stack(gather=) with SYNC_BN")
+        if SYNC_BN and not SYNC_BN_FUSED:
+            raise NotImplementedError("mlp_stack(gather=) with the layer-by-layer SyncBN form")
     if preagg is not None:
         if gather is not None or not preagg_ok(layers, is_training, preagg["c"]) or cin != preagg["c"] + preagg["side_n"]:
             raise NotImplementedError("mlp_stack(preagg=): training-mode BN stacks of >= 2 layers, cin = c + side_n, no gather")
@@ -607,12 +645,18 @@ def mlp_stack(x, cin, layers, is_training, bn_decay, pool_ns=None, grad_cols=Non
         raise ValueError("rows must be a multiple of pool_ns")
     if grad_cols is not None and not (0 <= grad_cols[0] and grad_cols[1] > 0 and grad_cols[0] + grad_cols[1] <= cin):
         raise ValueError("grad_cols must be a column range inside [0, cin)")
+    sync_fused = False
     if SYNC_BN and is_training and any(lp.bn for lp in layers):
         import torch.distributed as dist
         if dist.is_initialized() and dist.get_world_size() > 1:
-            return _mlp_stack_sync_bn(x, cin, layers, 0.9 if bn_decay is None else float(bn_decay), pool_ns)
+            # the fused kernels when every layer is batch-normalised and the early coefficients are on (see SYNC_BN_FUSED); else layer by layer
+            sync_fused = SYNC_BN_FUSED and EARLY_R and not DEFER_DW and all(lp.bn for lp in layers)
+            if not sync_fused:
+                if gather is not None or preagg is not None:
+                    raise NotImplementedError("mlp_stack(gather= / preagg=) with the layer-by-layer SyncBN form")
+                return _mlp_stack_sync_bn(x, cin, layers, 0.9 if bn_decay is None else float(bn_decay), pool_ns)
     spec = {"layers": layers, "is_training": is_training, "decay": 0.9 if bn_decay is None else float(bn_decay), "pool_ns": pool_ns,
-            "grad_cols": grad_cols, "gather": gather, "preagg": preagg}
+            "grad_cols": grad_cols, "gather": gather, "preagg": preagg, "sync_bn": sync_fused}
     flat = []
     for lp in layers:
         flat += lp.tensors()

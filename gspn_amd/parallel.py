@@ -184,3 +184,25 @@ class FlatAdam:
         with torch.cuda.device(self.flat.device):
             L.check(L.lib().gspn_adam_flat(self.flat.numel(), L.ptr(self.flat), L.ptr(self.bucket.flat), L.ptr(self.m), L.ptr(self.v), self.lr,
                                            self.betas[0], self.betas[1], self.eps, self.weight_decay, float(grad_scale), self.t, L.stream()), "adam_flat")
+
+
+def average_moving_statistics(tensors):
+    """Plain data parallelism (the default) normalises every replica with ITS OWN batch statistics, so the ranks' moving_mean /
+    moving_variance drift apart (the parameters do not: their gradients are all-reduced).  Call this before evaluating or checkpointing:
+    one flat all-reduce leaves the rank AVERAGE of every moving statistic on every rank.  `tensors`: an iterable of the moving_mean /
+    moving_variance tensors (e.g. `[v for k, v in store.vars.items() if "moving_" in k]`).  The mean of the replicas' moving variances
+    is an approximation of the global-batch variance (it leaves out the spread of the replicas' means): exact global-batch statistics
+    are what SyncBN is for (mlp.SYNC_BN; with it the moving statistics are identical on all ranks and this call is a no-op in effect)."""
+    ts = [t for t in tensors]
+    if not ts or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    flat = torch.cat([t.detach().reshape(-1).float() for t in ts])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat.div_(dist.get_world_size())
+    off = 0
+    with torch.no_grad():
+        for t in ts:
+            n = t.numel()
+            t.copy_(flat[off:off + n].view_as(t))
+            off += n
+

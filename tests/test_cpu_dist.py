@@ -150,3 +150,37 @@ def test_forced_collective_at_world_1():
     out = mgr.dict()
     mp.spawn(_worker_forced, args=(1, _free_port(), out), nprocs=1, join=True)
     assert out[0] == (True, 1, 0, 2, True)
+
+
+def _worker_mv(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from gspn_amd import parallel
+    parallel.init_from_env(backend="gloo")
+    mm = torch.full((5,), float(rank + 1))                 # rank-dependent moving statistics (per-replica batch norm drifts like this)
+    mv = torch.arange(3.) * (rank + 1)
+    parallel.average_moving_statistics([mm, mv])
+    out[rank] = (mm.tolist(), mv.tolist())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_moving_statistics_are_averaged_over_ranks():
+    """r04: per-replica batch norm leaves different moving statistics on every rank; average_moving_statistics puts
+    the rank mean on all of them (one flat all-reduce) before evaluation / checkpointing"""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_mv, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert out[0] == out[1]
+    assert out[0][0] == [1.5] * 5 and out[0][1] == [0.0, 1.5, 3.0]
+
+
+def test_init_from_env_needs_a_master_port_for_several_ranks(monkeypatch):
+    """without MASTER_PORT every rank of a manual launch would pick a port of its own and hang in the rendezvous"""
+    import pytest
+    from gspn_amd import parallel
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.delenv("MASTER_PORT", raising=False)
+    with pytest.raises(RuntimeError, match="MASTER_PORT"):
+        parallel.init_from_env(backend="gloo")

@@ -156,3 +156,100 @@ def test_two_ranks_rehearsal_on_one_gpu_over_gloo():
     assert line["n_gpus"] == 2 and line["steps"] == 6 and line["scaling"] == "weak"
     assert line["config"]["global_batch"] == 16 and line["value"] > 0
     assert line["collective"]["world"] == 2
+
+
+SYNC_CHILD = r'''
+import json, os, sys
+sys.path.insert(0, %(root)r)
+import torch
+import torch.distributed as dist
+from gspn_amd import mlp as M
+from gspn_amd import parallel
+from gspn_amd.mlp import LayerParams, mlp_stack
+
+rank, local, world = parallel.init_from_env()
+dev = torch.device("cuda", local)
+res = {}
+
+
+def layers_of(chans, cin, seed):
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for c in chans:
+        w = (torch.randn(cin, c, generator=g) * (1.0 / cin ** 0.5)).to(dev).requires_grad_(True)
+        b = (torch.randn(c, generator=g) * 0.1).to(dev).requires_grad_(True)
+        be = (torch.randn(c, generator=g) * 0.1).to(dev).requires_grad_(True)
+        ga = (torch.rand(c, generator=g) + 0.5).to(dev).requires_grad_(True)
+        out.append(LayerParams(w, b, True, be, ga, torch.zeros(c, device=dev), torch.ones(c, device=dev)))
+        cin = c
+    return out
+
+
+def rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+for name, rows, cin, chans, ns in (("pooled", 2 * 8192, 64, [64, 64, 128], 32), ("dense", 2 * 4096, 32, [64, 32], None), ("dense1", 2 * 2048, 24, [48], None)):
+    g = torch.Generator().manual_seed(5)
+    X = torch.randn(rows, cin, generator=g)
+    half = rows // world
+    go_rows = rows // ns if ns else rows
+    GO = torch.randn(go_rows, chans[-1], generator=g)
+    gh = go_rows // world
+    # ---- this rank's shard, BN statistics over both ranks (fused SyncBN) ----
+    M.SYNC_BN = True
+    lay = layers_of(chans, cin, 9)
+    x = X[rank * half:(rank + 1) * half].to(dev).requires_grad_(True)
+    out = mlp_stack(x, cin, lay, True, 0.6, pool_ns=ns)
+    (out * GO[rank * gh:(rank + 1) * gh].to(dev)).sum().backward()
+    flat = torch.cat([t.grad.reshape(-1) for lp in lay for t in lp.tensors()])
+    dist.all_reduce(flat)                                # the gradient bucket's SUM all-reduce
+    mv = torch.cat([torch.cat([lp.moving_mean, lp.moving_variance]) for lp in lay])
+    # ---- the whole batch on one rank, plain fused stack ----
+    M.SYNC_BN = False
+    ref = layers_of(chans, cin, 9)
+    xr = X.to(dev).requires_grad_(True)
+    outr = mlp_stack(xr, cin, ref, True, 0.6, pool_ns=ns)
+    (outr * GO.to(dev)).sum().backward()
+    flatr = torch.cat([t.grad.reshape(-1) for lp in ref for t in lp.tensors()])
+    mvr = torch.cat([torch.cat([lp.moving_mean, lp.moving_variance]) for lp in ref])
+    res[name] = {"out": rel(out.detach(), outr.detach()[rank * gh:(rank + 1) * gh]), "dx": rel(x.grad, xr.grad[rank * half:(rank + 1) * half]),
+                 "params": rel(flat, flatr), "moving": rel(mv, mvr)}
+torch.cuda.synchronize()
+gathered = [None] * world
+dist.all_gather_object(gathered, res)
+if rank == 0:
+    print("RESULT " + json.dumps(gathered), flush=True)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_fused_sync_bn_two_ranks_equal_the_whole_batch_on_one():
+    """r04: SyncBN on the fused kernels (mlp.SYNC_BN_FUSED: the per-workgroup partial rows of every BN reduction all-reduced between the
+    producing and the summing kernel).  Two ranks on the one GPU (gloo), each with half of the rows: outputs, input gradients, the
+    bucket-summed parameter gradients and the moving statistics equal those of ONE process running the plain fused stack on the whole
+    batch -- the reference's single-GPU batch norm (tf_util.py:529-534).  Pooled stack, dense stack, one-layer dense stack."""
+    import json
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.update(GSPN_DIST_BACKEND="gloo", GSPN_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    script = os.path.join(ROOT, "gpurun_out", "_sync_child.py")
+    os.makedirs(os.path.dirname(script), exist_ok=True)
+    with open(script, "w") as f:
+        f.write(SYNC_CHILD % {"root": ROOT})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port), script]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    assert len(res) == 2
+    for per_rank in res:
+        for name, e in per_rank.items():
+            assert e["out"] < 1e-5 and e["moving"] < 1e-5, (name, e)
+            assert e["dx"] < 1e-4 and e["params"] < 1e-4, (name, e)
