@@ -210,7 +210,7 @@ def main():
         return loss.detach()          # (a live loss would keep the autograd graph -- and its AccumulateGrad nodes -- alive across captures)
 
     def finish(in_graph=False):
-        if not in_graph:
+        if not in_graph and not state.get("skip_collective"):
             state["bucket"].all_reduce(average=False, force=FORCE_COLL)    # one flat RCCL all-reduce (SUM; no-op at world 1 unless --force-collective)
         state["opt"].step(grad_scale=1.0 / world)    # the division by the world size rides in the Adam kernel
 
@@ -450,6 +450,27 @@ def main():
     if world > 1 or FORCE_COLL:         # every rank enters (a collective is entered by all ranks or by none); after the timed region
         coll = collective_leg(state["bucket"], world, FORCE_COLL, "last node of the captured step" if (use_graph and COLL_IN_GRAPH) else
                               "after the graph replay, before the Adam kernel (same stream)")
+        # what the collective costs INSIDE the step: the same steps once more without it (a difference run; the replicas' parameters drift
+        # apart from here on, which no longer matters -- the timed region is over).  Not possible when the all-reduce is a node of the graph.
+        if not (use_graph and COLL_IN_GRAPH) and not LAYERS_ONLY:
+            nd = min(args.steps, 40)
+            state["skip_collective"] = True
+            for _ in range(3):
+                step()
+            sync()
+            t1 = time.perf_counter()
+            for _ in range(nd):
+                step()
+            sync()
+            dt_nc = time.perf_counter() - t1
+            state["skip_collective"] = False
+            if world > 1:
+                tt = torch.tensor([dt_nc], dtype=torch.float64, device=dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dt_nc = float(tt.item())
+            coll["ms_per_step_without_collective"] = dt_nc / nd * 1e3
+            coll["allreduce_ms_in_step"] = dt / args.steps * 1e3 - dt_nc / nd * 1e3
+            coll["difference_run_steps"] = nd
     if rank == 0:
         global_batch = SCENES_PER_GPU * world
         res = {
@@ -521,7 +542,7 @@ def data_kinds_legs(res_u, kinds=("S", "D"), timeout=600):
         bq = r.get("roofline_ball_query", {})
         return {"ms_per_step": r["ms_per_step"], "scenes_per_s": r["value"], "steps": r["steps"],
                 "fps_sa1": {k: r["roofline"].get(k) for k in ("avg_launch_ms", "us_per_pick", "frac")},
-                "ball_query": [{k: lv.get(k) for k in ("level", "radius", "avg_launch_ms", "sum_visited", "upper_bound_bytes", "algorithmic_bytes_per_launch", "frac", "kernel")}
+                "ball_query": [{k: lv.get(k) for k in ("level", "radius", "avg_launch_ms", "sum_visited", "upper_bound_bytes", "algorithmic_bytes_per_launch", "frac")}
                                for lv in bq.get("levels", [])] if isinstance(bq, dict) else bq}
     out = {DATA_KIND: pick(res_u)}
     for k in kinds:
