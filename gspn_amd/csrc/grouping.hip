@@ -480,10 +480,40 @@ __global__ __launch_bounds__(256) void sa_group_concat_grad_csr_kernel(int n, in
     for (; e < e1; ++e) acc += gs[(size_t)ord[e] * ld + lc];
     if (l < c) grad_points[((size_t)scene * n + p) * c + l] = acc;
 }
+// narrow rows (c <= 8: the coordinate / colour gradients of group_point and gather_point): one THREAD per data point walks its list and sums
+// the c columns itself -- a wave per data point would run 3 of its 64 lanes.  Same fixed order (ascending grouped position).
+__global__ __launch_bounds__(256) void sa_group_concat_grad_csr_narrow_kernel(long total, int n, int c, int m_ns, int col0, int ld, const float* __restrict__ grad_out,
+                                                                              const int* __restrict__ order, const int* __restrict__ offsets,
+                                                                              float* __restrict__ grad_points) {
+    for (long sp = blockIdx.x * (long)blockDim.x + threadIdx.x; sp < total; sp += (long)gridDim.x * blockDim.x) {
+        const int scene = (int)(sp / n), p = (int)(sp - (long)scene * n);
+        const int* off = offsets + (size_t)scene * (n + 1);
+        const int e0 = off[p], e1 = off[p + 1];
+        const int* ord = order + (size_t)scene * m_ns;
+        const float* gs = grad_out + (size_t)scene * m_ns * ld + col0;
+        float acc[8];
+#pragma unroll
+        for (int l = 0; l < 8; ++l) acc[l] = 0.f;
+        for (int e = e0; e < e1; ++e) {
+            const float* row = gs + (size_t)ord[e] * ld;
+#pragma unroll
+            for (int l = 0; l < 8; ++l) if (l < c) acc[l] += row[l];
+        }
+        float* o = grad_points + (size_t)sp * c;
+#pragma unroll
+        for (int l = 0; l < 8; ++l) if (l < c) o[l] = acc[l];
+    }
+}
 extern "C" int gspn_sa_group_concat_grad_csr(int b, int n, int c, int m, int nsample, const int* order, const int* offsets, int xyz_first, int ld_out,
                                              const float* grad_out, float* grad_points, void* stream) {
     if (b < 0 || n <= 0 || c <= 0 || m < 0 || nsample < 0 || ld_out < (xyz_first ? 3 : 0) + c || !order || !offsets) return GSPN_ERR_ARG;
     if (b == 0) return 0;
+    if (c <= 8 && grad_out && grad_points) {
+        const long total = (long)b * n;
+        hipLaunchKernelGGL(sa_group_concat_grad_csr_narrow_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, total, n, c, m * nsample,
+                           xyz_first ? 3 : 0, ld_out, grad_out, order, offsets, grad_points);
+        return gspn_launch_status();
+    }
     if (!xyz_first && grad_out && grad_points) {                     // sixteen lanes per data point (csr_gather.h); same sums, same order
         const CsrCopy cp{nullptr, nullptr, 0, 0, 0, 0};
         const int rc = csr_gather16(false, b, n, m * nsample, (long)m * nsample, c, ld_out, 0, grad_out, order, offsets, nullptr, grad_points, cp, (hipStream_t)stream);
