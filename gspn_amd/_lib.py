@@ -87,6 +87,7 @@ SIGNATURES = {
     "gspn_mlp_bwd_data_ex": [_L, _I, _I, _c.POINTER(DyArgs), _P, _I, _I, _P, _I, _P, _I, _P, _P, _F, _I, _I, _P, _P,
                              _P, _I, _P, _P, _P, _P, _F, _P, _c.POINTER(_I), _P],
     "gspn_mlp_bwd_fused": [_L, _I, _I, _c.POINTER(DyArgs), _P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _F, _P, _c.POINTER(_I), _P],
+    "gspn_mlp_bwd_fused_coef": [_L, _I, _I, _c.POINTER(DyArgs), _P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _F, _P, _c.POINTER(_I), _P, _P, _P, _P, _P, _P, _P, _P],
     "gspn_bn_finalize": [_L, _I, _P, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P],
     "gspn_bn_finalize_parts": [_L, _I, _P, _I, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P],
     "gspn_bn_finalize_parts_pivot": [_L, _I, _P, _I, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P, _P],

@@ -2609,13 +2609,33 @@ extern "C" int gspn_dense_rsum(long rows, int c, const float* dZ, int ldz, const
     *nparts_out = (int)nblk;
     return gspn_launch_status();
 }
+struct CoefJob {
+    long rows; int c, nparts; const float* part; const float* mean; const float* var; const float* gamma; float eps;
+    float *cA, *cB, *cC, *dgamma, *dbeta, *dbias;
+};
+__device__ __forceinline__ void bwd_coef_block(const CoefJob& q, int n, double (*sh)[4]);
 __global__ __launch_bounds__(256) void bwd_coef_kernel(long rows, int c, int nparts, const float* __restrict__ part, const float* __restrict__ mean,
                                                        const float* __restrict__ var, const float* __restrict__ gamma, float eps,
                                                        float* __restrict__ cA, float* __restrict__ cB, float* __restrict__ cC,
                                                        float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dbias) {
     __shared__ double sh[2][4];
+    const CoefJob q{rows, c, nparts, part, mean, var, gamma, eps, cA, cB, cC, dgamma, dbeta, dbias};
+    bwd_coef_block(q, blockIdx.x, sh);
+}
+// r04: the coefficient kernel of the PREVIOUS layer and the dW reduction of THIS layer both depend on the fused backward launch only and
+// on nothing else: one launch of c + nblk workgroups instead of two dependent ~3.5 us kernels (gspn_mlp_bwd_fused_coef)
+__global__ __launch_bounds__(256) void bwd_coef_dw_kernel(CoefJob q, DwJob j) {
+    __shared__ double sh[2 * 4 * DW_OX];
+    if ((int)blockIdx.x < q.c) bwd_coef_block(q, blockIdx.x, reinterpret_cast<double (*)[4]>(sh));
+    else wgrad_dw_block<256>(j, blockIdx.x - (unsigned)q.c, sh);
+}
+__device__ __forceinline__ void bwd_coef_block(const CoefJob& q, int n, double (*sh)[4]) {
+    const long rows = q.rows; const int c = q.c, nparts = q.nparts;
+    const float* __restrict__ part = q.part; const float* __restrict__ mean = q.mean; const float* __restrict__ var = q.var; const float* __restrict__ gamma = q.gamma;
+    const float eps = q.eps;
+    float* __restrict__ cA = q.cA; float* __restrict__ cB = q.cB; float* __restrict__ cC = q.cC;
+    float* __restrict__ dgamma = q.dgamma; float* __restrict__ dbeta = q.dbeta; float* __restrict__ dbias = q.dbias;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int n = blockIdx.x;
     double a0 = 0.0, a1 = 0.0;
     for (int p = t; p < nparts; p += 256) { a0 += (double)part[(size_t)p * 2 * c + n]; a1 += (double)part[(size_t)p * 2 * c + c + n]; }
     a0 = wave_sum_f64(a0); a1 = wave_sum_f64(a1);
@@ -3832,9 +3852,9 @@ extern "C" long gspn_mlp_bwd_fused_work_bytes(long rows, int cin, int cout) {
 //   dX (rows, ldx >= cin) = dY . W^T
 //   part (optional, with Xp's layer statistics): the BN reductions of dX against Xp, as gspn_mlp_bwd_data_ex leaves them; *nparts_out rows
 // GSPN_ERR_UNSUPPORTED for every shape outside the kernel's own (the caller then runs pass A and pass B).
-extern "C" int gspn_mlp_bwd_fused(long rows, int cin, int cout, const gspn_dy_args* a, const float* W, const float* Xp, int ldxp, const float* in_scale,
-                                  const float* in_shift, float* dX, int ldx, float* work, float* dW, const float* mean_p, const float* var_p,
-                                  float eps_p, float* part, int* nparts_out, void* stream) {
+static int bwd_fused_impl(long rows, int cin, int cout, const gspn_dy_args* a, const float* W, const float* Xp, int ldxp, const float* in_scale,
+                          const float* in_shift, float* dX, int ldx, float* work, float* dW, const float* mean_p, const float* var_p,
+                          float eps_p, float* part, int* nparts_out, void* stream, CoefJob* cj) {
     if (rows <= 0 || cin <= 0 || cout <= 0 || !a || !a->Y || !a->scale || !a->shift || !W || !Xp || !dX || !work || !dW || ldxp < cin || ldx < cin)
         return GSPN_ERR_ARG;
     if (part && (!mean_p || !var_p || !nparts_out)) return GSPN_ERR_ARG;
@@ -3871,8 +3891,28 @@ extern "C" int gspn_mlp_bwd_fused(long rows, int cin, int cout, const gspn_dy_ar
     if (nparts_out) *nparts_out = (int)g;
     DwJob j = dw_job(rows, cin, cout, (long)g, PP, nullptr, nullptr, nullptr, nullptr, 0.f, 0, 0, dW);
     j.plain = 1;
+    if (cj) {                                                      // the previous layer's coefficients from `part` + this layer's dW reduction: one launch
+        cj->nparts = (int)g;
+        hipLaunchKernelGGL(bwd_coef_dw_kernel, dim3((unsigned)(cj->c + j.nblk)), dim3(256), 0, st, *cj, j);
+        return gspn_launch_status();
+    }
     hipLaunchKernelGGL(wgrad_dw_kernel, dim3((unsigned)dw_blocks((long)cin * cout, g, 1024)), dim3(1024), 0, st, j);
     return gspn_launch_status();
+}
+extern "C" int gspn_mlp_bwd_fused(long rows, int cin, int cout, const gspn_dy_args* a, const float* W, const float* Xp, int ldxp, const float* in_scale,
+                                  const float* in_shift, float* dX, int ldx, float* work, float* dW, const float* mean_p, const float* var_p,
+                                  float eps_p, float* part, int* nparts_out, void* stream) {
+    return bwd_fused_impl(rows, cin, cout, a, W, Xp, ldxp, in_scale, in_shift, dX, ldx, work, dW, mean_p, var_p, eps_p, part, nparts_out, stream, nullptr);
+}
+// gspn_mlp_bwd_fused followed by gspn_mlp_bwd_coef of the PREVIOUS layer (its cin channels: batch statistics mean_p / var_p, gamma_p; outputs
+// cA_p .. dbias_p as gspn_mlp_bwd_coef writes them) with this layer's dW reduction in the same second launch.  part / nparts_out required.
+extern "C" int gspn_mlp_bwd_fused_coef(long rows, int cin, int cout, const gspn_dy_args* a, const float* W, const float* Xp, int ldxp, const float* in_scale,
+                                       const float* in_shift, float* dX, int ldx, float* work, float* dW, const float* mean_p, const float* var_p,
+                                       float eps_p, float* part, int* nparts_out, const float* gamma_p, float* cA_p, float* cB_p, float* cC_p,
+                                       float* dgamma_p, float* dbeta_p, float* dbias_p, void* stream) {
+    if (!part || !nparts_out || !mean_p || !var_p || !cA_p || !cB_p || !cC_p) return GSPN_ERR_ARG;
+    CoefJob cj{rows, cin, 0, part, mean_p, var_p, gamma_p, eps_p, cA_p, cB_p, cC_p, dgamma_p, dbeta_p, dbias_p};
+    return bwd_fused_impl(rows, cin, cout, a, W, Xp, ldxp, in_scale, in_shift, dX, ldx, work, dW, mean_p, var_p, eps_p, part, nparts_out, stream, &cj);
 }
 static int bwd_data_launch(long rows, int cin, int cout, const gspn_dy_args* a, const float* W, int col0, int ncols, float* dX, int ldx, const DwJob* dwj,
                            hipStream_t st, const RsumArgs* rsp = nullptr, int* nparts_out = nullptr) {

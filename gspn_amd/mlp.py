@@ -38,7 +38,8 @@ FUSE_DW = os.environ.get("GSPN_FUSE_DW", "1") != "0"
 # pass A and pass B of a layer in one launch where the library has the kernel for the shape (gspn_mlp_bwd_fused: both products from one staged
 # dY tile); the library's own switch is GSPN_BWD_FUSED
 FUSED_BWD = os.environ.get("GSPN_FUSED_BWD", "1") != "0"
-POOLTOP_FUSED = os.environ.get("GSPN_POOLTOP_FUSED", "1") != "0"       # the pooled (nsample = 32) top layer through the fused launch as well
+POOLTOP_FUSED = os.environ.get("GSPN_POOLTOP_FUSED", "1") != "0"
+FUSED_COEF = os.environ.get("GSPN_FUSED_COEF", "1") != "0"          # r04: the coefficient kernel after a fused launch carries that launch's dW reduction       # the pooled (nsample = 32) top layer through the fused launch as well
 # the top layer of a stack with a dense upstream gradient takes its BN reductions in a streaming pre-pass (gspn_dense_rsum) from this many rows on
 DENSE_TOP_RSUM = os.environ.get("GSPN_DENSE_TOP_RSUM", "1") != "0"
 DENSE_TOP_MIN_ROWS = int(os.environ.get("GSPN_DENSE_TOP_MIN_ROWS", "65536"))
@@ -341,16 +342,29 @@ class _MlpStack(torch.autograd.Function):
                     part = torch.empty(int(lib.gspn_rsum_part_floats(rows, cin)), dtype=torch.float32, device=dev) if want_rsum else None
                     npart = ctypes.c_int(0)
                     ev = _tic()
+                    merged = None
                     try:
-                        L.check(lib.gspn_mlp_bwd_fused(rows, cin, cout, ctypes.byref(a), L.ptr(lp.weights), L.ptr(xin), xld, L.ptr(in_scale), L.ptr(in_shift),
-                                                       L.ptr(dx), cin, L.ptr(work), L.ptr(dW), L.ptr(pmean), L.ptr(pvar), BN_EPS, L.ptr(part),
-                                                       ctypes.byref(npart), st), "mlp_bwd_fused")
+                        if want_rsum and sw == 1 and FUSED_COEF:
+                            # the previous layer's coefficient kernel and this layer's dW reduction depend on the fused launch only: one launch
+                            pc = [torch.empty(cin, dtype=torch.float32, device=dev) for _ in range(3)]
+                            pg = torch.empty((3, cin), dtype=torch.float32, device=dev)
+                            L.check(lib.gspn_mlp_bwd_fused_coef(rows, cin, cout, ctypes.byref(a), L.ptr(lp.weights), L.ptr(xin), xld, L.ptr(in_scale),
+                                                                L.ptr(in_shift), L.ptr(dx), cin, L.ptr(work), L.ptr(dW), L.ptr(pmean), L.ptr(pvar), BN_EPS,
+                                                                L.ptr(part), ctypes.byref(npart), L.ptr(prev.gamma), L.ptr(pc[0]), L.ptr(pc[1]), L.ptr(pc[2]),
+                                                                L.ptr(pg[0]), L.ptr(pg[1]), L.ptr(pg[2]), st), "mlp_bwd_fused_coef")
+                            merged = (pc[0], pc[1], pc[2], pg[0], pg[1], pg[2])
+                        else:
+                            L.check(lib.gspn_mlp_bwd_fused(rows, cin, cout, ctypes.byref(a), L.ptr(lp.weights), L.ptr(xin), xld, L.ptr(in_scale), L.ptr(in_shift),
+                                                           L.ptr(dx), cin, L.ptr(work), L.ptr(dW), L.ptr(pmean), L.ptr(pvar), BN_EPS, L.ptr(part),
+                                                           ctypes.byref(npart), st), "mlp_bwd_fused")
                         fused = True
                     except NotImplementedError:
                         fused = False
                     if fused:
                         _toc(ev, "fused", rows, cin, cout, 4.0 * rows * cin * cout)
-                        if want_rsum:
+                        if merged is not None:
+                            coef[li - 1] = merged
+                        elif want_rsum:
                             coef[li - 1] = _coef_from_parts(lib, rows, cin, npart.value, part, pmean, pvar, prev, dev, st, sw)
                         g = [dW, dbias]
                         if lp.bn:

@@ -35,7 +35,7 @@ extern "C" {
  *   3: round 3 (gspn_sa_rel_shift, gspn_bn_apply, gspn_mlp_gemm_*, status word of the multi-CU FPS checked).
  *   4: round 3 (gspn_mlp_bwd_fused, gspn_mlp_bwd_fused_work_bytes).   5: round 3 (gspn_dense_rsum; the fused launch's pooled form).
  *   6: round 3 (gspn_fps_cells_prepass_order, gspn_bn_colsum / gspn_bn_apply_grad of tf_util's stand-alone batch norm).
- *   7: round 4 (gspn_nmdistance_grad_csr, gspn_bn_finalize_parts_pivot; gspn_queryballpoint now launches a prefix scan + a continuation kernel -- same output). */
+ *   7: round 4 (gspn_nmdistance_grad_csr, gspn_bn_finalize_parts_pivot, gspn_mlp_bwd_fused_coef; gspn_queryballpoint now launches a prefix scan + a continuation kernel -- same output). */
 #define GSPN_ABI_VERSION 7
 int gspn_dist_policy(void);
 int gspn_abi_version(void);
@@ -389,6 +389,12 @@ long gspn_mlp_bwd_fused_work_bytes(long rows, int cin, int cout);
 int gspn_mlp_bwd_fused(long rows, int cin, int cout, const gspn_dy_args* a, const float* W, const float* Xp, int ldxp, const float* in_scale,
                        const float* in_shift, float* dX, int ldx, float* work, float* dW, const float* mean_p, const float* var_p,
                        float eps_p, float* part, int* nparts_out, void* stream);
+/* gspn_mlp_bwd_fused + gspn_mlp_bwd_coef of the PREVIOUS layer (cin channels; gamma_p and the outputs as gspn_mlp_bwd_coef takes them) with this
+ * layer's dW reduction riding in the coefficient launch: two launches instead of three (r04).  part / nparts_out / mean_p / var_p required. */
+int gspn_mlp_bwd_fused_coef(long rows, int cin, int cout, const gspn_dy_args* a, const float* W, const float* Xp, int ldxp, const float* in_scale,
+                            const float* in_shift, float* dX, int ldx, float* work, float* dW, const float* mean_p, const float* var_p,
+                            float eps_p, float* part, int* nparts_out, const float* gamma_p, float* cA_p, float* cB_p, float* cC_p,
+                            float* dgamma_p, float* dbeta_p, float* dbias_p, void* stream);
 
 /* Pre-aggregated first layer of an SA / FP module (gspn_amd/csrc/mlp.hip, "Pre-aggregated first layer"): the layer is linear, so its
  * feature part is multiplied on the SOURCE points (F = feat.W_feat, a small GEMM through gspn_mlp_fwd) and the grouped / interpolated
