@@ -45,7 +45,7 @@ template <int CPL, bool WEIGHTED>
 __global__ __launch_bounds__(256) void csr_gather16_kernel(int nt, int L, long src_scene_floats, int ld, int col0, const float* __restrict__ src,
                                                            const int* __restrict__ order, const int* __restrict__ offsets,
                                                            const float* __restrict__ weight, float* __restrict__ out, long ntot, long part,
-                                                           unsigned gather_blocks, CsrCopy cp) {
+                                                           unsigned gather_blocks, CsrCopy cp, int chunks) {
     constexpr int U = CPL == 1 ? GSPN_CSR_U1 : (CPL == 2 ? GSPN_CSR_U1 / 2 : GSPN_CSR_U1 / 4);          // list entries whose row loads are issued together
     if (blockIdx.x >= gather_blocks) {
         const long nthreads = (long)(gridDim.x - gather_blocks) * 256;
@@ -57,15 +57,19 @@ __global__ __launch_bounds__(256) void csr_gather16_kernel(int nt, int L, long s
         return;
     }
     const int q = threadIdx.x & 15, sub = threadIdx.x >> 4;
+    // a work item = (target, chunk of 64 * CPL channels); `chunks` > 1 spreads a wide row over several 16-lane rows, each with its own
+    // loads in flight (CPL = 1 then: 8 per lane) -- the walks are latency-bound, so more rows in flight beat fewer, fatter loads
     const long lt = (long)(blockIdx.x >> 3) * 16 + sub;
-    const long tg = (long)(blockIdx.x & 7) * part + lt;
-    if (lt >= part || tg >= ntot) return;                         // (whole 16-lane rows leave together: the DPP moves below stay inside live rows)
+    const long it = (long)(blockIdx.x & 7) * part + lt;
+    if (lt >= part || it >= ntot * chunks) return;               // (whole 16-lane rows leave together: the DPP moves below stay inside live rows)
+    const long tg = it / chunks;
+    const int ch = (int)(it - tg * chunks);
     const int s = (int)(tg / nt), j = (int)(tg - (long)s * nt);
     const int* off = offsets + (size_t)s * (nt + 1);
     const int e0 = off[j], e1 = off[j + 1];
     const int* ord = order + (size_t)s * L;
     const float* w = WEIGHTED ? weight + (size_t)s * L : nullptr;
-    const char* gs = reinterpret_cast<const char*>(src + (size_t)s * src_scene_floats + col0 + 4 * q);
+    const char* gs = reinterpret_cast<const char*>(src + (size_t)s * src_scene_floats + col0 + 64 * CPL * ch + 4 * q);
     float4 acc[CPL];
 #pragma unroll
     for (int h = 0; h < CPL; ++h) acc[h] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -120,7 +124,7 @@ __global__ __launch_bounds__(256) void csr_gather16_kernel(int nt, int L, long s
         ob = obn;
         wt = wtn;
     }
-    float* o = out + (size_t)tg * (64 * CPL) + 4 * q;
+    float* o = out + ((size_t)tg * chunks + ch) * (64 * CPL) + 4 * q;
 #pragma unroll
     for (int h = 0; h < CPL; ++h) *reinterpret_cast<float4*>(o + 64 * h) = acc[h];
 }
@@ -135,7 +139,9 @@ static int csr_gather16(bool weighted, int b, int nt, int L, long src_rows_per_s
     if ((ld & 3) || (col0 & 3) || ((uintptr_t)src % 16) || ((uintptr_t)out % 16)) return GSPN_ERR_UNSUPPORTED;
     if (src_rows_per_scene * (long)ld * 4 >= (1L << 31)) return GSPN_ERR_UNSUPPORTED;
     const long ntot = (long)b * nt;
-    const long part = ((ntot + 7) / 8 + 15) / 16 * 16;            // targets per XCD slice, whole workgroups
+    static const int wide = getenv("GSPN_CSR_WIDE") ? atoi(getenv("GSPN_CSR_WIDE")) : 0;      // (A/B hook: 1 = one 16-lane row per target whatever its width)
+    const int chunks = (!wide && c == 128) ? 2 : 1;              // measured (tools/r04_gather_family.py): 128 channels as two rows 13.5 -> 9.0 us; 256 as four 7.8 -> 9.7
+    const long part = ((ntot * chunks + 7) / 8 + 15) / 16 * 16;   // work items per XCD slice, whole workgroups
     const long gb = 8 * (part / 16);
     long cb = 0;
     if (cp.total > 0) {
@@ -145,9 +151,9 @@ static int csr_gather16(bool weighted, int b, int nt, int L, long src_rows_per_s
     if (gb + cb > 0x7FFFFFFFl) return GSPN_ERR_UNSUPPORTED;
     const dim3 grid((unsigned)(gb + cb));
     const long ssf = src_rows_per_scene * (long)ld;
-#define CSR_GO(CPL_, W_) hipLaunchKernelGGL((csr_gather16_kernel<CPL_, W_>), grid, dim3(256), 0, st, nt, L, ssf, ld, col0, src, order, offsets, weight, out, ntot, part, (unsigned)gb, cp)
-    if (weighted) { if (c == 64) CSR_GO(1, true); else if (c == 128) CSR_GO(2, true); else CSR_GO(4, true); }
-    else { if (c == 64) CSR_GO(1, false); else if (c == 128) CSR_GO(2, false); else CSR_GO(4, false); }
+#define CSR_GO(CPL_, W_) hipLaunchKernelGGL((csr_gather16_kernel<CPL_, W_>), grid, dim3(256), 0, st, nt, L, ssf, ld, col0, src, order, offsets, weight, out, ntot, part, (unsigned)gb, cp, chunks)
+    if (weighted) { if (c == 64 || chunks > 1) CSR_GO(1, true); else if (c == 128) CSR_GO(2, true); else CSR_GO(4, true); }
+    else { if (c == 64 || chunks > 1) CSR_GO(1, false); else if (c == 128) CSR_GO(2, false); else CSR_GO(4, false); }
 #undef CSR_GO
     return gspn_launch_status();
 }
