@@ -165,7 +165,14 @@ def main():
         @staticmethod
         def forward(ctx, out, g):
             ctx.g = g
-            return torch.dot(out.reshape(-1), g.reshape(-1))
+            from gspn_amd import _lib as L
+            if not out.is_contiguous():
+                out = out.contiguous()
+            if "dot_work" not in state:
+                state["dot_work"] = torch.empty(int(L.lib().gspn_dot_work_floats()), dtype=torch.float32, device=out.device)
+            res = torch.empty((), dtype=torch.float32, device=out.device)
+            L.check(L.lib().gspn_dot(out.numel(), L.ptr(out), L.ptr(g), L.ptr(state["dot_work"]), L.ptr(res), L.stream()), "dot")     # (hand-written: no library kernel in the step)
+            return res
 
         @staticmethod
         def backward(ctx, grad):

@@ -108,6 +108,7 @@ SIGNATURES = {
     "gspn_multi_copy": [_I, _P, _P, _P, _P],
     "gspn_three_nn_weights": [_L, _P, _P, _P],
     "gspn_adam_flat": [_L, _P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _L, _P],
+    "gspn_dot": [_L, _P, _P, _P, _P, _P],
     "gspn_fill_zero": [_P, _L, _P],
 }
 
@@ -126,6 +127,7 @@ SPECIAL = {
     "gspn_preagg_fwd_parts": ([_L, _I], _L),
     "gspn_pooltop_scratch_floats": ([_L, _I, _I], _L),
     "gspn_inverse_lists_work_ints": ([_I, _I, _I], _L),
+    "gspn_dot_work_floats": ([], _L),
 }
 
 ABI_VERSION = 7         # == GSPN_ABI_VERSION of include/gspn_hip.h this binding was written against

@@ -31,3 +31,43 @@ extern "C" int gspn_adam_flat(long n, float* p, const float* g, float* m, float*
                        (float)sqrt(bc2), weight_decay, grad_scale);
     return gspn_launch_status();
 }
+
+// <a, b> over n floats, deterministic: DOT_BLOCKS workgroups leave one partial each (per-thread sums in grid-stride order, wave shuffle tree,
+// one LDS hop), a second tiny launch adds the partials in index order, in double.  The loss of a training step as a product with a constant
+// tensor (bench.py) -- two streams at HBM rate instead of a library reduction.  work: DOT_BLOCKS floats.
+#define DOT_BLOCKS 1024
+__global__ __launch_bounds__(256) void dot_partial_kernel(long n4, long n, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ part) {
+    __shared__ float sw[4];
+    float s = 0.f;
+    const float4* a4 = reinterpret_cast<const float4*>(a);
+    const float4* b4 = reinterpret_cast<const float4*>(b);
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const float4 x = a4[i], y = b4[i];
+        s += x.x * y.x; s += x.y * y.y; s += x.z * y.z; s += x.w * y.w;
+    }
+    if (blockIdx.x == 0) for (long i = 4 * n4 + threadIdx.x; i < n; i += 256) s += a[i] * b[i];          // tail
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) s += __shfl_xor(s, sft, 64);
+    if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (sw[0] + sw[1]) + (sw[2] + sw[3]);
+}
+__global__ __launch_bounds__(64) void dot_final_kernel(int nparts, const float* __restrict__ part, float* __restrict__ out) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 64) s += (double)part[i];
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) s += __shfl_xor(s, sft, 64);
+    if (threadIdx.x == 0) out[0] = (float)s;
+}
+extern "C" long gspn_dot_work_floats(void) { return DOT_BLOCKS; }
+extern "C" int gspn_dot(long n, const float* a, const float* b, float* work, float* out, void* stream) {
+    if (n < 0 || !out || !work || (n > 0 && (!a || !b))) return GSPN_ERR_ARG;
+    const bool vec = (((uintptr_t)a | (uintptr_t)b) & 15) == 0;
+    const long n4 = vec ? n / 4 : 0;
+    long nb = (n4 + 255) / 256;
+    nb = nb < 1 ? 1 : (nb > DOT_BLOCKS ? DOT_BLOCKS : nb);
+    hipLaunchKernelGGL(dot_partial_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, n4, n, a, b, work);
+    hipLaunchKernelGGL(dot_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (int)nb, work, out);
+    return gspn_launch_status();
+}
+

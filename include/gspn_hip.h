@@ -35,7 +35,7 @@ extern "C" {
  *   3: round 3 (gspn_sa_rel_shift, gspn_bn_apply, gspn_mlp_gemm_*, status word of the multi-CU FPS checked).
  *   4: round 3 (gspn_mlp_bwd_fused, gspn_mlp_bwd_fused_work_bytes).   5: round 3 (gspn_dense_rsum; the fused launch's pooled form).
  *   6: round 3 (gspn_fps_cells_prepass_order, gspn_bn_colsum / gspn_bn_apply_grad of tf_util's stand-alone batch norm).
- *   7: round 4 (gspn_nmdistance_grad_csr, gspn_bn_finalize_parts_pivot, gspn_mlp_bwd_fused_coef; gspn_queryballpoint now launches a prefix scan + a continuation kernel -- same output). */
+ *   7: round 4 (gspn_nmdistance_grad_csr, gspn_bn_finalize_parts_pivot, gspn_mlp_bwd_fused_coef, gspn_dot; gspn_queryballpoint now launches a prefix scan + a continuation kernel -- same output). */
 #define GSPN_ABI_VERSION 7
 int gspn_dist_policy(void);
 int gspn_abi_version(void);
@@ -468,6 +468,10 @@ int gspn_multi_copy(int n, const void* const* src, void* const* dst, const long*
  * this update.  One launch for the whole model. */
 int gspn_adam_flat(long n, float* p, const float* g, float* m, float* v, float lr, float b1, float b2, float eps, float weight_decay,
                    float grad_scale, long step, void* stream);
+
+/* out[0] = <a, b> over n floats, deterministic (1024 per-workgroup partials added in index order, in double).  work: gspn_dot_work_floats() floats. */
+long gspn_dot_work_floats(void);
+int gspn_dot(long n, const float* a, const float* b, float* work, float* out, void* stream);
 
 int gspn_fill_zero(void* ptr, long bytes, void* stream);
 

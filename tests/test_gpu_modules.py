@@ -450,3 +450,25 @@ def test_flat_adam_matches_torch_adam():
     for p_, q_ in zip(pa, pb):
         assert q_.data_ptr() >= opt.flat.data_ptr() and q_.data_ptr() < opt.flat.data_ptr() + opt.flat.numel() * 4
         assert rel_err(q_.detach(), p_.detach()) < 2e-6
+
+
+@pytest.mark.parametrize("n", [1, 3, 4096, 1_000_003, 16_777_216])
+def test_dot_kernel_is_deterministic_and_close_to_float64(n):
+    """gspn_dot (r04: the bench's loss <out, g> on the library's own kernel instead of a library reduction): two launches, 1024 partials added
+    in index order in double -- the same bits on every call, 1e-6 of the float64 product sum; unaligned operands take the scalar tail"""
+    from gspn_amd import _lib as L
+    g = torch.Generator(device="cuda").manual_seed(n)
+    a = torch.randn(n + 1, device="cuda", generator=g)[1:]          # 4-byte aligned only
+    b = torch.randn(n, device="cuda", generator=g)
+    w = torch.empty(int(L.lib().gspn_dot_work_floats()), device="cuda")
+    outs = []
+    for x in (a, a.clone()):                                         # unaligned / aligned copies of the same data
+        for _ in range(2):
+            o = torch.empty((), device="cuda")
+            L.check(L.lib().gspn_dot(n, L.ptr(x), L.ptr(b), L.ptr(w), L.ptr(o), L.stream()), "dot")
+            outs.append(o.clone())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[2], outs[3])
+    ref = (a.double() * b.double()).sum()
+    scale = (a.double() * b.double()).abs().sum() + 1e-30
+    for o in outs:
+        assert float((o.double() - ref).abs() / scale) < 1e-6
