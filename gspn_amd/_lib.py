@@ -48,6 +48,7 @@ SIGNATURES = {
     "gspn_scatteraddpoint": [_I, _I, _I, _P, _P, _P, _P],
     "gspn_probsample": [_I, _I, _I, _P, _P, _P, _P, _P],
     "gspn_queryballpoint": [_I, _I, _I, _F, _I, _P, _P, _P, _P, _P],
+    "gspn_queryballpoint_ws": [_I, _I, _I, _F, _I, _P, _P, _P, _P, _P, _P],
     "gspn_queryballpoint_lds": [_I, _I, _I, _F, _I, _P, _P, _P, _P, _P],
     "gspn_selectionsort": [_I, _I, _I, _I, _P, _P, _P, _P],
     "gspn_knn_point": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
@@ -128,6 +129,7 @@ SPECIAL = {
     "gspn_pooltop_scratch_floats": ([_L, _I, _I], _L),
     "gspn_inverse_lists_work_ints": ([_I, _I, _I], _L),
     "gspn_dot_work_floats": ([], _L),
+    "gspn_ball_ws_bytes": ([_I, _I, _I], _L),
 }
 
 ABI_VERSION = 7         # == GSPN_ABI_VERSION of include/gspn_hip.h this binding was written against

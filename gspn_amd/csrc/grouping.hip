@@ -31,13 +31,14 @@
 // its hits so far in row[0 .. cnt), cnt (< nsample) in pts_cnt, no padding -- for ball_query_cont_kernel to resume at n_scan.
 __global__ __launch_bounds__(BQ_WAVES * 64) void ball_query_kernel(int b, int n, int m, int n_scan, float thresh, int nsample,
                                                                   const float* __restrict__ xyz1, const float* __restrict__ xyz2,
-                                                                  int* __restrict__ idx, int* __restrict__ pts_cnt) {
+                                                                  int* __restrict__ idx, int* __restrict__ pts_cnt, const unsigned char* __restrict__ resolved) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int scene = blockIdx.x % b;            // scene <-> XCD affinity
     const int chunk = blockIdx.x / b;
     const int j = chunk * BQ_WAVES + wave;
     if (j >= m) return;
+    if (resolved && resolved[(size_t)scene * m + j]) return;      // answered by the cell-grid kernel (sparse clouds)
     const float* data = xyz1 + (size_t)scene * n * 3;
     const float* qp = xyz2 + ((size_t)scene * m + j) * 3;
     int* row = idx + ((size_t)scene * m + j) * nsample;
@@ -99,14 +100,14 @@ __global__ __launch_bounds__(BQ_WAVES * 64) void ball_query_kernel(int b, int n,
 #endif
 __global__ __launch_bounds__(BQM_WAVES * 64) void ball_query_cont_kernel(int b, int n, int m, int n0, float thresh, int nsample,
                                                                         const float* __restrict__ xyz1, const float* __restrict__ xyz2,
-                                                                        int* __restrict__ idx, int* __restrict__ pts_cnt) {
+                                                                        int* __restrict__ idx, int* __restrict__ pts_cnt, const unsigned char* __restrict__ resolved) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int scene = blockIdx.x % b;
     const int j0 = ((blockIdx.x / b) * BQM_WAVES + wave) * BQM_QW;
     const float* data = xyz1 + (size_t)scene * n * 3;
     float qx = 0.f, qy = 0.f, qz = 0.f;
     int cnt = nsample, first = 0;
-    if (lane < BQM_QW && j0 + lane < m) {
+    if (lane < BQM_QW && j0 + lane < m && !(resolved && resolved[(size_t)scene * m + j0 + lane])) {
         const size_t qi = (size_t)scene * m + j0 + lane;
         qx = xyz2[qi * 3 + 0]; qy = xyz2[qi * 3 + 1]; qz = xyz2[qi * 3 + 2];
         cnt = pts_cnt[qi];
@@ -213,6 +214,209 @@ static float ball_threshold(float radius) {
 // exported so the host-side threshold search can be tested without a GPU
 extern "C" float gspn_ball_threshold(float radius) { return ball_threshold(radius); }
 
+// ============================================================================================
+// Ball query through a cell grid over the DATA points -- the sparse regime (r04).  On room scenes at the model's radii a ball holds
+// fewer than nsample points, so the reference's scan reads the whole cloud for most queries (170 us at 8 x 32768 <- 2048 even with the
+// continuation kernel above).  When few points are inside a ball, "the first nsample hits in index order" is "ALL hits, sorted by index":
+//   build  (one workgroup per scene) bounding box, cells of edge >= 1.01 r (<= 32 per axis), counting sort of the points by cell in LDS:
+//          cell_start[] and the points as (x, y, z, index) in cell order -- and the decision whether the cloud is sparse at all: with the
+//          volumetric estimate n * (4/3 pi r^3) / box volume >= 8 nsample (a dense cloud: the scan's early exit wins there) the
+//          grid is not used and the sort is skipped;
+//   query  (one wave per query) the 3 x 3 x 3 block of cells around the query's cell holds every point closer than r: nine contiguous
+//          runs of the sorted array, fetched 64 candidates per load; the reference's test (dist2_cuda < T, bit-exact, see above) picks the
+//          hits, a ballot appends their indices to a per-wave LDS list, a rank sort puts them in ascending index order, the first nsample
+//          are the row.  More than BQG_CAP hits or candidates: the query is left to the scan kernels (resolved[q] stays 0).
+// Output identical to the scan (tests/test_gpu_fullsize.py on the S clouds; tools/ball_bench.py compares all kernels).
+// ============================================================================================
+#define BQG_MAXG 32
+#define BQG_CELLS (BQG_MAXG * BQG_MAXG * BQG_MAXG)
+#ifndef BQG_CAP
+#define BQG_CAP 256
+#endif
+//                 // hits a wave sorts; more: the query is dense, the scan's early exit is the better tool
+#ifndef BQG_MAXCAND
+#define BQG_MAXCAND 2048
+#endif
+//            // candidates of a block a wave is willing to test
+struct BallGridHdr { float lo[3]; float inv[3]; int G[3]; int use; int pad[6]; };                  // 64 bytes per scene
+static inline size_t bqg_scene_bytes(int n) {       // per scene: header, cell_start, sorted points; the (b, m) `resolved` bytes follow the b scene blocks
+    return sizeof(BallGridHdr) + ((sizeof(int) * (size_t)(BQG_CELLS + 1) + 15) / 16) * 16 + 16 * (size_t)n;
+}
+#define BQG_PTS_OFF (sizeof(BallGridHdr) + ((sizeof(int) * (size_t)(BQG_CELLS + 1) + 15) / 16) * 16)
+__global__ __launch_bounds__(1024) void ball_grid_build_kernel(int n, int m, float radius, int nsample, const float* __restrict__ xyz1, char* __restrict__ ws, size_t scene_bytes,
+                                                               unsigned char* __restrict__ resolved_all) {
+    extern __shared__ int bg_cnt[];                  // [cells]
+    __shared__ float s_red[6][16];
+    __shared__ int s_wsum[16];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const float* data = xyz1 + (size_t)blockIdx.x * n * 3;
+    char* base = ws + (size_t)blockIdx.x * scene_bytes;
+    BallGridHdr* hdr = reinterpret_cast<BallGridHdr*>(base);
+    int* cell_start = reinterpret_cast<int*>(base + sizeof(BallGridHdr));
+    float4* pts = reinterpret_cast<float4*>(base + BQG_PTS_OFF);
+    unsigned char* resolved = resolved_all + (size_t)blockIdx.x * m;
+    for (int j = t; j < m; j += 1024) resolved[j] = 0;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int k = t; k < n; k += 1024)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { const float v = data[(size_t)k * 3 + a]; lo[a] = fminf(lo[a], v); hi[a] = fmaxf(hi[a], v); }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        for (int sft = 32; sft >= 1; sft >>= 1) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], sft, 64)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], sft, 64)); }
+        if (lane == 0) { s_red[a][wave] = lo[a]; s_red[3 + a][wave] = hi[a]; }
+    }
+    __syncthreads();
+    int G[3];
+    float inv[3];
+    double vol = 1.0;
+    bool finite = true;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = s_red[a][0]; hi[a] = s_red[3 + a][0];
+        for (int w = 1; w < 16; ++w) { lo[a] = fminf(lo[a], s_red[a][w]); hi[a] = fmaxf(hi[a], s_red[3 + a][w]); }
+        const float ext = hi[a] - lo[a];
+        finite = finite && isfinite(ext);
+        int g = (ext > 0.f && isfinite(ext)) ? (int)floorf(ext / (1.01f * radius)) : 1;      // cell edge = ext / g >= 1.01 r
+        g = g < 1 ? 1 : (g > BQG_MAXG ? BQG_MAXG : g);
+        G[a] = g;
+        inv[a] = (ext > 0.f && isfinite(ext)) ? (float)g / ext : 0.f;
+        vol *= (double)fmaxf(ext, radius);
+    }
+    // dense or sparse?  expected points per ball under a uniform density in the box (surfaces hold more than this says: the cap below
+    // catches those queries one by one)
+    const double expect = (double)n * 4.18879 * (double)radius * radius * radius / vol;
+    const int use = (finite && n >= 1024 && expect < 8.0 * nsample) ? 1 : 0;
+    if (t == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { hdr->lo[a] = lo[a]; hdr->inv[a] = inv[a]; hdr->G[a] = G[a]; }
+        hdr->use = use;
+    }
+    if (!use) return;                                // (uniform across the workgroup)
+    const int cells = G[0] * G[1] * G[2];
+    for (int c = t; c < cells; c += 1024) bg_cnt[c] = 0;
+    __syncthreads();
+    auto cell_of = [&](float x, float y, float z) {
+        const int cx = min(max((int)floorf((x - lo[0]) * inv[0]), 0), G[0] - 1);
+        const int cy = min(max((int)floorf((y - lo[1]) * inv[1]), 0), G[1] - 1);
+        const int cz = min(max((int)floorf((z - lo[2]) * inv[2]), 0), G[2] - 1);
+        return (cz * G[1] + cy) * G[0] + cx;
+    };
+    for (int k = t; k < n; k += 1024) atomicAdd(&bg_cnt[cell_of(data[(size_t)k * 3], data[(size_t)k * 3 + 1], data[(size_t)k * 3 + 2])], 1);
+    __syncthreads();
+    {
+        const int per = (cells + 1023) / 1024;
+        int local = 0;
+        for (int c = t * per; c < min((t + 1) * per, cells); ++c) local += bg_cnt[c];
+        int incl = local;
+#pragma unroll
+        for (int sft = 1; sft < 64; sft <<= 1) { const int u = __shfl_up(incl, sft, 64); if (lane >= sft) incl += u; }
+        if (lane == 63) s_wsum[wave] = incl;
+        __syncthreads();
+        int run = incl - local;
+        for (int w = 0; w < wave; ++w) run += s_wsum[w];
+        for (int c = t * per; c < min((t + 1) * per, cells); ++c) { const int v = bg_cnt[c]; cell_start[c] = run; bg_cnt[c] = run; run += v; }
+        if (t == 1023) cell_start[cells] = run;
+    }
+    __syncthreads();
+    for (int k = t; k < n; k += 1024) {
+        const float x = data[(size_t)k * 3], y = data[(size_t)k * 3 + 1], z = data[(size_t)k * 3 + 2];
+        pts[atomicAdd(&bg_cnt[cell_of(x, y, z)], 1)] = make_float4(x, y, z, __int_as_float(k));
+    }
+}
+__global__ __launch_bounds__(256) void ball_grid_query_kernel(int b, int n, int m, float thresh, int nsample, const float* __restrict__ xyz2,
+                                                              char* __restrict__ ws, size_t scene_bytes, int* __restrict__ idx, int* __restrict__ pts_cnt,
+                                                              unsigned char* __restrict__ resolved_all) {
+    __shared__ int s_hits[4][BQG_CAP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int scene = blockIdx.x % b;                // scene <-> XCD affinity for the sorted cloud
+    const int j = (blockIdx.x / b) * 4 + wave;
+    if (j >= m) return;
+    char* base = ws + (size_t)scene * scene_bytes;
+    const BallGridHdr* hdr = reinterpret_cast<const BallGridHdr*>(base);
+    if (!hdr->use) return;
+    const int* cell_start = reinterpret_cast<const int*>(base + sizeof(BallGridHdr));
+    const float4* pts = reinterpret_cast<const float4*>(base + BQG_PTS_OFF);
+    unsigned char* resolved = resolved_all + (size_t)scene * m;
+    const float* qp = xyz2 + ((size_t)scene * m + j) * 3;
+    const float qx = qp[0], qy = qp[1], qz = qp[2];
+    const int G0 = hdr->G[0], G1 = hdr->G[1], G2 = hdr->G[2];
+    const int cx = min(max((int)floorf((qx - hdr->lo[0]) * hdr->inv[0]), 0), G0 - 1);
+    const int cy = min(max((int)floorf((qy - hdr->lo[1]) * hdr->inv[1]), 0), G1 - 1);
+    const int cz = min(max((int)floorf((qz - hdr->lo[2]) * hdr->inv[2]), 0), G2 - 1);
+    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, G0 - 1);
+    // lane r < 9: run r = (dz, dy) of the block; its range of the sorted array (empty when the row is outside the grid)
+    int rs = 0, re = 0;
+    if (lane < 9) {
+        const int yy = cy + (lane % 3) - 1, zz = cz + (lane / 3) - 1;
+        if (yy >= 0 && yy < G1 && zz >= 0 && zz < G2) {
+            const int row = (zz * G1 + yy) * G0;
+            rs = cell_start[row + x0];
+            re = cell_start[row + x1 + 1];
+        }
+    }
+    // exclusive prefix of the run lengths over lanes 0..8
+    const int len = re - rs;
+    int incl = len;
+#pragma unroll
+    for (int sft = 1; sft < 16; sft <<= 1) { const int u = __shfl_up(incl, sft, 64); if (lane >= sft) incl += u; }
+    const int total = __builtin_amdgcn_readlane(incl, 8);
+    if (total > BQG_MAXCAND) return;                 // a crowded block: leave it to the scan
+    int pre[10], st[9];
+#pragma unroll
+    for (int r = 0; r < 9; ++r) { pre[r] = __builtin_amdgcn_readlane(incl - len, r); st[r] = __builtin_amdgcn_readlane(rs, r); }
+    pre[9] = total;
+    int* hits = s_hits[wave];
+    int cnt = 0;
+    for (int t0 = 0; t0 < total; t0 += 64) {
+        const int tt = t0 + lane;
+        bool hit = false;
+        int k = 0;
+        if (tt < total) {
+            int e = 0;
+#pragma unroll
+            for (int r = 0; r < 9; ++r) if (tt >= pre[r] && tt < pre[r + 1]) e = st[r] + (tt - pre[r]);
+            const float4 p = pts[e];
+            hit = dist2_cuda(qx - p.x, qy - p.y, qz - p.z) < thresh;                        // (x2-x1): query minus data, :27
+            k = __float_as_int(p.w);
+        }
+        const unsigned long long mask = __ballot(hit);
+        if (mask != 0ull) {
+            const int pos = cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+            if (hit && pos < BQG_CAP) hits[pos] = k;
+            cnt += __builtin_popcountll(mask);
+        }
+    }
+    if (cnt > BQG_CAP) return;                       // too many for the sort: a dense ball, the scan's early exit handles it
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    int* row = idx + ((size_t)scene * m + j) * nsample;
+    int first = 0;
+    if (cnt <= 64) {
+        const int v = lane < cnt ? hits[lane] : 0x7FFFFFFF;
+        int rank = 0;
+        for (int i = 0; i < cnt; ++i) rank += (__builtin_amdgcn_readlane(v, i) < v) ? 1 : 0;
+        if (lane < cnt && rank < nsample) row[rank] = v;                                      // :33: ascending k, the first nsample
+        const int vmin = wave_max_i32(lane < cnt ? -v : (int)0x80000001);                     // min index = -(max of -v)
+        first = cnt > 0 ? -vmin : 0;
+    } else {
+        int vmin = 0x7FFFFFFF;
+        for (int i = lane; i < cnt; i += 64) {
+            const int v = hits[i];
+            int rank = 0;
+            for (int q = 0; q < cnt; ++q) rank += (hits[q] < v) ? 1 : 0;
+            if (rank < nsample) row[rank] = v;
+            vmin = min(vmin, v);
+        }
+        first = -wave_max_i32(-vmin);
+    }
+    const int c = cnt < nsample ? cnt : nsample;
+    for (int l = c + lane; l < nsample; l += 64) row[l] = first;                              // :29-32 (rows without a hit are zero-filled)
+    if (lane == 0) { pts_cnt[(size_t)scene * m + j] = c; resolved[j] = 1; }
+}
+extern "C" long gspn_ball_ws_bytes(int b, int n, int m) {
+    if (b < 0 || n <= 0 || m < 0) return GSPN_ERR_ARG;
+    return (long)((size_t)b * bqg_scene_bytes(n) + (((size_t)b * m + 15) / 16) * 16);
+}
+
 // LDS-tiled variant (what BASELINE.json's north_star sketches: point tiles staged in LDS, shared by the queries of a workgroup).
 // 8 waves = 8 queries per workgroup walk the data cloud in tiles of BQL_TILE points; a wave stops testing once it has nsample hits,
 // the workgroup stops loading once all of its waves have.  Same output as ball_query_kernel.  Kept as a measured alternative, NOT
@@ -284,26 +488,54 @@ extern "C" int gspn_queryballpoint_lds(int b, int n, int m, float radius, int ns
     return gspn_launch_status();
 }
 
-extern "C" int gspn_queryballpoint(int b, int n, int m, float radius, int nsample, const float* xyz1, const float* xyz2,
-                                   int* idx, int* pts_cnt, void* stream) {
+static int ball_query_impl(int b, int n, int m, float radius, int nsample, const float* xyz1, const float* xyz2, void* ws,
+                           int* idx, int* pts_cnt, void* stream) {
     if (!(radius > 0.0f) || nsample <= 0) return GSPN_ERR_ARG;        // tf_grouping.cpp:101,104
     if (b < 0 || n <= 0 || m < 0) return GSPN_ERR_ARG;
     if (b == 0 || m == 0) return 0;
     const long long blocks = (long long)b * ((m + BQ_WAVES - 1) / BQ_WAVES);
     if (blocks > 0x7FFFFFFFll || (long long)n * 3 > 0x7FFFFFFFll) return GSPN_ERR_UNSUPPORTED;
+    // sparse clouds: the cell grid answers the queries whose ball holds few points, the scan kernels below skip those (resolved[])
+    const unsigned char* resolved = nullptr;
+    static const int cells_on = getenv("GSPN_BALL_CELLS") ? atoi(getenv("GSPN_BALL_CELLS")) : 1;      // (A/B hook)
+    if (ws && cells_on && n >= 8192 && ((uintptr_t)ws % 16) == 0 && nsample <= BQG_CAP) {
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&ball_grid_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(int) * BQG_CELLS));
+            if (ea != hipSuccess) return (int)ea;
+            attr_done = true;
+        }
+        const size_t sb = bqg_scene_bytes(n);
+        unsigned char* res = reinterpret_cast<unsigned char*>((char*)ws + (size_t)b * sb);
+        hipLaunchKernelGGL(ball_grid_build_kernel, dim3(b), dim3(1024), sizeof(int) * BQG_CELLS, (hipStream_t)stream, n, m, radius, nsample, xyz1, (char*)ws, sb, res);
+        hipLaunchKernelGGL(ball_grid_query_kernel, dim3((unsigned)((long long)b * ((m + 3) / 4))), dim3(256), 0, (hipStream_t)stream, b, n, m, ball_threshold(radius), nsample,
+                           xyz2, (char*)ws, sb, idx, pts_cnt, res);
+        resolved = res;
+    }
     // clouds longer than the prefix: wave-per-query scan of the first BQ_PREFIX points (all of a dense cloud's queries end there), then
     // the register-blocked continuation for whatever is still open (GSPN_BALL_PREFIX=0: one pass over the whole cloud, round 3's form)
     static const int prefix = getenv("GSPN_BALL_PREFIX") ? atoi(getenv("GSPN_BALL_PREFIX")) : 8192;
     const int n_scan = (prefix > 0 && n > prefix) ? (prefix + 255) / 256 * 256 : n;
     hipLaunchKernelGGL(ball_query_kernel, dim3((unsigned)blocks), dim3(BQ_WAVES * 64), 0, (hipStream_t)stream,
-                       b, n, m, n_scan, ball_threshold(radius), nsample, xyz1, xyz2, idx, pts_cnt);
+                       b, n, m, n_scan, ball_threshold(radius), nsample, xyz1, xyz2, idx, pts_cnt, resolved);
     if (n_scan < n) {
         const int per_wg = BQM_WAVES * BQM_QW;
         const long long cblocks = (long long)b * ((m + per_wg - 1) / per_wg);
         hipLaunchKernelGGL(ball_query_cont_kernel, dim3((unsigned)cblocks), dim3(BQM_WAVES * 64), 0, (hipStream_t)stream,
-                           b, n, m, n_scan, ball_threshold(radius), nsample, xyz1, xyz2, idx, pts_cnt);
+                           b, n, m, n_scan, ball_threshold(radius), nsample, xyz1, xyz2, idx, pts_cnt, resolved);
     }
     return gspn_launch_status();
+}
+// the drop-in symbol (the reference's argument list: no workspace): prefix scan + continuation
+extern "C" int gspn_queryballpoint(int b, int n, int m, float radius, int nsample, const float* xyz1, const float* xyz2,
+                                   int* idx, int* pts_cnt, void* stream) {
+    return ball_query_impl(b, n, m, radius, nsample, xyz1, xyz2, nullptr, idx, pts_cnt, stream);
+}
+// the same with a workspace of gspn_ball_ws_bytes(b, n, m) bytes (16-byte aligned): sparse clouds are answered through a cell grid over
+// the data points, dense ones (and the queries of a sparse cloud whose ball is crowded) by the scan; identical output
+extern "C" int gspn_queryballpoint_ws(int b, int n, int m, float radius, int nsample, const float* xyz1, const float* xyz2, void* ws,
+                                      int* idx, int* pts_cnt, void* stream) {
+    return ball_query_impl(b, n, m, radius, nsample, xyz1, xyz2, ws, idx, pts_cnt, stream);
 }
 
 // ============================================================================================

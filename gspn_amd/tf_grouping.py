@@ -37,8 +37,14 @@ def query_ball_point(radius, nsample, xyz1, xyz2):
                       EVENT_POOL.pop() if EVENT_POOL else torch.cuda.Event(enable_timing=True))
             ev[0].record()
             PROFILE_BUDGET[0] -= 1
-        L.check(L.lib().gspn_queryballpoint(b, n, m, radius, nsample, L.ptr(xyz1), L.ptr(xyz2), L.ptr(idx), L.ptr(cnt), L.stream()),
-                "query_ball_point")
+        if n >= 8192 and nsample <= 256:
+            # a workspace lets sparse clouds take the cell-grid kernel (grouping.hip: ball_grid_*); dense clouds decide on the device to scan
+            ws = torch.empty(int(L.lib().gspn_ball_ws_bytes(b, n, m)), dtype=torch.uint8, device=xyz1.device)
+            L.check(L.lib().gspn_queryballpoint_ws(b, n, m, radius, nsample, L.ptr(xyz1), L.ptr(xyz2), L.ptr(ws), L.ptr(idx), L.ptr(cnt), L.stream()),
+                    "query_ball_point")
+        else:
+            L.check(L.lib().gspn_queryballpoint(b, n, m, radius, nsample, L.ptr(xyz1), L.ptr(xyz2), L.ptr(idx), L.ptr(cnt), L.stream()),
+                    "query_ball_point")
         if ev is not None:
             ev[1].record()
             PROFILE.append((ev[0], ev[1], b, n, m, radius, nsample))

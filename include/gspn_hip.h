@@ -35,7 +35,7 @@ extern "C" {
  *   3: round 3 (gspn_sa_rel_shift, gspn_bn_apply, gspn_mlp_gemm_*, status word of the multi-CU FPS checked).
  *   4: round 3 (gspn_mlp_bwd_fused, gspn_mlp_bwd_fused_work_bytes).   5: round 3 (gspn_dense_rsum; the fused launch's pooled form).
  *   6: round 3 (gspn_fps_cells_prepass_order, gspn_bn_colsum / gspn_bn_apply_grad of tf_util's stand-alone batch norm).
- *   7: round 4 (gspn_nmdistance_grad_csr, gspn_bn_finalize_parts_pivot, gspn_mlp_bwd_fused_coef, gspn_dot; gspn_queryballpoint now launches a prefix scan + a continuation kernel -- same output). */
+ *   7: round 4 (gspn_nmdistance_grad_csr, gspn_bn_finalize_parts_pivot, gspn_mlp_bwd_fused_coef, gspn_dot, gspn_queryballpoint_ws; gspn_queryballpoint now launches a prefix scan + a continuation kernel -- same output). */
 #define GSPN_ABI_VERSION 7
 int gspn_dist_policy(void);
 int gspn_abi_version(void);
@@ -104,6 +104,12 @@ int gspn_probsample(int b, int n, int m, const float* inp_p, const float* inp_r,
  * tf_grouping_g.cu:186-189.  Rows without any hit are zero-filled (uninitialised in the reference). */
 int gspn_queryballpoint(int b, int n, int m, float radius, int nsample, const float* xyz1, const float* xyz2,
                         int* idx, int* pts_cnt, void* stream);
+/* the same with a workspace (gspn_ball_ws_bytes(b, n, m) bytes, 16-byte aligned): on sparse clouds -- a ball holds few points, the
+ * reference's scan reads the whole cloud -- the queries are answered through a cell grid over the data points (all hits of the 3 x 3 x 3
+ * block around the query's cell, sorted by index); dense clouds and crowded balls take the scan.  Identical output. */
+long gspn_ball_ws_bytes(int b, int n, int m);
+int gspn_queryballpoint_ws(int b, int n, int m, float radius, int nsample, const float* xyz1, const float* xyz2, void* ws,
+                           int* idx, int* pts_cnt, void* stream);
 /* Same output through LDS-staged point tiles shared by the 8 queries of a workgroup (the shape BASELINE.json's north_star sketches).
  * A measured alternative, not what the Python surface calls: with the reference's early exit the queries of a workgroup need very
  * different prefixes of the cloud, and the scene is L2-resident anyway (DESIGN.md 4.2 has the numbers). */

@@ -313,3 +313,27 @@ def test_inverse_lists_long_groups_on_clustered_clouds(rooms):
     order, offsets = inverse_lists(one, 16)
     assert torch.equal(order, torch.arange(L, dtype=torch.int32, device=t.device).repeat(2, 1))
     assert offsets[0].tolist() == [0] + [L] * 16 and offsets[1].tolist() == [0] + [L // 2] * 7 + [L] * 9
+
+
+@pytest.mark.parametrize("radius,nsample", [(0.2, 32), (0.05, 8), (0.35, 64), (3.0, 16)])
+def test_ball_query_cell_grid_path_equals_the_reference_scan(radius, nsample):
+    """r04: clouds of >= 8192 points take gspn_queryballpoint_ws -- a cell grid over the data points answers the queries whose ball holds few
+    points (all hits of the 3 x 3 x 3 block, sorted by index), the scan the rest.  Index-exact against the oracle on a cloud built to hit every
+    branch: a sparse background (grid answers), two tight clusters (more hits than the grid sorts: handed to the scan), queries that are
+    not data points -- some far outside the bounding box (no hit: zero row, count 0) --, a radius larger than the cloud (dense estimate: no grid)."""
+    from gspn_amd.tf_grouping import query_ball_point
+    rng = np.random.default_rng(77)
+    b, n, m = 2, 16384, 700
+    xyz = (rng.random((b, n, 3)).astype(np.float32) * np.array([8.0, 6.0, 3.0], np.float32))
+    xyz[:, 1000:3000] = (np.array([2.0, 2.0, 1.0], np.float32) + 0.03 * rng.standard_normal((b, 2000, 3))).astype(np.float32)      # a crowded ball
+    xyz[:, 9000:9600] = (np.array([6.5, 4.0, 2.0], np.float32) + 0.10 * rng.standard_normal((b, 600, 3))).astype(np.float32)
+    q = np.concatenate([np.stack([xyz[s][rng.integers(0, n, size=500)] for s in range(b)]),
+                        (rng.random((b, 150, 3)).astype(np.float32) * np.array([8.0, 6.0, 3.0], np.float32)),
+                        (rng.random((b, 50, 3)).astype(np.float32) * 40.0 - 15.0)], axis=1).astype(np.float32)
+    idx, cnt = query_ball_point(radius, nsample, torch.from_numpy(xyz).cuda(), torch.from_numpy(q).cuda())
+    ridx, rcnt = O.query_ball_point(radius, nsample, xyz, q, mt=True)
+    np.testing.assert_array_equal(cnt.cpu().numpy(), rcnt)
+    got = idx.cpu().numpy()
+    hit = rcnt > 0                                          # (rows without a hit are zero-filled here, uninitialised in the reference)
+    np.testing.assert_array_equal(got[hit], ridx[hit])
+    assert (got[~hit] == 0).all()

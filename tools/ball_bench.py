@@ -15,9 +15,13 @@ for kind in kinds:
         n = cur.shape[1]
         q = gather_point(cur, farthest_point_sample(m, cur))
         out = []
-        for name, fn in (("l2-wave", lib.gspn_queryballpoint), ("lds-tile", lib.gspn_queryballpoint_lds)) + ((("auto", lib.gspn_queryballpoint_auto),) if hasattr(lib, "gspn_queryballpoint_auto") else ()):
+        ws = torch.empty(int(lib.gspn_ball_ws_bytes(8, n, m)), dtype=torch.uint8, device="cuda")
+        for name, fn in (("scan (prefix + continuation)", lib.gspn_queryballpoint), ("lds-tile", lib.gspn_queryballpoint_lds), ("cell grid + scan", None)):
             idx = torch.empty(8, m, ns, dtype=torch.int32, device="cuda"); cnt = torch.empty(8, m, dtype=torch.int32, device="cuda")
-            run = lambda: L.check(fn(8, n, m, r, ns, L.ptr(cur), L.ptr(q), L.ptr(idx), L.ptr(cnt), L.stream()), name)
+            if fn is None:
+                run = lambda: L.check(lib.gspn_queryballpoint_ws(8, n, m, r, ns, L.ptr(cur), L.ptr(q), L.ptr(ws), L.ptr(idx), L.ptr(cnt), L.stream()), name)
+            else:
+                run = lambda: L.check(fn(8, n, m, r, ns, L.ptr(cur), L.ptr(q), L.ptr(idx), L.ptr(cnt), L.stream()), name)
             us = bench._ev_time(run) * 1e3
             out.append((name, us, idx.clone(), cnt.clone()))
         same = all(torch.equal(out[0][2], o[2]) and torch.equal(out[0][3], o[3]) for o in out[1:])
