@@ -1,0 +1,145 @@
+"""A second opinion from the reference's OWN kernel sources (not a pin: see oracle/Makefile `ref_hip`, oracle/ref_hip.py): tf_sampling_g.cu and
+tf_grouping_g.cu compiled as they lie for gfx950 by hipcc and launched through the launchers the reference's OpKernels call.  Checked here:
+ * the order / tie semantics the restatement in oracle/gspn_oracle.c claims (FPS's (d desc, k mod 512 asc, k asc) winner, the ball query's
+   ascending scan with its break and padding, first-maximum group_maxpool, the selection sort's displacement order, prob_sample's prefix sums)
+   -- on clouds full of ties, where a wrong rule shows;
+ * which contraction of a*a+b*b+c*c an LLVM back end picks for these very sources (the nvcc question of DESIGN 2, asked of a sibling compiler).
+Skipped where oracle/_ref holds no hipcc build (no reference checkout when the tree was built)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from oracle import ref_hip as R
+from tests import data as D
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not R.available(), reason="oracle/_ref/libtf_*_g_hip.so absent")]
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def lattice(b, n, side, seed):
+    rng = np.random.default_rng(seed)
+    return rng.integers(0, side, size=(b, n, 3)).astype(np.float32)          # integer lattice: equal distances everywhere, arithmetic exact
+
+
+@pytest.mark.parametrize("kind,b,n,m", [("lattice", 3, 3000, 600), ("lattice", 2, 700, 900), ("D", 4, 8192, 512), ("U", 2, 32768, 1024), ("lattice", 40, 600, 64)])
+def test_fps_reference_source_equals_the_oracle_and_the_hip_kernels(kind, b, n, m):
+    from gspn_amd.tf_sampling import farthest_point_sample
+    xyz = lattice(b, n, 9, 5) if kind == "lattice" else D.batch(kind, b, n, 3)
+    ref = R.farthest_point_sample(m, dev(xyz)).cpu().numpy()
+    if kind == "lattice":                                   # exact arithmetic: whatever the contraction, the reference's own code must agree bit for bit
+        np.testing.assert_array_equal(ref, R.farthest_point_sample(m, dev(xyz), nofma=True).cpu().numpy())
+        np.testing.assert_array_equal(O.farthest_point_sample(m, xyz), ref)
+        np.testing.assert_array_equal(farthest_point_sample(m, dev(xyz)).cpu().numpy(), ref)
+    else:                                                   # real coordinates: equal to the build's policy iff hipcc contracts these sources the same way
+        ours = farthest_point_sample(m, dev(xyz)).cpu().numpy()
+        np.testing.assert_array_equal(O.farthest_point_sample(m, xyz), ours)
+        agree = float((ref == ours).all(axis=1).mean())
+        agree_nofma = float((R.farthest_point_sample(m, dev(xyz), nofma=True).cpu().numpy() == ours).all(axis=1).mean())
+        print("FPS %s %dx%d->%d: scenes identical to the hipcc-default build of the reference source: %.2f, to its -ffp-contract=off build: %.2f" % (kind, b, n, m, agree, agree_nofma))
+        assert agree == 1.0 or agree_nofma == 1.0 or O.dist_policy() == 1          # policy 2 or 0 must match one of the two builds
+
+
+@pytest.mark.parametrize("kind,radius,ns", [("lattice", 2.0, 16), ("lattice", 1.0, 32), ("U", 0.2, 32), ("D", 0.1, 8)])
+def test_ball_query_reference_source(kind, radius, ns):
+    from gspn_amd.tf_grouping import query_ball_point
+    b, n, m = 3, 4096, 256
+    xyz = lattice(b, n, 12, 8) if kind == "lattice" else D.batch(kind, b, n, 4)
+    q = xyz[:, ::n // m][:, :m].copy()
+    if kind == "lattice":
+        q[:, ::5] += 0.5                                    # some queries between lattice points: distances exactly ON the radius occur (sqrt(4) < 2 is false)
+    ridx, rcnt = R.query_ball_point(radius, ns, dev(xyz), dev(q))
+    oidx, ocnt = O.query_ball_point(radius, ns, xyz, q)
+    idx, cnt = query_ball_point(radius, ns, dev(xyz), dev(q))
+    if kind == "lattice":
+        np.testing.assert_array_equal(rcnt.cpu().numpy(), ocnt)
+        hit = ocnt > 0
+        np.testing.assert_array_equal(ridx.cpu().numpy()[hit], oidx[hit])
+    np.testing.assert_array_equal(cnt.cpu().numpy(), ocnt)
+    np.testing.assert_array_equal(idx.cpu().numpy()[ocnt > 0], oidx[ocnt > 0])
+    same = bool(torch.equal(ridx, idx) and torch.equal(rcnt, cnt))
+    same_nofma = all(torch.equal(a, b_) for a, b_ in zip(R.query_ball_point(radius, ns, dev(xyz), dev(q), nofma=True), (idx, cnt)))
+    print("ball query %s r=%g: identical to hipcc-default reference build: %s, to -ffp-contract=off: %s" % (kind, radius, same, same_nofma))
+    assert same or same_nofma or O.dist_policy() == 1
+
+
+def test_group_gather_maxpool_sort_reference_source():
+    from gspn_amd.tf_grouping import group_maxpool, group_point, select_top_k
+    from gspn_amd.tf_sampling import gather_point, prob_sample
+    rng = np.random.default_rng(9)
+    b, n, m, ns, c = 2, 600, 70, 12, 10
+    pts = rng.standard_normal((b, n, c)).astype(np.float32)
+    idx = rng.integers(0, n, size=(b, m, ns)).astype(np.int32)
+    assert torch.equal(group_point(dev(pts), dev(idx)), R.group_point(dev(pts), dev(idx)))
+    pts_q = np.round(pts * 2) / 2                            # quantised features: equal maxima inside a group, the first one must win
+    out, mi = group_maxpool(dev(pts_q), dev(idx))
+    rout, rmi = R.group_maxpool(dev(pts_q), dev(idx))
+    assert torch.equal(out, rout) and torch.equal(mi, rmi)
+    xyz = rng.standard_normal((b, n, 3)).astype(np.float32)
+    gi = rng.integers(0, n, size=(b, 300)).astype(np.int32)
+    assert torch.equal(gather_point(dev(xyz), dev(gi)), R.gather_point(dev(xyz), dev(gi)))
+    # gradients: the reference adds with atomics (no order) -- equal to rounding, and exactly equal where an index occurs once
+    go = rng.standard_normal((b, m, ns, c)).astype(np.float32)
+    p = dev(pts).requires_grad_(True)
+    group_point(p, dev(idx)).backward(dev(go))
+    np.testing.assert_allclose(p.grad.cpu().numpy(), R.group_point_grad(n, dev(idx), dev(go)).cpu().numpy(), rtol=1e-5, atol=2e-5)
+    dist = rng.integers(0, 20, size=(2, 9, 150)).astype(np.float32)      # many ties: the selection sort's displacement order shows
+    oi, od = select_top_k(17, dev(dist))
+    ri, rd = R.select_top_k(17, dev(dist))
+    assert torch.equal(oi[..., :17], ri[..., :17]) and torch.equal(od[..., :17], rd[..., :17])
+    w = rng.random((3, 5000)).astype(np.float32)
+    u = rng.random((3, 777)).astype(np.float32)
+    assert torch.equal(prob_sample(dev(w), dev(u)), R.prob_sample(dev(w), dev(u)))
+
+
+def test_which_contraction_an_llvm_back_end_gives_the_reference_source():
+    """DESIGN 2's question -- how does the reference's compiler contract (x2-x1)*(x2-x1)+(y2-y1)*(y2-y1)+(z2-z1)*(z2-z1)? -- asked of hipcc, an
+    LLVM back end like NVVM: the FPS kernel's scratch holds the min squared distances as the compiled expression produced them.  They are
+    compared bit for bit with every way of fusing that expression, evaluated in numpy (fma emulated through float64).  Recorded, not
+    decisive: hipcc is not nvcc.  What IS asserted: the -ffp-contract=off build is the unfused form (policy 0), and the default build is
+    reproduced exactly by one of the fused forms."""
+    xyz = D.batch("U", 1, 4096, 123)
+    m = 48
+    x = xyz[0].astype(np.float32)
+
+    def fma(a, b, c):
+        return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(np.float32)
+
+    def mul(a, b):
+        return (a * b).astype(np.float32)
+
+    forms = {
+        "policy 0: (dx*dx + dy*dy) + dz*dz": lambda dx, dy, dz: ((mul(dx, dx) + mul(dy, dy)).astype(np.float32) + mul(dz, dz)).astype(np.float32),
+        "policy 1: fma(dz,dz, fma(dy,dy, dx*dx))": lambda dx, dy, dz: fma(dz, dz, fma(dy, dy, mul(dx, dx))),
+        "policy 2: fma(dz,dz, fma(dx,dx, dy*dy))": lambda dx, dy, dz: fma(dz, dz, fma(dx, dx, mul(dy, dy))),
+        "fma(dz,dz, dx*dx + dy*dy)": lambda dx, dy, dz: fma(dz, dz, (mul(dx, dx) + mul(dy, dy)).astype(np.float32)),
+        "fma(dx,dx, dy*dy) + dz*dz": lambda dx, dy, dz: (fma(dx, dx, mul(dy, dy)) + mul(dz, dz)).astype(np.float32),
+        "fma(dy,dy, dx*dx) + dz*dz": lambda dx, dy, dz: (fma(dy, dy, mul(dx, dx)) + mul(dz, dz)).astype(np.float32),
+        "fma(dx,dx, fma(dy,dy, dz*dz))": lambda dx, dy, dz: fma(dx, dx, fma(dy, dy, mul(dz, dz))),
+    }
+    res = {}
+    builds = (False, True) + (("fast",) if R.lib("sampling", "fast") is not None else ())
+    for nofma in builds:
+        idx, temp = R.fps_min_distances(m, dev(xyz), nofma=nofma)
+        idx, temp = idx.cpu().numpy()[0], temp.cpu().numpy()[0]
+        for name, f in forms.items():                        # the kernel updates temp with the centres idx[0 .. m-2] (the last pick is not applied)
+            td = np.full(4096, 1e38, np.float32)
+            for c in idx[:m - 1]:
+                td = np.minimum(td, f(x[:, 0] - x[c, 0], x[:, 1] - x[c, 1], x[:, 2] - x[c, 2]))
+            res[(nofma, name)] = float((td == temp).mean())
+    for nofma in builds:
+        print("reference FPS source built by hipcc %s: fraction of 4096 min-distances reproduced bit for bit" % (
+            "-ffp-contract=fast (the LLVM back end contracts, as NVVM does under --fmad=true)" if nofma == "fast" else ("-ffp-contract=off" if nofma else "(default: clang's front-end contraction)")))
+        for name in forms:
+            print("    %-44s %.4f" % (name, res[(nofma, name)]))
+    assert res[(True, "policy 0: (dx*dx + dy*dy) + dz*dz")] == 1.0
+    best = max((v, k[1]) for k, v in res.items() if k[0] is False)
+    print("hipcc's default contraction of the reference expression:", best[1])
+    assert best[0] == 1.0 and not best[1].startswith("policy 0")
+    if "fast" in builds:
+        bf = max((v, k[1]) for k, v in res.items() if k[0] == "fast")
+        print("the LLVM back end's contraction (-ffp-contract=fast) of the reference expression:", bf[1], "(this build's GSPN_DIST_POLICY: %d)" % O.dist_policy())
+        assert bf[0] == 1.0
