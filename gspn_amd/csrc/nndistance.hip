@@ -14,19 +14,30 @@
 #define NM_TILE 1024
 #define NM_BLOCK 256
 
+// NM_Q queries per lane (r04): one broadcast LDS read feeds NM_Q independent distance chains -- half the LDS instructions per pair at NM_Q = 2
+// and twice the independent work between dependent compare / select pairs (round 3's SQ counters: 0.36 of the vector issue rate, half the
+// wave cycles stalled on issue).  Queries j, j + NM_BLOCK of a slab of NM_Q * NM_BLOCK points.
+// Only when the grid still fills the chip at NM_Q = 2 (the model's 2048 clouds: 267 -> 212 us); a launch with few workgroups keeps one
+// query per lane (the harness shape's 1024-query direction: 64 workgroups at NM_Q = 2 ran twice as long).
+template <int NM_Q>
 __global__ __launch_bounds__(NM_BLOCK) void nm_distance_kernel(int b, int n, const float* __restrict__ xyz, int m, const float* __restrict__ xyz2,
                                                                float* __restrict__ result, int* __restrict__ result_i) {
     __shared__ float4 tile[NM_TILE];
     const int cloud = blockIdx.x % b;
-    const int j = (blockIdx.x / b) * NM_BLOCK + threadIdx.x;
-    const bool live = j < n;
-    float x1 = 0.f, y1 = 0.f, z1 = 0.f;
-    if (live) {
-        const float* q = xyz + ((size_t)cloud * n + j) * 3;
-        x1 = q[0]; y1 = q[1]; z1 = q[2];
+    const int j0 = (blockIdx.x / b) * (NM_BLOCK * NM_Q) + threadIdx.x;
+    float x1[NM_Q], y1[NM_Q], z1[NM_Q], best[NM_Q];
+    int best_i[NM_Q];
+#pragma unroll
+    for (int u = 0; u < NM_Q; ++u) {
+        const int j = j0 + u * NM_BLOCK;
+        x1[u] = y1[u] = z1[u] = 0.f;
+        if (j < n) {
+            const float* q = xyz + ((size_t)cloud * n + j) * 3;
+            x1[u] = q[0]; y1[u] = q[1]; z1[u] = q[2];
+        }
+        best[u] = 0.f;
+        best_i[u] = 0;
     }
-    float best = 0.f;
-    int best_i = 0;
     const float* sp = xyz2 + (size_t)cloud * m * 3;
     for (int k0 = 0; k0 < m; k0 += NM_TILE) {
         const int cnt = min(NM_TILE, m - k0);
@@ -34,16 +45,30 @@ __global__ __launch_bounds__(NM_BLOCK) void nm_distance_kernel(int b, int n, con
         for (int t = threadIdx.x; t < cnt; t += NM_BLOCK)
             tile[t] = make_float4(sp[(size_t)(k0 + t) * 3 + 0], sp[(size_t)(k0 + t) * 3 + 1], sp[(size_t)(k0 + t) * 3 + 2], 0.f);
         __syncthreads();
-#pragma unroll 4
-        for (int k = 0; k < cnt; ++k) {
+        int k = 0;
+        if (k0 == 0) {                                            // candidate 0 initialises (:29): peeled, the loop body is then branch-free
+            const float4 p = tile[0];
+#pragma unroll
+            for (int u = 0; u < NM_Q; ++u) { best[u] = dist2_cuda(p.x - x1[u], p.y - y1[u], p.z - z1[u]); best_i[u] = 0; }
+            k = 1;
+        }
+#pragma unroll 8
+        for (; k < cnt; ++k) {
             const float4 p = tile[k];
-            const float d = dist2_cuda(p.x - x1, p.y - y1, p.z - z1);       // :25-28
-            if ((k0 + k) == 0 || d < best) { best = d; best_i = k0 + k; }    // :29, :119
+#pragma unroll
+            for (int u = 0; u < NM_Q; ++u) {
+                const float d = dist2_cuda(p.x - x1[u], p.y - y1[u], p.z - z1[u]);       // :25-28
+                if (d < best[u]) { best[u] = d; best_i[u] = k0 + k; }                      // :29, :119: strict '<', the lowest index wins ties
+            }
         }
     }
-    if (live) {
-        result[(size_t)cloud * n + j] = best;
-        result_i[(size_t)cloud * n + j] = best_i;
+#pragma unroll
+    for (int u = 0; u < NM_Q; ++u) {
+        const int j = j0 + u * NM_BLOCK;
+        if (j < n) {
+            result[(size_t)cloud * n + j] = best[u];
+            result_i[(size_t)cloud * n + j] = best_i[u];
+        }
     }
 }
 extern "C" int gspn_nmdistance(int b, int n, const float* xyz, int m, const float* xyz2, float* result, int* result_i,
@@ -51,10 +76,15 @@ extern "C" int gspn_nmdistance(int b, int n, const float* xyz, int m, const floa
     if (b < 0 || n < 0 || m < 0) return GSPN_ERR_ARG;
     if (b == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    const long long g1 = (long long)b * ((n + NM_BLOCK - 1) / NM_BLOCK), g2 = (long long)b * ((m + NM_BLOCK - 1) / NM_BLOCK);
-    if (g1 > 0x7FFFFFFFll || g2 > 0x7FFFFFFFll) return GSPN_ERR_UNSUPPORTED;
-    if (n > 0) hipLaunchKernelGGL(nm_distance_kernel, dim3((unsigned)g1), dim3(NM_BLOCK), 0, st, b, n, xyz, m, xyz2, result, result_i);
-    if (m > 0) hipLaunchKernelGGL(nm_distance_kernel, dim3((unsigned)g2), dim3(NM_BLOCK), 0, st, b, m, xyz2, n, xyz, result2, result2_i);
+    auto go = [&](int nq, const float* q, int nc, const float* c, float* r, int* ri) -> int {
+        if (nq <= 0) return 0;
+        const long long g2 = (long long)b * ((nq + 2 * NM_BLOCK - 1) / (2 * NM_BLOCK)), g1 = (long long)b * ((nq + NM_BLOCK - 1) / NM_BLOCK);
+        if (g1 > 0x7FFFFFFFll) return GSPN_ERR_UNSUPPORTED;
+        if (g2 >= 1024) hipLaunchKernelGGL(nm_distance_kernel<2>, dim3((unsigned)g2), dim3(NM_BLOCK), 0, st, b, nq, q, nc, c, r, ri);
+        else hipLaunchKernelGGL(nm_distance_kernel<1>, dim3((unsigned)g1), dim3(NM_BLOCK), 0, st, b, nq, q, nc, c, r, ri);
+        return 0;
+    };
+    if (go(n, xyz, m, xyz2, result, result_i) || go(m, xyz2, n, xyz, result2, result2_i)) return GSPN_ERR_UNSUPPORTED;
     return gspn_launch_status();
 }
 

@@ -1,0 +1,348 @@
+// bf16_split.hip -- VERDICT r03 item 8 (exploratory, gated): can the SIMD issue budget of the fp32 shared-MLP GEMMs be bought back by
+// splitting both fp32 operands into three bf16 pieces (8 + 8 + 8 = all 24 significand bits, by truncation: every piece and every residual
+// is exact) and accumulating six v_mfma_f32_32x32x16_bf16 products in fp32 --  hi.hi + hi.mid + mid.hi + hi.lo + lo.hi + mid.mid; the
+// three dropped products are below 2^-24 of |x.w| -- instead of eight v_mfma_f32_32x32x2_f32 per K = 16?
+//
+// The kernel here is a whole forward layer, not an MFMA loop:   Y = relu(X * scale + shift) . W + bias,  column sums of Y and Y^2 per
+// workgroup (the production layer's contract, gspn_mlp_fwd), INCLUDING the split's vector instructions at operand-staging time:
+//   * W is split once per optimiser step by a small kernel (wsplit_kernel, timed separately) into three (N, K) bf16 planes, k contiguous;
+//     a workgroup copies them into LDS once (padded pitch: conflict-free ds_read_b128);
+//   * the A operand never touches LDS: lane (row l & 31, half l >> 5) of a wave loads K/2 consecutive floats of ITS row (float4 loads,
+//     the whole row block of the next tile in flight during this one), applies the previous layer's BN + ReLU with two roundings, and
+//     splits in registers (11 vector instructions per two elements: 3 v_perm packs, 4 v_and, 4 v_sub).  Which physical k a (half, slot)
+//     pair of the MFMA carries is free as long as A and B agree: half h takes k in [h K/2, (h+1) K/2);
+//   * a wave owns 32 rows x N columns: 6 N/32 MFMAs of 8 passes per 16 k against 8 N/32 of 16 passes.
+// It is compared with the production library's gspn_mlp_fwd on the same buffers (rotating over enough buffer sets to defeat the 256 MB
+// Infinity Cache, and on one set), and both are checked against an fp64 host product on sampled rows.
+//
+// build:  hipcc --offload-arch=gfx950 -O3 -o bf16_split bf16_split.hip -L../../gspn_amd/lib -lgspn_hip -Wl,-rpath,'$ORIGIN/../../gspn_amd/lib'
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+extern "C" int gspn_mlp_fwd(long rows, int cin, int cout, const float* X, int ldx, const float* in_scale, const float* in_shift, const float* W,
+                            const float* bias, float* Y, int ldy, float* stats, void* stream);
+extern "C" long gspn_mlp_fwd_stats_bytes(long rows, int cout);
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+// W (K, N) fp32 row-major  ->  planes[3][N][K] bf16 bit patterns, by truncation
+__global__ void wsplit_kernel(int K, int N, const float* __restrict__ W, uint16_t* __restrict__ planes) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= K * N) return;
+    const int n = i / K, k = i - n * K;
+    const float x = W[(size_t)k * N + n];
+    const unsigned u = __float_as_uint(x);
+    const float r1 = x - __uint_as_float(u & 0xFFFF0000u);
+    const unsigned u1 = __float_as_uint(r1);
+    const float r2 = r1 - __uint_as_float(u1 & 0xFFFF0000u);
+    planes[(size_t)0 * N * K + i] = (uint16_t)(u >> 16);
+    planes[(size_t)1 * N * K + i] = (uint16_t)(u1 >> 16);
+    planes[(size_t)2 * N * K + i] = (uint16_t)(__float_as_uint(r2) >> 16);
+}
+
+__device__ __forceinline__ unsigned pack_hi(float x1, float x0) {       // (top half of x1) : (top half of x0)
+    return __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);
+}
+__device__ __forceinline__ float drop_hi(float x) { return x - __uint_as_float(__float_as_uint(x) & 0xFFFF0000u); }      // exact
+
+#ifndef MINB
+#define MINB 2
+#endif
+template <int K, int N, bool SPLIT3>
+__global__ __launch_bounds__(256, MINB) void fwd_split_kernel(int rows, const float* __restrict__ X, int ldx, const float* __restrict__ in_scale,
+                                                        const float* __restrict__ in_shift, const uint16_t* __restrict__ planes,
+                                                        const float* __restrict__ bias, float* __restrict__ Y, int ldy, float* __restrict__ stats) {
+    constexpr int NT = N / 32, KS = K / 16, KH = K / 2, PITCH = K * 2 + 16;
+    constexpr int NP = SPLIT3 ? 3 : 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sW = smem;                                               // [3][N][PITCH]
+    float* sC = reinterpret_cast<float*>(smem + 3 * N * PITCH);            // [2][K]
+    float* sRed = sC + 2 * K;                                               // [4][2][N]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, kh = lane >> 5;
+    for (int i = t; i < 3 * N * (K / 8); i += 256) {                        // 16-byte pieces
+        const int row = i / (K / 8), c = i - row * (K / 8);
+        *reinterpret_cast<uint4*>(sW + (size_t)row * PITCH + c * 16) = *reinterpret_cast<const uint4*>(planes + (size_t)row * K + c * 8);
+    }
+    for (int i = t; i < K; i += 256) { sC[i] = in_scale[i]; sC[K + i] = in_shift[i]; }
+    float bv[NT], csum[NT], csq[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { bv[nt] = bias[nt * 32 + l31]; csum[nt] = csq[nt] = 0.f; }
+    const int ntiles = rows >> 7;
+    float4 xr[KH / 4], xn[KH / 4];
+    auto fetch = [&](int tile, float4* d) {
+        const float* p = X + (size_t)((tile << 7) + wave * 32 + l31) * ldx + KH * kh;
+#pragma unroll
+        for (int i = 0; i < KH / 4; ++i) d[i] = *reinterpret_cast<const float4*>(p + 4 * i);
+    };
+    if ((int)blockIdx.x < ntiles) fetch((int)blockIdx.x, xn);
+    __syncthreads();
+    const unsigned char* pb = sW + (size_t)l31 * PITCH + KH * kh * 2;
+    for (int tile = (int)blockIdx.x; tile < ntiles; tile += (int)gridDim.x) {
+#pragma unroll
+        for (int i = 0; i < KH / 4; ++i) xr[i] = xn[i];
+        if (tile + (int)gridDim.x < ntiles) fetch(tile + (int)gridDim.x, xn);
+        f32x16 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            float v[8];
+            {
+                const float4 a0 = xr[2 * s], a1 = xr[2 * s + 1];
+                const float4 s0 = *reinterpret_cast<const float4*>(sC + KH * kh + 8 * s), s1 = *reinterpret_cast<const float4*>(sC + KH * kh + 8 * s + 4);
+                const float4 h0 = *reinterpret_cast<const float4*>(sC + K + KH * kh + 8 * s), h1 = *reinterpret_cast<const float4*>(sC + K + KH * kh + 8 * s + 4);
+                const float xs[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+                const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float y = __fadd_rn(__fmul_rn(xs[j], sc[j]), sh[j]);       // two roundings, as the production operand
+                    v[j] = y > 0.f ? y : 0.f;
+                }
+            }
+            u32x4 ap[3];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float x0 = v[2 * j], x1 = v[2 * j + 1];
+                ap[0][j] = pack_hi(x1, x0);
+                if (SPLIT3) {
+                    const float r0 = drop_hi(x0), r1 = drop_hi(x1);
+                    ap[1][j] = pack_hi(r1, r0);
+                    ap[2][j] = pack_hi(drop_hi(r1), drop_hi(r0));
+                }
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                u32x4 bp[3];
+#pragma unroll
+                for (int p = 0; p < NP; ++p) bp[p] = *reinterpret_cast<const u32x4*>(pb + (size_t)(p * N + nt * 32) * PITCH + 16 * s);
+#define MF(ia, ib) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ap[ia]), __builtin_bit_cast(bf16x8, bp[ib]), acc[nt], 0, 0, 0)
+                if (SPLIT3) { MF(2, 0); MF(0, 2); MF(1, 1); MF(1, 0); MF(0, 1); }
+                MF(0, 0);
+#undef MF
+                __builtin_amdgcn_sched_barrier(0);               // (keeps hipcc from hoisting every step's B fragments to the top: 308 registers, one workgroup per CU)
+            }
+        }
+        const int m0 = (tile << 7) + wave * 32 + 4 * kh;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float y = acc[nt][r] + bv[nt];
+                Y[(size_t)(m0 + (r & 3) + 8 * (r >> 2)) * ldy + nt * 32 + l31] = y;
+                csum[nt] += y;
+                csq[nt] = __builtin_fmaf(y, y, csq[nt]);
+            }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        csum[nt] += __shfl_xor(csum[nt], 32, 64);
+        csq[nt] += __shfl_xor(csq[nt], 32, 64);
+        if (lane < 32) { sRed[(wave * 2 + 0) * N + nt * 32 + lane] = csum[nt]; sRed[(wave * 2 + 1) * N + nt * 32 + lane] = csq[nt]; }
+    }
+    __syncthreads();
+    for (int j = t; j < N; j += 256) {
+        float sm = 0.f, q = 0.f;
+        for (int w = 0; w < 4; ++w) { sm += sRed[(w * 2 + 0) * N + j]; q += sRed[(w * 2 + 1) * N + j]; }
+        stats[(size_t)blockIdx.x * 2 * N + j] = sm;
+        stats[(size_t)blockIdx.x * 2 * N + N + j] = q;
+    }
+}
+
+// The same frame with EXACT fp32 products (v_mfma_f32_32x32x2_f32): A straight from global memory into the lanes that multiply it -- half h of a
+// wave takes k in [h K/2, (h+1) K/2), MFMA number s of a row block multiplies k = s (half 0) and k = K/2 + s (half 1) -- W transposed in LDS
+// once per workgroup (one ds_read_b128 = four MFMAs' B values), no barrier and no LDS write in the row loop.  Is the production kernel's
+// distance from the memory frame its MFMA count or its operand staging?
+template <int K, int N>
+__global__ __launch_bounds__(256, MINB) void fwd_direct_f32_kernel(int rows, const float* __restrict__ X, int ldx, const float* __restrict__ in_scale,
+                                                                    const float* __restrict__ in_shift, const float* __restrict__ W,
+                                                                    const float* __restrict__ bias, float* __restrict__ Y, int ldy, float* __restrict__ stats) {
+    constexpr int NT = N / 32, KH = K / 2, PITCH = K + 4;                  // floats
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* sW = reinterpret_cast<float*>(smem);                              // [N][PITCH]: W transposed
+    float* sC = sW + N * PITCH;                                              // [2][K]
+    float* sRed = sC + 2 * K;                                                // [4][2][N]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, kh = lane >> 5;
+    for (int i = t; i < K * (N / 4); i += 256) {
+        const int k = i / (N / 4), n4 = (i - k * (N / 4)) * 4;
+        const float4 w = *reinterpret_cast<const float4*>(W + (size_t)k * N + n4);
+        sW[(n4 + 0) * PITCH + k] = w.x; sW[(n4 + 1) * PITCH + k] = w.y; sW[(n4 + 2) * PITCH + k] = w.z; sW[(n4 + 3) * PITCH + k] = w.w;
+    }
+    for (int i = t; i < K; i += 256) { sC[i] = in_scale[i]; sC[K + i] = in_shift[i]; }
+    float bv[NT], csum[NT], csq[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { bv[nt] = bias[nt * 32 + l31]; csum[nt] = csq[nt] = 0.f; }
+    const int ntiles = rows >> 7;
+    float4 xr[KH / 4], xn[KH / 4];
+    auto fetch = [&](int tile, float4* d) {
+        const float* p = X + (size_t)((tile << 7) + wave * 32 + l31) * ldx + KH * kh;
+#pragma unroll
+        for (int i = 0; i < KH / 4; ++i) d[i] = *reinterpret_cast<const float4*>(p + 4 * i);
+    };
+    if ((int)blockIdx.x < ntiles) fetch((int)blockIdx.x, xn);
+    __syncthreads();
+    const float* pb = sW + (size_t)l31 * PITCH + KH * kh;
+    for (int tile = (int)blockIdx.x; tile < ntiles; tile += (int)gridDim.x) {
+#pragma unroll
+        for (int i = 0; i < KH / 4; ++i) xr[i] = xn[i];
+        if (tile + (int)gridDim.x < ntiles) fetch(tile + (int)gridDim.x, xn);
+        f32x16 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KH / 4; ++s) {
+            const float4 a = xr[s];
+            const float4 sc = *reinterpret_cast<const float4*>(sC + KH * kh + 4 * s), sh = *reinterpret_cast<const float4*>(sC + K + KH * kh + 4 * s);
+            float v[4] = {__fadd_rn(__fmul_rn(a.x, sc.x), sh.x), __fadd_rn(__fmul_rn(a.y, sc.y), sh.y), __fadd_rn(__fmul_rn(a.z, sc.z), sh.z), __fadd_rn(__fmul_rn(a.w, sc.w), sh.w)};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const float4 b = *reinterpret_cast<const float4*>(pb + (size_t)(nt * 32) * PITCH + 4 * s);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[0], b.x, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[1], b.y, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[2], b.z, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[3], b.w, acc[nt], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const int m0 = (tile << 7) + wave * 32 + 4 * kh;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float y = acc[nt][r] + bv[nt];
+                Y[(size_t)(m0 + (r & 3) + 8 * (r >> 2)) * ldy + nt * 32 + l31] = y;
+                csum[nt] += y;
+                csq[nt] = __builtin_fmaf(y, y, csq[nt]);
+            }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        csum[nt] += __shfl_xor(csum[nt], 32, 64);
+        csq[nt] += __shfl_xor(csq[nt], 32, 64);
+        if (lane < 32) { sRed[(wave * 2 + 0) * N + nt * 32 + lane] = csum[nt]; sRed[(wave * 2 + 1) * N + nt * 32 + lane] = csq[nt]; }
+    }
+    __syncthreads();
+    for (int j = t; j < N; j += 256) {
+        float sm = 0.f, q = 0.f;
+        for (int w = 0; w < 4; ++w) { sm += sRed[(w * 2 + 0) * N + j]; q += sRed[(w * 2 + 1) * N + j]; }
+        stats[(size_t)blockIdx.x * 2 * N + j] = sm;
+        stats[(size_t)blockIdx.x * 2 * N + N + j] = q;
+    }
+}
+
+template <int K, int N>
+static void run(int rows, int sets, int wgs_per_cu) {
+    constexpr int PITCH = K * 2 + 16;
+    const size_t lds = 3 * N * PITCH + 2 * K * 4 + 8 * N * 4;
+    std::vector<float> hX((size_t)rows * K), hW((size_t)K * N), hs(K), hh(K), hb(N);
+    uint64_t st = 0x9E3779B97F4A7C15ull;
+    auto rnd = [&]() { st = st * 6364136223846793005ull + 1442695040888963407ull; return (float)((st >> 33) & 0xFFFFFF) / 16777216.f; };
+    auto gauss = [&]() { float a = 0.f; for (int i = 0; i < 12; ++i) a += rnd(); return a - 6.f; };
+    for (auto& v : hX) v = gauss() * 1.7f + 0.3f;
+    for (auto& v : hW) v = gauss() * 0.1f;
+    for (int k = 0; k < K; ++k) { hs[k] = 0.5f + rnd(); hh[k] = rnd() - 0.5f; }
+    for (auto& v : hb) v = rnd() - 0.5f;
+    std::vector<float*> dX(sets), dY(sets);
+    for (int i = 0; i < sets; ++i) {
+        CK(hipMalloc(&dX[i], hX.size() * 4)); CK(hipMalloc(&dY[i], (size_t)rows * N * 4));
+        CK(hipMemcpy(dX[i], hX.data(), hX.size() * 4, hipMemcpyHostToDevice));
+    }
+    float *dW, *ds, *dh, *db, *dstats, *dstats2;
+    uint16_t* dP;
+    CK(hipMalloc(&dW, hW.size() * 4)); CK(hipMalloc(&ds, K * 4)); CK(hipMalloc(&dh, K * 4)); CK(hipMalloc(&db, N * 4));
+    CK(hipMalloc(&dP, (size_t)3 * N * K * 2));
+    CK(hipMemcpy(dW, hW.data(), hW.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(ds, hs.data(), K * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dh, hh.data(), K * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(db, hb.data(), N * 4, hipMemcpyHostToDevice));
+    int grid = 256 * wgs_per_cu;
+    if (grid > rows / 128) grid = rows / 128;
+    CK(hipMalloc(&dstats, (size_t)grid * 2 * N * 4));
+    CK(hipMalloc(&dstats2, gspn_mlp_fwd_stats_bytes(rows, N)));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_split_kernel<K, N, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_split_kernel<K, N, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const size_t ldsf = (size_t)N * (K + 4) * 4 + 2 * K * 4 + 8 * N * 4;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_direct_f32_kernel<K, N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    auto time_us = [&](auto&& f, int reps) {
+        for (int i = 0; i < 5; ++i) f(i);
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0, 0));
+        for (int i = 0; i < reps; ++i) f(i);
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        return ms * 1e3 / reps;
+    };
+    const double t_ws = time_us([&](int) { hipLaunchKernelGGL(wsplit_kernel, dim3((K * N + 255) / 256), dim3(256), 0, 0, K, N, dW, dP); }, 50);
+    auto split3 = [&](int i) { hipLaunchKernelGGL((fwd_split_kernel<K, N, true>), dim3(grid), dim3(256), lds, 0, rows, dX[i % sets], K, ds, dh, dP, db, dY[i % sets], N, dstats); };
+    auto split1 = [&](int i) { hipLaunchKernelGGL((fwd_split_kernel<K, N, false>), dim3(grid), dim3(256), lds, 0, rows, dX[i % sets], K, ds, dh, dP, db, dY[i % sets], N, dstats); };
+    auto direct = [&](int i) { hipLaunchKernelGGL((fwd_direct_f32_kernel<K, N>), dim3(grid), dim3(256), ldsf, 0, rows, dX[i % sets], K, ds, dh, dW, db, dY[i % sets], N, dstats); };
+    auto prod = [&](int i) { if (gspn_mlp_fwd(rows, K, N, dX[i % sets], K, ds, dh, dW, db, dY[i % sets], N, dstats2, nullptr)) { fprintf(stderr, "gspn_mlp_fwd failed\n"); exit(1); } };
+    const int reps = 40;
+    const double t3 = time_us(split3, reps), t1 = time_us(split1, reps), tp = time_us(prod, reps);
+    const double td = time_us(direct, reps), tds = time_us([&](int) { direct(0); }, reps);
+    const double t3s = time_us([&](int) { split3(0); }, reps), tps = time_us([&](int) { prod(0); }, reps);
+    // accuracy on sampled rows against an fp64 product of the fp32-rounded operand (relu(x*s+h) with two fp32 roundings, as both kernels form it)
+    std::vector<float> y3((size_t)rows * N), yp((size_t)rows * N), y1((size_t)rows * N), yd((size_t)rows * N);
+    direct(0); CK(hipDeviceSynchronize()); CK(hipMemcpy(yd.data(), dY[0], yd.size() * 4, hipMemcpyDeviceToHost));
+    split3(0); CK(hipDeviceSynchronize()); CK(hipMemcpy(y3.data(), dY[0], y3.size() * 4, hipMemcpyDeviceToHost));
+    split1(0); CK(hipDeviceSynchronize()); CK(hipMemcpy(y1.data(), dY[0], y1.size() * 4, hipMemcpyDeviceToHost));
+    prod(0); CK(hipDeviceSynchronize()); CK(hipMemcpy(yp.data(), dY[0], yp.size() * 4, hipMemcpyDeviceToHost));
+    double e3 = 0, ep = 0, e1m = 0, mx = 0, s3 = 0, sp = 0, ed = 0, sd = 0;
+    long cnt = 0;
+    for (int q = 0; q < 4096; ++q) {
+        const long r = (long)(rnd() * rows) % rows;
+        for (int n = 0; n < N; ++n) {
+            double a = hb[n];
+            double dot = 0;
+            for (int k = 0; k < K; ++k) {
+                float v = hX[(size_t)r * K + k] * hs[k];
+                v = v + hh[k];
+                v = v > 0.f ? v : 0.f;
+                dot += (double)v * (double)hW[(size_t)k * N + n];
+            }
+            a += dot;
+            const double d3 = fabs(y3[(size_t)r * N + n] - a), dp = fabs(yp[(size_t)r * N + n] - a), d1 = fabs(y1[(size_t)r * N + n] - a);
+            e3 = fmax(e3, d3); ep = fmax(ep, dp); e1m = fmax(e1m, d1); mx = fmax(mx, fabs(a));
+            s3 += d3 * d3; sp += dp * dp; ++cnt;
+            { const double dd = fabs(yd[(size_t)r * N + n] - a); ed = fmax(ed, dd); sd += dd * dd; }
+        }
+    }
+    const double gb = (double)rows * (K + N) * 4 / 1e9, gf = 2.0 * rows * K * N / 1e9;
+    printf("%7d x %3d -> %3d  (%d buffer sets, grid %d, %zu B LDS)\n", rows, K, N, sets, grid, lds);
+    printf("   production gspn_mlp_fwd (fp32 MFMA)      : %6.1f us rotating  %6.1f us one set   %5.2f TB/s  %5.1f TF\n", tp, tps, gb / tp * 1e3, gf / tp * 1e3);
+    printf("   3 x bf16 split, 6 products (this kernel) : %6.1f us rotating  %6.1f us one set   %5.2f TB/s  %5.1f TF   x%.2f\n", t3, t3s, gb / t3 * 1e3, gf / t3 * 1e3, tp / t3);
+    printf("   fp32 MFMA, A direct from global (exact)  : %6.1f us rotating  %6.1f us one set   %5.2f TB/s  %5.1f TF   x%.2f\n", td, tds, gb / td * 1e3, gf / td * 1e3, tp / td);
+    printf("   1 x bf16 (hi.hi only: the kernel's frame): %6.1f us rotating\n", t1);
+    printf("   W split kernel (once per optimiser step) : %6.1f us\n", t_ws);
+    printf("   max |err| / max |y| vs fp64: production %.3g   split-6 %.3g   bf16 %.3g     rms err: production %.3g  split-6 %.3g   (max |y| %.3g)\n   direct fp32: max %.3g rms %.3g\n",
+           ep / mx, e3 / mx, e1m / mx, sqrt(sp / cnt), sqrt(s3 / cnt), mx, ed / mx, sqrt(sd / cnt));
+    for (int i = 0; i < sets; ++i) { CK(hipFree(dX[i])); CK(hipFree(dY[i])); }
+    CK(hipFree(dW)); CK(hipFree(ds)); CK(hipFree(dh)); CK(hipFree(db)); CK(hipFree(dP)); CK(hipFree(dstats)); CK(hipFree(dstats2));
+}
+
+int main(int argc, char** argv) {
+    const int wpc = argc > 1 ? atoi(argv[1]) : 2;
+    run<64, 64>(262144, 6, wpc);
+    run<64, 64>(524288, 3, wpc);
+    run<64, 128>(131072, 6, wpc);
+    run<32, 64>(524288, 4, wpc);
+    run<128, 128>(32768, 12, wpc);
+    return 0;
+}
