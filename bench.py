@@ -1022,6 +1022,8 @@ def other_configs(xyz, col, dev):
         col_g = col.clone().requires_grad_(True)
 
         def c3():
+            for p_ in tf_util.get_variable_store().parameters():
+                p_.grad = None                                   # (as c4: a step starts from cleared gradients -- r03's leg accumulated into them, 35 torch adds a step)
             pred = pred0.clone().requires_grad_(True)
             _, new_points, _, _ = multi_encoding_net(xyz, col_g, 256, [0.5, 1.0, 1.5], [256, 256, 512], [[64, 128, 256]] * 3, [], True, 0.5, 'c3', use_xyz=True)
             loss = new_points.mean() + chamfer_recons_loss(pred, gt, mask)

@@ -964,6 +964,164 @@ __global__ __launch_bounds__(256) void fwd_lean_kernel(int rows, int cin, int co
         }
     }
 }
+// ============================================================================================
+// Forward with both operands split into three bf16 pieces (r04; OPT-IN: GSPN_MFMA_SPLIT=1.  The default build computes exact fp32
+// products).  VERDICT r03 item 8 asked whether the SIMD issue budget of the fp32 MFMAs (16 passes per 32x32x2) can be bought back:
+// an fp32 value is hi + mid + lo with three bf16 numbers exactly (8 + 8 + 8 significand bits by truncation; every residual is an
+// exact fp32 subtraction), a product of two pieces is exact in fp32, and six v_mfma_f32_32x32x16_bf16 (8 passes per 16 k) --
+// hi.hi + hi.mid + mid.hi + hi.lo + lo.hi + mid.mid, smallest first, fp32 accumulation -- replace eight fp32 MFMAs per 16 k; the
+// three dropped products are below 2^-24 of |x.w| each.  Measured against fp64 the result is as good as the fp32 MFMA's
+// (tools/clk/bf16_split.hip: max error 2.5e-7 of max |y| both, rms 1.5e-7 vs 1.3e-7), 1.3-1.45x faster on the long layers.
+//   * W (cin, cout) is split by the workgroup while it is staged: three (cout, cin) bf16 planes in LDS, k contiguous, pitch 2 cin + 16
+//     bytes (conflict-free ds_read_b128), once per persistent workgroup;
+//   * the A operand does not pass through LDS: lane (row l & 31, half h = l >> 5) loads cin/2 consecutive floats of ITS row (the next
+//     tile's in flight during this one), applies relu(x*scale + shift) with two roundings and splits in registers (11 vector
+//     instructions per two elements).  Which k a (half, slot) pair of the MFMA carries is free as long as A and B agree: half h
+//     takes k in [h cin/2, (h+1) cin/2);
+//   * a wave owns 32 rows x cout columns; no barrier and no LDS write in the row loop.
+// Contract as fwd_lean_kernel (Y, per-workgroup partial column sums, optional 32-row pool epilogue); results are NOT bit-identical to
+// the fp32 kernels' (another summation order and the dropped terms), which is why this is a switch and not the default.
+// ============================================================================================
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+__device__ __forceinline__ unsigned bf_pack_hi(float x1, float x0) {       // (top half of x1) : (top half of x0)
+    return __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);
+}
+__device__ __forceinline__ float bf_drop_hi(float x) { return x - __uint_as_float(__float_as_uint(x) & 0xFFFF0000u); }      // exact
+
+template <int K, int N, bool ACT, bool POOL>
+__global__ __launch_bounds__(256, 2) void fwd_split_kernel(int rows, const float* __restrict__ X, int ldx, const float* __restrict__ in_scale,
+                                                           const float* __restrict__ in_shift, const float* __restrict__ W, const float* __restrict__ bias,
+                                                           float* __restrict__ Y, int ldy, float* __restrict__ stats, PoolOut po) {
+    constexpr int NT = N / 32, KS = K / 16, KH = K / 2, PITCH = K * 2 + 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_split[];
+    unsigned char* sW = s_split;                                             // [3][N][PITCH]
+    float* sC = reinterpret_cast<float*>(s_split + 3 * N * PITCH);           // [2][K]
+    float* sRed = sC + 2 * K;                                                // [4][2][N]
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), l31 = lane & 31, kh = lane >> 5;
+    for (int i = t; i < (K / 2) * (N / 4); i += 256) {                       // item: rows k, k+1 of W x four columns
+        const int k = (i / (N / 4)) * 2, n4 = (i % (N / 4)) * 4;
+        const float4 w0 = *reinterpret_cast<const float4*>(W + (size_t)k * N + n4), w1 = *reinterpret_cast<const float4*>(W + (size_t)(k + 1) * N + n4);
+        const float a0[4] = {w0.x, w0.y, w0.z, w0.w}, a1[4] = {w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float r0 = bf_drop_hi(a0[j]), r1 = bf_drop_hi(a1[j]);
+            unsigned char* d = sW + (size_t)(n4 + j) * PITCH + k * 2;
+            *reinterpret_cast<unsigned*>(d) = bf_pack_hi(a1[j], a0[j]);
+            *reinterpret_cast<unsigned*>(d + (size_t)N * PITCH) = bf_pack_hi(r1, r0);
+            *reinterpret_cast<unsigned*>(d + (size_t)2 * N * PITCH) = bf_pack_hi(bf_drop_hi(r1), bf_drop_hi(r0));
+        }
+    }
+    if constexpr (ACT)
+        for (int i = t; i < K; i += 256) { sC[i] = in_scale[i]; sC[K + i] = in_shift[i]; }
+    float bv[NT], csum[NT], csq[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { bv[nt] = bias ? bias[nt * 32 + l31] : 0.f; csum[nt] = csq[nt] = 0.f; }
+    const int ntiles = rows >> 7;
+    float4 xr[KH / 4], xn[KH / 4];
+    auto fetch = [&](int tile, float4* d) {
+        const float* p = X + (size_t)((tile << 7) + wave * 32 + l31) * ldx + KH * kh;
+#pragma unroll
+        for (int i = 0; i < KH / 4; ++i) d[i] = *reinterpret_cast<const float4*>(p + 4 * i);
+    };
+    if ((int)blockIdx.x < ntiles) fetch((int)blockIdx.x, xn);
+    __syncthreads();
+    const unsigned char* pb = sW + (size_t)l31 * PITCH + KH * kh * 2;
+    for (int tile = (int)blockIdx.x; tile < ntiles; tile += (int)gridDim.x) {
+#pragma unroll
+        for (int i = 0; i < KH / 4; ++i) xr[i] = xn[i];
+        if (tile + (int)gridDim.x < ntiles) fetch(tile + (int)gridDim.x, xn);
+        f32x16 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const float4 a0 = xr[2 * s], a1 = xr[2 * s + 1];
+            float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            if constexpr (ACT) {
+                const float4 s0 = *reinterpret_cast<const float4*>(sC + KH * kh + 8 * s), s1 = *reinterpret_cast<const float4*>(sC + KH * kh + 8 * s + 4);
+                const float4 h0 = *reinterpret_cast<const float4*>(sC + K + KH * kh + 8 * s), h1 = *reinterpret_cast<const float4*>(sC + K + KH * kh + 8 * s + 4);
+                const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+                const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float y = __fadd_rn(__fmul_rn(v[j], sc[j]), sh[j]);       // two roundings: act1's operand
+                    v[j] = y > 0.f ? y : 0.f;
+                }
+            }
+            u32x4 ap[3];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float x0 = v[2 * j], x1 = v[2 * j + 1];
+                const float r0 = bf_drop_hi(x0), r1 = bf_drop_hi(x1);
+                ap[0][j] = bf_pack_hi(x1, x0);
+                ap[1][j] = bf_pack_hi(r1, r0);
+                ap[2][j] = bf_pack_hi(bf_drop_hi(r1), bf_drop_hi(r0));
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                u32x4 bp[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) bp[p] = *reinterpret_cast<const u32x4*>(pb + (size_t)(p * N + nt * 32) * PITCH + 16 * s);
+#define MF(ia, ib) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ap[ia]), __builtin_bit_cast(bf16x8, bp[ib]), acc[nt], 0, 0, 0)
+                MF(2, 0); MF(0, 2); MF(1, 1); MF(1, 0); MF(0, 1); MF(0, 0);
+#undef MF
+                __builtin_amdgcn_sched_barrier(0);               // (or hipcc hoists every step's B fragments to the top: 308 registers, one workgroup per CU)
+            }
+        }
+        const int m0 = (tile << 7) + wave * 32;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            if constexpr (POOL) pool32_tile(acc[nt], bv[nt], lane, po, (size_t)(m0 >> 5) * N + nt * 32 + l31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float y = acc[nt][r] + bv[nt];
+                Y[(size_t)(m0 + 4 * kh + (r & 3) + 8 * (r >> 2)) * ldy + nt * 32 + l31] = y;
+                csum[nt] += y;
+                csq[nt] = __builtin_fmaf(y, y, csq[nt]);
+            }
+        }
+    }
+    if (stats) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            csum[nt] += __shfl_xor(csum[nt], 32, 64);
+            csq[nt] += __shfl_xor(csq[nt], 32, 64);
+            if (lane < 32) { sRed[(wave * 2 + 0) * N + nt * 32 + lane] = csum[nt]; sRed[(wave * 2 + 1) * N + nt * 32 + lane] = csq[nt]; }
+        }
+        __syncthreads();
+        float* ws = stats + (size_t)blockIdx.x * 2 * N;
+        for (int j = t; j < N; j += 256) {
+            float sm = 0.f, q = 0.f;
+            for (int w = 0; w < 4; ++w) { sm += sRed[(w * 2 + 0) * N + j]; q += sRed[(w * 2 + 1) * N + j]; }
+            ws[j] = sm;
+            ws[N + j] = q;
+        }
+    }
+}
+// the shapes the split kernel takes: cin 32 / 64, cout 32 / 64 / 128, rows a multiple of 128 and at least 65536 (below that the layer is launch- and
+// latency-bound, not issue-bound), dense W, 16-byte rows
+static bool fwd_split_go(long rows, int cin, int cout, const float* X, int ldx, const float* in_scale, const float* in_shift, const float* W, const float* bias,
+                         float* Y, int ldy, float* stats, PoolOut po, hipStream_t st) {
+    static const int on = env_int("GSPN_MFMA_SPLIT", 0);
+    if (!on || rows < 65536 || (rows & 127) || rows >= (1L << 31) || !vec_ok(X, ldx) || !vec_ok(W, cout)) return false;
+    if (!((cin == 32 || cin == 64) && (cout == 32 || cout == 64 || cout == 128))) return false;
+    const dim3 g(fwd_blocks(rows, cout));
+#define FS_GO(K_, N_, A_, P_) do { const size_t dyn = 3 * N_ * (K_ * 2 + 16) + 2 * K_ * 4 + 8 * N_ * 4;                                              \
+        hipLaunchKernelGGL((fwd_split_kernel<K_, N_, A_, P_>), g, dim3(256), dyn, st, (int)rows, X, ldx, in_scale, in_shift, W, bias, Y, ldy, stats, po); } while (0)
+#define FS_P(K_, N_, A_) do { if (po.vmax) FS_GO(K_, N_, A_, true); else FS_GO(K_, N_, A_, false); } while (0)
+#define FS_A(K_, N_) do { if (in_scale) FS_P(K_, N_, true); else FS_P(K_, N_, false); } while (0)
+#define FS_N(K_) do { if (cout == 32) FS_A(K_, 32); else if (cout == 64) FS_A(K_, 64); else FS_A(K_, 128); } while (0)
+    if (cin == 32) FS_N(32); else FS_N(64);
+#undef FS_N
+#undef FS_A
+#undef FS_P
+#undef FS_GO
+    return true;
+}
+
 static int mlp_fwd_impl(long rows, int cin, int cout, const float* X, int ldx, const float* in_scale, const float* in_shift,
                         const float* W, const float* bias, float* Y, int ldy, float* stats, PoolOut po, void* stream,
                         const GatherSrc* gsrc = nullptr) {
@@ -974,6 +1132,7 @@ static int mlp_fwd_impl(long rows, int cin, int cout, const float* X, int ldx, c
     if (rows == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     {
+        if (!gsrc && (!po.vmax || !(rows & 31)) && fwd_split_go(rows, cin, cout, X, ldx, in_scale, in_shift, W, bias, Y, ldy, stats, po, st)) return gspn_launch_status();
         static const int lean_on = env_int("GSPN_FWD_LEAN", 1);             // (A/B hook)
         static const int lean_bn = env_int("GSPN_FWD_LEAN_BN", 0);          // (tuning hook)
         // (beyond ~0.75 M rows the eight 32-column blocks of a 256-column layer re-read X from beyond the L2s: 1 M x 128 -> 256 946 us against

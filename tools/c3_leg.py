@@ -15,6 +15,8 @@ gt = torch.randn(b * 256, 512, 3, device=dev, generator=gen)
 mask = (torch.rand(b * 256, device=dev, generator=gen) > 0.2).float()
 col_g = col.clone().requires_grad_(True)
 def step():
+    for p_ in tf_util.get_variable_store().parameters():
+        p_.grad = None
     pred = pred0.clone().requires_grad_(True)
     _, new_points, _, _ = multi_encoding_net(xyz, col_g, 256, [0.5, 1.0, 1.5], [256, 256, 512], [[64, 128, 256]] * 3, [], True, 0.5, 'c3', use_xyz=True)
     loss = new_points.mean() + chamfer_recons_loss(pred, gt, mask)
