@@ -1,6 +1,6 @@
-"""The opt-in forward kernel on 3 x bf16 operand pieces (GSPN_MFMA_SPLIT=1, gspn_amd/csrc/mlp.hip fwd_split_kernel) against fp64,
-at the SAME tolerance as the exact-fp32 kernels (1e-5 of max |y|, BASELINE.json north_star), and beside them: the switch is read once per
-process, so the check runs in a child process with the switch set."""
+"""The forward kernels of the long thin layers against fp64 at ONE tolerance (1e-5 of max |y|, BASELINE.json north_star): the default
+(exact fp32 products) and the opt-in kernel on 3 x bf16 operand pieces (GSPN_MFMA_SPLIT=1, fwd_split_kernel).  The switch
+is read once per process, so each check runs in a child process."""
 import os
 import subprocess
 import sys
@@ -17,7 +17,7 @@ dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev).manual_seed(5)
 worst = 0.0
 for (rows, cin, cout, act, pool) in ((65536, 32, 32, True, False), (131072, 64, 128, True, True), (65536, 64, 64, False, False), (262144, 32, 64, True, True),
-                                     (65536 + 128, 64, 32, True, False)):
+                                     (65536 + 128, 64, 32, True, False), (262144 + 384, 64, 64, True, False), (524288, 64, 128, True, True), (262144, 32, 32, False, True)):
     X = torch.randn(rows, cin, device=dev, generator=g) * 1.5 + 0.2
     W = torch.randn(cin, cout, device=dev, generator=g) * 0.1
     bias = torch.rand(cout, device=dev, generator=g) - 0.5
@@ -51,9 +51,9 @@ print("WORST %.3g" % worst)
 '''
 
 
-@pytest.mark.parametrize("split", ["1", "0"])
-def test_forward_on_bf16_pieces_meets_the_fp32_tolerance(split):
-    env = dict(os.environ, GSPN_MFMA_SPLIT=split)
+@pytest.mark.parametrize("switches", [{}, {"GSPN_MFMA_SPLIT": "1"}], ids=["default", "bf16_pieces"])
+def test_long_layer_forward_kernels_meet_the_fp32_tolerance(switches):
+    env = dict(os.environ, **switches)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", CHILD], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
