@@ -16,7 +16,7 @@ from gspn_amd.fea_extractor import pn2_geometry
 
 lib = L.lib()
 dev = torch.device("cuda", 0)
-xyz_np, _ = bench.synth(8, 32768, 0)
+xyz_np, _ = bench.synth(8, 32768, 0, os.environ.get("GSPN_GATHER_KIND", "U"))
 xyz = torch.from_numpy(xyz_np).to(dev)
 G = pn2_geometry(xyz)
 gen = torch.Generator(device=dev).manual_seed(3)
