@@ -76,6 +76,7 @@ SIGNATURES = {
     "gspn_mlp_fwd": [_L, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P],
     "gspn_mlp_fwd_pool32": [_L, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P],
     "gspn_pool32_select": [_L, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P],
+    "gspn_pool32_select_groups": [_L, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P],
     "gspn_sa_rel": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "gspn_sa_rel_shift": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     "gspn_mlp_gather_cin": [_c.POINTER(GatherArgs)],
@@ -132,7 +133,7 @@ SPECIAL = {
     "gspn_ball_ws_bytes": ([_I, _I, _I], _L),
 }
 
-ABI_VERSION = 7         # == GSPN_ABI_VERSION of include/gspn_hip.h this binding was written against
+ABI_VERSION = 8         # == GSPN_ABI_VERSION of include/gspn_hip.h this binding was written against
 
 _lib = None
 

@@ -213,6 +213,72 @@ extern "C" int gspn_pool32_select(long groups, int c, float* vmax, const int* am
     return gspn_launch_status();
 }
 
+// The same for a max-pool over ns = 32 * sub rows (the proposal head's 256 / 512-row groups, model_rpointnet.py:68): the forward launch
+// left the maximum and its row offset of every 32-row tile; a group's maximum is the first largest of its `sub` tile maxima (ascending
+// tiles, strict '>': the first row that reaches the maximum, as the tile epilogue picks it inside a tile).  Replaces a pass over the
+// (rows, c) tensor (bnrelu_maxpool4_kernel: 1 GB at the 1 M-row branch of the configs[3] shard) by one over (rows / 32, c).  Channels with
+// a negative scale take the group MINIMUM from Y.  yarg (groups, c) receives y at the arg row (what gspn_pool_rsum reads in backward).
+__global__ void pool_select_groups_kernel(long total4, int sub, int c4, PoolOut po, const float* __restrict__ Y, int ldy, const float* __restrict__ scale,
+                                          const float* __restrict__ shift, float* __restrict__ out, int* __restrict__ arg, float* __restrict__ yarg) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+        const long g = i / c4;
+        const int col = (int)(i - g * c4) * 4;
+        const long c = 4L * c4;
+        const float4 sc = *reinterpret_cast<const float4*>(scale + col), sh = *reinterpret_cast<const float4*>(shift + col);
+        const float* pv = po.vmax + (g * sub) * c + col;
+        const int* pa = po.amax + (g * sub) * c + col;
+        float4 best = *reinterpret_cast<const float4*>(pv);
+        int4 bi = *reinterpret_cast<const int4*>(pa);
+        for (int k0 = 1; k0 < sub; k0 += 4) {
+            float4 v[4];
+            int4 a[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = min(k0 + u, sub - 1);
+                v[u] = *reinterpret_cast<const float4*>(pv + (size_t)k * c);
+                a[u] = *reinterpret_cast<const int4*>(pa + (size_t)k * c);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = k0 + u;
+                if (k < sub) {
+                    if (v[u].x > best.x) { best.x = v[u].x; bi.x = 32 * k + a[u].x; }
+                    if (v[u].y > best.y) { best.y = v[u].y; bi.y = 32 * k + a[u].y; }
+                    if (v[u].z > best.z) { best.z = v[u].z; bi.z = 32 * k + a[u].z; }
+                    if (v[u].w > best.w) { best.w = v[u].w; bi.w = 32 * k + a[u].w; }
+                }
+            }
+        }
+        float y[4] = {best.x, best.y, best.z, best.w};
+        int ai[4] = {bi.x, bi.y, bi.z, bi.w};
+        const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
+        float z[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (scv[j] < 0.f) {                                  // (rare) the group minimum, first row that reaches it
+                const float* p = Y + g * (32L * sub) * ldy + col + j;
+                y[j] = p[0]; ai[j] = 0;
+                for (int k = 1; k < 32 * sub; ++k) { const float t = p[(size_t)k * ldy]; if (t < y[j]) { y[j] = t; ai[j] = k; } }
+            }
+            z[j] = y[j] * scv[j] + shv[j];                       // two roundings, as every other BN application here
+            z[j] = z[j] > 0.f ? z[j] : 0.f;
+        }
+        *reinterpret_cast<float4*>(out + g * c + col) = make_float4(z[0], z[1], z[2], z[3]);
+        *reinterpret_cast<float4*>(yarg + g * c + col) = make_float4(y[0], y[1], y[2], y[3]);
+        if (arg) *reinterpret_cast<int4*>(arg + g * c + col) = make_int4(ai[0], ai[1], ai[2], ai[3]);
+    }
+}
+extern "C" int gspn_pool32_select_groups(long groups, int sub, int c, const float* vmax, const int* amax, const float* Y, int ldy,
+                                         const float* scale, const float* shift, float* out, int* arg, float* yarg, void* stream) {
+    if (groups < 0 || sub <= 0 || c <= 0 || !scale || !shift || !out || !yarg || !Y || !vmax || !amax || ldy < c) return GSPN_ERR_ARG;
+    if (c % 4 || ((uintptr_t)vmax | (uintptr_t)amax | (uintptr_t)scale | (uintptr_t)shift | (uintptr_t)out | (uintptr_t)yarg | (uintptr_t)arg) % 16) return GSPN_ERR_UNSUPPORTED;
+    const long total4 = groups * (c / 4);
+    if (total4 == 0) return 0;
+    PoolOut po{const_cast<float*>(vmax), const_cast<int*>(amax)};
+    hipLaunchKernelGGL(pool_select_groups_kernel, dim3(grid_for(total4, 256)), dim3(256), 0, (hipStream_t)stream, total4, sub, c / 4, po, Y, ldy, scale, shift, out, arg, yarg);
+    return gspn_launch_status();
+}
+
 // ============================================================================================
 // Forward:  Y = act(X).W + bias  (+ column sum / sumsq)
 // grid (persistent row tiles, cout tiles of BN); block 256 = 4 waves, wave w owns rows w*32..+31.

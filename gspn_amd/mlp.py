@@ -24,6 +24,8 @@ DEFER_DW = os.environ.get("GSPN_DEFER_DW", "0") == "1"
 # max-pool over nsample = 32 rows taken from the last layer's accumulators (gspn_mlp_fwd_pool32 + gspn_pool32_select) instead of a pass
 # over the (rows, c) output
 FUSE_POOL32 = os.environ.get("GSPN_FUSE_POOL32", "1") != "0"
+# the same for pools over a multiple of 32 rows (the proposal head's 256 / 512): tile maxima from the forward launch + gspn_pool32_select_groups
+FUSE_POOLN = os.environ.get("GSPN_FUSE_POOLN", "1") != "0"
 # early coefficients (mlp.hip, "Early coefficients"): the BN reductions of a layer are taken before its pass A -- by the epilogue of the
 # next layer's pass B, or from the pool arg-max for the top layer of a pooled stack -- so that pass A is one GEMM instead of two
 EARLY_R = os.environ.get("GSPN_EARLY_R", "1") != "0"
@@ -162,7 +164,8 @@ class _MlpStack(torch.autograd.Function):
                 else:
                     stats = torch.empty(int(lib.gspn_mlp_fwd_stats_bytes(rows, cout)) // 4, dtype=torch.float32, device=dev) if use_stats else None
                 ev = _tic()
-                if FUSE_POOL32 and pool_ns == 32 and li == len(layers) - 1 and rows % 32 == 0:
+                if (FUSE_POOL32 and pool_ns and (pool_ns == 32 or (FUSE_POOLN and pool_ns % 32 == 0 and lp.weights.shape[1] % 4 == 0)) and li == len(layers) - 1 and rows % 32 == 0
+                        and not (li == 0 and (pre is not None or gather is not None))):      # (a one-layer stack with a gathered / pre-aggregated input has no plain forward)
                     g32 = rows // 32
                     pool = (torch.empty((g32, cout), dtype=torch.float32, device=dev), torch.empty((g32, cout), dtype=torch.int32, device=dev))
                     L.check(lib.gspn_mlp_fwd_pool32(rows, cin, cout, L.ptr(cur), cur_ld, L.ptr(in_scale), L.ptr(in_shift), L.ptr(lp.weights),
@@ -219,9 +222,14 @@ class _MlpStack(torch.autograd.Function):
                 groups = rows // pool_ns
                 out = torch.empty((groups, cl), dtype=torch.float32, device=dev)
                 arg = torch.empty((groups, cl), dtype=torch.int32, device=dev)
-                if pool is not None:             # the group extrema came out of the last forward launch: finish on (groups, c) elements
+                if pool is not None and pool_ns == 32:             # the group extrema came out of the last forward launch: finish on (groups, c) elements
                     L.check(lib.gspn_pool32_select(groups, cl, L.ptr(pool[0]), L.ptr(pool[1]), L.ptr(cur), cur_ld,
                                                    L.ptr(in_scale), L.ptr(in_shift), L.ptr(out), L.ptr(arg), st), "pool32_select")
+                elif pool is not None:           # groups of 32 * sub rows: the first largest of the tile maxima
+                    yarg = torch.empty((groups, cl), dtype=torch.float32, device=dev)
+                    L.check(lib.gspn_pool32_select_groups(groups, pool_ns // 32, cl, L.ptr(pool[0]), L.ptr(pool[1]), L.ptr(cur), cur_ld,
+                                                          L.ptr(in_scale), L.ptr(in_shift), L.ptr(out), L.ptr(arg), L.ptr(yarg), st), "pool32_select_groups")
+                    pool = (yarg, None)
                 else:
                     L.check(lib.gspn_bnrelu_maxpool(groups, pool_ns, cl, L.ptr(cur), cur_ld, L.ptr(in_scale), L.ptr(in_shift),
                                                     L.ptr(out), L.ptr(arg), st), "bnrelu_maxpool")

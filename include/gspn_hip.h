@@ -35,8 +35,9 @@ extern "C" {
  *   3: round 3 (gspn_sa_rel_shift, gspn_bn_apply, gspn_mlp_gemm_*, status word of the multi-CU FPS checked).
  *   4: round 3 (gspn_mlp_bwd_fused, gspn_mlp_bwd_fused_work_bytes).   5: round 3 (gspn_dense_rsum; the fused launch's pooled form).
  *   6: round 3 (gspn_fps_cells_prepass_order, gspn_bn_colsum / gspn_bn_apply_grad of tf_util's stand-alone batch norm).
+ *   8: round 4 (gspn_pool32_select_groups).
  *   7: round 4 (gspn_nmdistance_grad_csr, gspn_bn_finalize_parts_pivot, gspn_mlp_bwd_fused_coef, gspn_dot, gspn_queryballpoint_ws; gspn_queryballpoint now launches a prefix scan + a continuation kernel -- same output). */
-#define GSPN_ABI_VERSION 7
+#define GSPN_ABI_VERSION 8
 int gspn_dist_policy(void);
 int gspn_abi_version(void);
 
@@ -241,6 +242,11 @@ int gspn_mlp_fwd_pool32(long rows, int cin, int cout, const float* X, int ldx, c
                         const float* W, const float* bias, float* Y, int ldy, float* stats, float* vmax, int* amax, void* stream);
 int gspn_pool32_select(long groups, int c, float* vmax, const int* amax, const float* Y, int ldy,
                        const float* scale, const float* shift, float* out, int* arg, void* stream);
+/* The same for groups of ns = 32 * sub rows (model_rpointnet.py:68: max over 256 / 512 grouped rows): vmax / amax (groups * sub, c) as
+ * gspn_mlp_fwd_pool32 left them (not modified); out, arg (row offset inside the group, 0 .. ns-1), yarg (y at the arg row) are (groups, c).
+ * c a multiple of 4, 16-byte aligned arrays (GSPN_ERR_UNSUPPORTED otherwise: the caller then runs gspn_bnrelu_maxpool over Y). */
+int gspn_pool32_select_groups(long groups, int sub, int c, const float* vmax, const int* amax, const float* Y, int ldy,
+                              const float* scale, const float* shift, float* out, int* arg, float* yarg, void* stream);
 /* bytes of the `stats` workspace for a (rows, cout) layer */
 long gspn_mlp_fwd_stats_bytes(long rows, int cout);
 

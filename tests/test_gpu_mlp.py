@@ -274,6 +274,33 @@ def test_pool_in_the_forward_epilogue_equals_the_pool_kernel(rows, cin, chans, m
         assert rel_err(a, b) < 1e-6
 
 
+@pytest.mark.parametrize("rows,cin,chans,ns", [(8192, 6, [64, 128], 256), (4096 + 512, 35, [64, 128, 256], 512), (2048, 32, [64], 64), (1920, 16, [32, 36], 96)])
+def test_pool_over_a_multiple_of_32_rows_from_the_tile_maxima(rows, cin, chans, ns, monkeypatch):
+    """pools over 32 * sub rows (the proposal head's 256 / 512, model_rpointnet.py:68): the first largest of the forward epilogue's tile
+    maxima (gspn_pool32_select_groups) returns the same pooled values, bit for bit, as the stand-alone pass over the (rows, c) tensor,
+    an arg-max that selects the same value, and the same gradients; negative BN scales take the group MINIMUM of the raw output"""
+    from gspn_amd import mlp as M
+    g = torch.Generator().manual_seed(rows + ns)
+    ld = (cin + 3) // 4 * 4
+    x = torch.randn(rows, ld, generator=g)
+    x[:, cin:] = 0
+    outs = []
+    for fuse in (False, True):
+        monkeypatch.setattr(M, "FUSE_POOLN", fuse)
+        ps = make_params(chans, cin, seed=5)
+        ps[-1]["gamma"][::3] *= -1.0                      # every third channel of the pooled layer: negative scale
+        layers = to_layers(ps)
+        xx = x.cuda().requires_grad_(True)
+        out = M.mlp_stack(xx, cin, layers, True, 0.7, pool_ns=ns)
+        out.square().sum().backward()
+        outs.append((out.detach().clone(), xx.grad.clone(), [lp.weights.grad.clone() for lp in layers], [lp.gamma.grad.clone() for lp in layers]))
+    assert outs[0][0].shape == (rows // ns, chans[-1])
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert rel_err(outs[1][1], outs[0][1]) < 1e-6          # equal unless two rows of a group tie exactly (then either is a valid arg-max)
+    for a, b in zip(outs[1][2] + outs[1][3], outs[0][2] + outs[0][3]):
+        assert rel_err(a, b) < 1e-6
+
+
 @pytest.mark.parametrize("rows,cin,chans,ns", [(4096, 32, [32, 64, 48], 32), (2048, 67, [64, 64, 128], 32), (3000, 20, [24, 40, 16], None), (1024, 131, [128, 256], 32)])
 def test_early_coefficients_equal_the_two_product_pass(rows, cin, chans, ns, monkeypatch):
     """mlp.EARLY_R: BN reductions taken by the previous pass-B epilogue / the pool arg-max, pass A as ONE GEMM on dY -- same gradients
