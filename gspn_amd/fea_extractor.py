@@ -9,13 +9,20 @@ from .pointnet_util import pointnet_fp_module, pointnet_sa_module
 PN2_SA_SPEC = ((2048, 0.2, 32), (512, 0.4, 32), (128, 0.8, 32))
 
 
-def pn2_geometry(xyz):
+def pn2_first_fps(xyz):
+    """the first launch chain of pn2_geometry alone (FPS of SA level 1, ~2/3 of a scene's geometry time): a caller that prefetches several
+    batches enqueues this for all of them before the rest of any (pn2_geometry(xyz, fps0=...) on the same stream)"""
+    from .tf_sampling import farthest_point_sample
+    return farthest_point_sample(PN2_SA_SPEC[0][0], xyz.detach(), return_order=True)
+
+
+def pn2_geometry(xyz, fps0=None):
     """Everything pn2_fea_extractor derives from coordinates alone: FPS + ball query of the three SA levels and the
     3-NN weights of the three FP levels.  Feed it to pn2_fea_extractor(..., geometry=...) -- typically computed for
-    the next batch on a GeometryStream (geometry.py) while the current batch trains."""
+    the next batch on a GeometryStream (geometry.py) while the current batch trains.  fps0: pn2_first_fps(xyz), already enqueued."""
     sa, cur = [], xyz
     for level, (npoint, radius, nsample) in enumerate(PN2_SA_SPEC):
-        g = sa_geometry(cur, npoint, radius, nsample, inverse=level > 0)      # level 0 groups the raw colours: no gradient flows there
+        g = sa_geometry(cur, npoint, radius, nsample, inverse=level > 0, fps=fps0 if level == 0 else None)      # level 0 groups the raw colours: no gradient flows there
         sa.append(g)
         cur = g.new_xyz
     l1, l2, l3 = sa[0].new_xyz, sa[1].new_xyz, sa[2].new_xyz

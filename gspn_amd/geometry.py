@@ -71,10 +71,12 @@ def sa_front(xyz, new_xyz, idx, shift=None):
     return rel, gidx
 
 
-def sa_geometry(xyz, npoint, radius, nsample, knn=False, inverse=True, front=True):
-    """pointnet_util.py:38-40: centres by FPS, neighbours by ball query (or kNN); front: also the coordinate half of the grouping."""
+def sa_geometry(xyz, npoint, radius, nsample, knn=False, inverse=True, front=True, fps=None):
+    """pointnet_util.py:38-40: centres by FPS, neighbours by ball query (or kNN); front: also the coordinate half of the grouping.
+    fps: (fps_idx, scan_order) of farthest_point_sample(npoint, xyz, return_order=True) when the caller has already enqueued it (on the
+    same stream) -- the long pole of a scene's geometry, worth starting before the host enqueues anything else"""
     xyz = xyz.detach()
-    fps_idx, scan_order = farthest_point_sample(npoint, xyz, return_order=True)
+    fps_idx, scan_order = fps if fps is not None else farthest_point_sample(npoint, xyz, return_order=True)
     new_xyz = gather_point(xyz, fps_idx)
     if knn:
         _, idx = knn_point(nsample, xyz, new_xyz)
