@@ -440,6 +440,8 @@ def main():
     if step_ev is not None:
         per = [step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps)]
         step_median_ms = float(np.median(per))             # GPU time between the ends of consecutive steps on the layers' stream
+        if os.environ.get("GSPN_BENCH_DUMP_STEPS") == "1" and rank == 0:      # (diagnostic)
+            print("per-step ms on the layers' stream: " + " ".join("%.2f" % v for v in per) + "   | sum %.2f of %.2f ms wall" % (sum(per), dt * 1e3), file=sys.stderr)
     if tf_sampling.PROFILE is not None:
         drain_events(final=True)
     tf_sampling.PROFILE = None
