@@ -1304,9 +1304,23 @@ extern "C" int gspn_mlp_fwd_pool32(long rows, int cin, int cout, const float* X,
 // BN finalize / element-wise tails
 // ============================================================================================
 // wave-wide sum of a double (all lanes get the total)
+// The butterfly v += v[lane ^ s], s = 32, 16, 8, 4, 2, 1.  The four steps inside a 16-lane row go through DPP moves (a few cycles each) instead
+// of ds_bpermute (an LDS-crossbar round trip each, twelve of them in a dependent chain for one double): row_ror:8 / row_ror:4 stand in for
+// lane ^ 8 / lane ^ 4 -- after the previous step lanes i and i ^ 8 (i ^ 4) hold the same bits, so the rotated partner holds exactly what the
+// xor partner holds -- and quad_perm for lane ^ 2, lane ^ 1.  Same operands in the same order at every step: bit-identical sums.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum_f64(double v) {
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s, 64);
+    v += __shfl_xor(v, 32, 64);
+    v += __shfl_xor(v, 16, 64);
+    v += dpp_f64<0x128>(v);          // row_ror:8
+    v += dpp_f64<0x124>(v);          // row_ror:4
+    v += dpp_f64<0x4E>(v);           // quad_perm [2,3,0,1]
+    v += dpp_f64<0xB1>(v);           // quad_perm [1,0,3,2]
     return v;
 }
 // one WORKGROUP per channel: 256 threads stride over the forward's per-block partials (double accumulation), then finalise
@@ -1320,6 +1334,15 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(long rows, int c, cons
     __shared__ double sh2[2][4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int j = blockIdx.x;
+    // (the channel's constants are asked for BEFORE the partial rows: behind the reduction they were one more dependent memory round trip)
+    float mm0 = 0.f, mv0 = 0.f, g = 1.f, be = 0.f, pv = 0.f;
+    if (threadIdx.x == 0) {
+        if (moving_mean) mm0 = moving_mean[j];
+        if (moving_var) mv0 = moving_var[j];
+        if (gamma) g = gamma[j];
+        if (beta) be = beta[j];
+        if (pivot) pv = pivot[j];
+    }
     double mu, v;
     if (is_training) {
         double a0 = 0.0, a1 = 0.0;
@@ -1333,18 +1356,16 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(long rows, int c, cons
         mu = a0 / (double)rows;
         v = a1 / (double)rows - mu * mu;                   // biased variance (tf.nn.moments)
         if (v < 0.0) v = 0.0;
-        if (pivot) mu += (double)pivot[j];
+        if (pivot) mu += (double)pv;
     } else {
-        mu = moving_mean[j];
-        v = moving_var[j];
+        mu = mm0;
+        v = mv0;
     }
     if (threadIdx.x != 0) return;
     if (is_training) {
-        if (moving_mean) moving_mean[j] = (float)((double)moving_mean[j] * decay + mu * (1.0 - (double)decay));
-        if (moving_var) moving_var[j] = (float)((double)moving_var[j] * decay + v * (1.0 - (double)decay));
+        if (moving_mean) moving_mean[j] = (float)((double)mm0 * decay + mu * (1.0 - (double)decay));
+        if (moving_var) moving_var[j] = (float)((double)mv0 * decay + v * (1.0 - (double)decay));
     }
-    const float g = gamma ? gamma[j] : 1.f;
-    const float be = beta ? beta[j] : 0.f;
     const float inv = (float)(1.0 / sqrt(v + (double)eps)) * g;       // inv = rsqrt(var+eps)*gamma
     mean[j] = (float)mu;
     var[j] = (float)v;
@@ -2861,6 +2882,8 @@ __device__ __forceinline__ void bwd_coef_block(const CoefJob& q, int n, double (
     float* __restrict__ cA = q.cA; float* __restrict__ cB = q.cB; float* __restrict__ cC = q.cC;
     float* __restrict__ dgamma = q.dgamma; float* __restrict__ dbeta = q.dbeta; float* __restrict__ dbias = q.dbias;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    float g0 = 1.f, v0 = 1.f, m0 = 0.f;                                // (asked for before the partial rows, see bn_finalize_kernel)
+    if (t == 0) { if (gamma) g0 = gamma[n]; v0 = var[n]; m0 = mean[n]; }
     double a0 = 0.0, a1 = 0.0;
     for (int p = t; p < nparts; p += 256) { a0 += (double)part[(size_t)p * 2 * c + n]; a1 += (double)part[(size_t)p * 2 * c + c + n]; }
     a0 = wave_sum_f64(a0); a1 = wave_sum_f64(a1);
@@ -2870,9 +2893,9 @@ __device__ __forceinline__ void bwd_coef_block(const CoefJob& q, int n, double (
     const double r0 = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
     const double r1 = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
     const double R = (double)rows;
-    const double g = gamma ? (double)gamma[n] : 1.0;
-    const double rstd = 1.0 / sqrt((double)var[n] + (double)eps);
-    const double mu = (double)mean[n];
+    const double g = (double)g0;
+    const double rstd = 1.0 / sqrt((double)v0 + (double)eps);
+    const double mu = (double)m0;
     cA[n] = (float)(g * rstd);                                         // same formulas as wgrad_small_reduce_kernel (training-mode BN)
     cB[n] = (float)(-g * rstd * rstd * (r1 / R));
     cC[n] = (float)(-g * rstd * (r0 / R - mu * rstd * (r1 / R)));
