@@ -301,6 +301,24 @@ def test_pool_over_a_multiple_of_32_rows_from_the_tile_maxima(rows, cin, chans, 
         assert rel_err(a, b) < 1e-6
 
 
+def test_grouped_pool_select_entry_point_rejects_what_it_cannot_take():
+    """gspn_pool32_select_groups: argument errors and the shapes it leaves to gspn_bnrelu_maxpool (c not a multiple of 4), like the other entry points
+    of the boundary (-1 = argument rejected, -2 = unsupported: include/gspn_hip.h)"""
+    from gspn_amd import _lib as L
+    lib = L.lib()
+    dev = torch.device("cuda", 0)
+    groups, sub, c = 8, 4, 6
+    vmax = torch.zeros(groups * sub, c, device=dev); amax = torch.zeros(groups * sub, c, dtype=torch.int32, device=dev)
+    Y = torch.zeros(groups * sub * 32, c, device=dev); sc = torch.ones(c, device=dev); sh = torch.zeros(c, device=dev)
+    out = torch.empty(groups, c, device=dev); arg = torch.empty(groups, c, dtype=torch.int32, device=dev); yarg = torch.empty(groups, c, device=dev)
+    call = lambda g_, s_, c_, ld_, ya: lib.gspn_pool32_select_groups(g_, s_, c_, L.ptr(vmax), L.ptr(amax), L.ptr(Y), ld_, L.ptr(sc), L.ptr(sh), L.ptr(out), L.ptr(arg), ya, L.stream())
+    assert call(groups, sub, c, c, L.ptr(yarg)) == -2          # c % 4
+    assert call(groups, 0, 8, 8, L.ptr(yarg)) == -1            # sub
+    assert call(groups, sub, 8, 4, L.ptr(yarg)) == -1          # ldy < c
+    assert call(groups, sub, 8, 8, None) == -1                 # yarg is required
+    assert call(0, sub, 8, 8, L.ptr(yarg)) == 0                # nothing to do
+
+
 @pytest.mark.parametrize("rows,cin,chans,ns", [(4096, 32, [32, 64, 48], 32), (2048, 67, [64, 64, 128], 32), (3000, 20, [24, 40, 16], None), (1024, 131, [128, 256], 32)])
 def test_early_coefficients_equal_the_two_product_pass(rows, cin, chans, ns, monkeypatch):
     """mlp.EARLY_R: BN reductions taken by the previous pass-B epilogue / the pool arg-max, pass A as ONE GEMM on dY -- same gradients
