@@ -1477,11 +1477,33 @@ __global__ void bnrelu_apply_kernel(long total, int c, const float* __restrict__
         out[row * ldo + col] = z;
     }
 }
+// the same, four channels per thread (16-byte rows): the scalar form above pays a 64-bit division and 4-byte accesses per element (4.1 TB/s on the
+// 134 MB of the extractor's output; this one streams)
+__global__ void bnrelu_apply4_kernel(long total4, int c4, const float* __restrict__ Y, int ldy, const float* __restrict__ scale,
+                                     const float* __restrict__ shift, float* __restrict__ out, int ldo) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+        const long row = i / c4;
+        const int col = (int)(i - row * c4) * 4;
+        float4 z = *reinterpret_cast<const float4*>(Y + row * ldy + col);
+        if (scale) {
+            const float4 sc = *reinterpret_cast<const float4*>(scale + col), sh = *reinterpret_cast<const float4*>(shift + col);
+            z.x = z.x * sc.x + sh.x; z.x = z.x > 0.f ? z.x : 0.f;
+            z.y = z.y * sc.y + sh.y; z.y = z.y > 0.f ? z.y : 0.f;
+            z.z = z.z * sc.z + sh.z; z.z = z.z > 0.f ? z.z : 0.f;
+            z.w = z.w * sc.w + sh.w; z.w = z.w > 0.f ? z.w : 0.f;
+        }
+        *reinterpret_cast<float4*>(out + row * ldo + col) = z;
+    }
+}
 extern "C" int gspn_bnrelu_apply(long rows, int c, const float* Y, int ldy, const float* scale, const float* shift, float* out, int ldo, void* stream) {
     if (rows < 0 || c <= 0 || ldy < c || ldo < c) return GSPN_ERR_ARG;
     if ((scale == nullptr) != (shift == nullptr)) return GSPN_ERR_ARG;
     const long total = rows * c;
     if (total == 0) return 0;
+    if (c % 4 == 0 && ldy % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)Y | (uintptr_t)out | (uintptr_t)scale | (uintptr_t)shift) % 16 == 0) {
+        hipLaunchKernelGGL(bnrelu_apply4_kernel, dim3(grid_for(total / 4, 256)), dim3(256), 0, (hipStream_t)stream, total / 4, c / 4, Y, ldy, scale, shift, out, ldo);
+        return gspn_launch_status();
+    }
     hipLaunchKernelGGL(bnrelu_apply_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, total, c, Y, ldy, scale, shift, out, ldo);
     return gspn_launch_status();
 }
