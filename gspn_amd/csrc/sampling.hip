@@ -209,7 +209,7 @@ __global__ __launch_bounds__(FPS_T) void fps_resident_kernel(int n, int m, const
 //     duplicate of one) repeats the rank-minimal point, like the reference.
 // ============================================================================================
 #ifndef FPS_AMAX
-#define FPS_AMAX 6        // max picks accepted per round
+#define FPS_AMAX 8        // max picks accepted per round (<= 16: four bits per accepted wave in a 64-bit list)
 #endif
 #ifdef FPS_PROFILE
 __device__ long long g_cell_prof[32];
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(FPS_T) void fps_cell_kernel(int n, int m, int csz, 
                                                          const float* __restrict__ inp0, int inp0_stride, int* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // [0,1024)   : candidates, 2 buffers x 16 waves x {int4 {v bits, x, y, z}, int4 {sorted position, bound bits, -, -}}
-    // [1024,1040): batch record written by wave 0
+    // [1024,1056): batch record written by wave 0 (two int4)
     // [1536,1536+64*P): per-wave row for the winning lane's min-distances (refresh)
     // [4096,..)  : z plane, float4 [P/4][1024]   (ZLDS only)
     int4* s_cand = reinterpret_cast<int4*>(smem);
@@ -288,7 +288,8 @@ __global__ __launch_bounds__(FPS_T) void fps_cell_kernel(int n, int m, int csz, 
     const float* p0 = inp0 + (size_t)blockIdx.x * inp0_stride;
     if (t == 0) s_cand[2 * FPS_W + 0] = make_int4(0, __float_as_int(p0[0]), __float_as_int(p0[1]), __float_as_int(p0[2]));
     __syncthreads();
-    int acc_list = 0, abuf = 2 * FPS_W;
+    unsigned long long acc_list = 0;       // (4 bits per accepted wave: up to 16 picks a round)
+    int abuf = 2 * FPS_W;
     int nacc = 1;
     int j = 1;                      // number of outputs written so far
     int wmax = __float_as_int(1e38f);          // wave's current max min-distance (bits); padding-only waves settle at -1.0f
@@ -319,7 +320,7 @@ __global__ __launch_bounds__(FPS_T) void fps_cell_kernel(int n, int m, int csz, 
         unsigned todo;
         {
             const int u = lane < nacc ? lane : 0;
-            const int4 cc = s_cand[abuf + ((acc_list >> (4 * u)) & 15) * 2];
+            const int4 cc = s_cand[abuf + (int)((acc_list >> (4 * u)) & 15ull) * 2];
             const float ccx = __int_as_float(cc.y), ccy = __int_as_float(cc.z), ccz = __int_as_float(cc.w);
             const float ex = fmaxf(fmaxf(bx0 - ccx, ccx - bx1), 0.f);
             const float ey = fmaxf(fmaxf(by0 - ccy, ccy - by1), 0.f);
@@ -330,7 +331,7 @@ __global__ __launch_bounds__(FPS_T) void fps_cell_kernel(int n, int m, int csz, 
         while (todo) {
             const int ci = __builtin_ctz(todo);
             todo &= todo - 1;
-            const int4 cc = s_cand[abuf + ((acc_list >> (4 * ci)) & 15) * 2];          // uniform address: LDS broadcast
+            const int4 cc = s_cand[abuf + (int)((acc_list >> (4 * ci)) & 15ull) * 2];          // uniform address: LDS broadcast
             const float cx = __int_as_float(__builtin_amdgcn_readfirstlane(cc.y));
             const float cy = __int_as_float(__builtin_amdgcn_readfirstlane(cc.z));
             const float cz = __int_as_float(__builtin_amdgcn_readfirstlane(cc.w));
@@ -470,7 +471,8 @@ __global__ __launch_bounds__(FPS_T) void fps_cell_kernel(int n, int m, int csz, 
         const bool slow = __ballot((info.x & 256) && rk < FPS_AMAX) != 0ull;    // equal values among the leaders (rare)
         if (!slow) {
             const int okb = __builtin_amdgcn_readfirstlane(row_or_i32((rk < FPS_AMAX && (info.x & 512)) ? (1 << rk) : 0));
-            const int wl = __builtin_amdgcn_readfirstlane(row_or_i32(rk < FPS_AMAX ? (l15 << (4 * rk)) : 0));       // wave of every rank
+            const unsigned wl = (unsigned)__builtin_amdgcn_readfirstlane(row_or_i32(rk < (FPS_AMAX < 8 ? FPS_AMAX : 8) ? (l15 << (4 * rk)) : 0));       // wave of every rank
+            const unsigned wh = FPS_AMAX > 8 ? (unsigned)__builtin_amdgcn_readfirstlane(row_or_i32((rk >= 8 && rk < FPS_AMAX) ? (l15 << (4 * (rk - 8))) : 0)) : 0u;
             int na = __builtin_ctz(~(unsigned)okb);               // run of acceptable ranks 0, 1, ...
             na = min(na, min(FPS_AMAX, m - j));
             int term = 0;
@@ -482,7 +484,7 @@ __global__ __launch_bounds__(FPS_T) void fps_cell_kernel(int n, int m, int csz, 
                 na = 0;
             }
             nacc = na;
-            acc_list = na > 0 ? (wl & (int)((1ull << (4 * na)) - 1ull)) : 0;
+            acc_list = na > 0 ? ((((unsigned long long)wh << 32) | wl) & (na >= 16 ? ~0ull : ((1ull << (4 * na)) - 1ull))) : 0ull;
             abuf = buf;
             termk = term;
             if (myrank < na) {                                     // own candidate accepted as pick number j+rank: write it, mark consumed
@@ -497,7 +499,8 @@ __global__ __launch_bounds__(FPS_T) void fps_cell_kernel(int n, int m, int csz, 
         }
         // ---- slow path: wave 0 extracts serially with reference-rank tie-breaks, then broadcasts ----
         if (wave == 0) {
-            int na = 0, alist = 0, term = 0, jn = j;
+            int na = 0, term = 0, jn = j;
+            unsigned long long alist = 0;
             int remaining = mine.x;               // value bits; -1.0f once consumed
             unsigned acc_mask = 0;                // bit w: wave w's candidate accepted this round
             int bound = NEG_ONE_BITS;             // max runner-up bound among accepted waves
@@ -530,25 +533,25 @@ __global__ __launch_bounds__(FPS_T) void fps_cell_kernel(int n, int m, int csz, 
                     const bool hit = ((acc_mask >> l15) & 1u) && (dd < __int_as_float(M));
                     if (__ballot(hit) != 0ull) break;
                 }
-                alist |= wsel << (4 * na);
+                alist |= (unsigned long long)wsel << (4 * na);
                 ++na;
                 acc_mask |= 1u << wsel;
                 bound = max(bound, __builtin_amdgcn_readfirstlane(sbound));
                 remaining = (l15 == wsel) ? NEG_ONE_BITS : remaining;
                 ++jn;
             }
-            if (lane == 0) *s_batch = make_int4(na, alist, term, jn);
+            if (lane == 0) { s_batch[0] = make_int4(na, (int)(unsigned)alist, term, jn); s_batch[1] = make_int4((int)(unsigned)(alist >> 32), 0, 0, 0); }
         }
         __syncthreads();
         {
             const int4 br = *s_batch;
             nacc = __builtin_amdgcn_readfirstlane(br.x);
-            acc_list = __builtin_amdgcn_readfirstlane(br.y);
+            acc_list = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(s_batch[1].x) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(br.y);
             abuf = buf;
             termk = __builtin_amdgcn_readfirstlane(br.z);
             const int jnew = __builtin_amdgcn_readfirstlane(br.w);
             for (int u = 0; u < nacc; ++u) {
-                const int wu = (acc_list >> (4 * u)) & 15;
+                const int wu = (int)((acc_list >> (4 * u)) & 15ull);
                 if (wu == wave) {
                     if (lane == 0) o[j + u] = ck;
                     need = true;
