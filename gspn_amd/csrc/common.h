@@ -113,6 +113,7 @@ static inline size_t gspn_claim_lds(int bit, const void* fn, size_t dyn) {
 // streams (one CU per scene, two streams: 2 per XCD), plus the short-lived 8-workgroup FPS launches of the smaller levels.  A grid sized
 // for exactly the CUs that happen to be free runs its last workgroups as a second wave, so the plan leaves 4 CUs per XCD out.
 // Measured on the full step (bench.py, ms per step): 256 -> 3.74, 240 -> 3.68, 224 -> 3.56, 216 -> 3.58, 208 -> 3.60, 192 -> 3.64.
+// Re-swept on round 4's kernels (tools/plan_cus_sweep.sh): 216 -> 1.752, 224 -> 1.740, 232 -> 1.763, 240 -> 1.773 (the layers alone: 1.532 / 1.527 / 1.517 / 1.509).
 #ifndef GSPN_PLAN_CUS
 #define GSPN_PLAN_CUS 224
 #endif
