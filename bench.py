@@ -1035,20 +1035,27 @@ def other_configs(xyz, col, dev):
         gt = torch.randn(b * 256, 512, 3, device=dev, generator=gen)
         mask = (torch.rand(b * 256, device=dev, generator=gen) > 0.2).float()
         col_g = col.clone().requires_grad_(True)
+        side = torch.cuda.Stream(dev)
 
         def c3():
             for p_ in tf_util.get_variable_store().parameters():
                 p_.grad = None                                   # (as c4: a step starts from cleared gradients -- r03's leg accumulated into them, 35 torch adds a step)
             pred = pred0.clone().requires_grad_(True)
+            # the Chamfer term has no input in common with the encoder: it runs on its own stream beside the encoder's FPS (8 CUs busy, 248 idle),
+            # and autograd runs its backward there as well (tools/c3_leg.py C3_SIDE=0 / 1: 8.69 -> 8.54 ms per step)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                ch = chamfer_recons_loss(pred, gt, mask)
             _, new_points, _, _ = multi_encoding_net(xyz, col_g, 256, [0.5, 1.0, 1.5], [256, 256, 512], [[64, 128, 256]] * 3, [], True, 0.5, 'c3', use_xyz=True)
-            loss = new_points.mean() + chamfer_recons_loss(pred, gt, mask)
+            torch.cuda.current_stream().wait_stream(side)
+            loss = new_points.mean() + ch
             loss.backward()
             col_g.grad = None
         t = _time_steps(c3, 2, 5)
         rows = b * 256 * (256 + 256 + 512)
         gf = 3 * 2.0 * rows * (6 * 64 + 64 * 128 + 128 * 256)
         out["configs[3] per-GPU shard"] = {"workload": "8 x 32768 pts: multi_encoding_net(256 seeds, r .5/1/1.5, ns 256/256/512, mlp [64,128,256] x3, use_xyz) + "
-                                                      "Chamfer nn_distance on 2048 x (512,512) clouds, fwd+bwd, eager, geometry inline",
+                                                      "Chamfer nn_distance on 2048 x (512,512) clouds (on a second stream beside the encoder), fwd+bwd, eager, geometry inline",
                                            "ms_per_step": t * 1e3, "scenes_per_s": b / t, "grouped_rows": rows, "mlp_TFLOPs_fwd_bwd_over_whole_step": gf / t / 1e12,
                                            "roofline": {"bound": "mfma_f32", "kernels": "the three 6 -> 64 -> 128 -> 256 stacks (forward, pass A, pass B): 3 x 2 x rows x (6*64 + 64*128 + "
                                                         "128*256) flops over the WHOLE leg (geometry, pooling and Chamfer included in the time)",
@@ -1081,12 +1088,16 @@ def other_configs(xyz, col, dev):
             for p_ in tf_util.get_variable_store().parameters():
                 p_.grad = None
             pred = pred0.clone().requires_grad_(True)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                ch = chamfer_recons_loss(pred, gt, mask)
             _, fea, _, _ = multi_encoding_net(xyz5, col5, 256, [0.5, 1.0, 1.5], [256, 256, 512], [[64, 128, 256]] * 3, [], True, 0.5, 'c4p', use_xyz=True,
                                               shift_pred=shift, fps_idx=seeds)
-            (fea.mean() + chamfer_recons_loss(pred, gt, mask)).backward()
+            torch.cuda.current_stream().wait_stream(side)
+            (fea.mean() + ch).backward()
         t = _time_steps(c4p, 2, 5)
         out["configs[4] per-GPU shard (proposal part)"] = {"workload": "8 x 65536 pts: multi_encoding_net(256 given seeds, stop-gradient shift, r .5/1/1.5, ns 256/256/512, mlp "
-                                                                       "[64,128,256] x3, use_xyz) + Chamfer on 2048 x (512,512) clouds, fwd+bwd, eager", "ms_per_step": t * 1e3,
+                                                                       "[64,128,256] x3, use_xyz) + Chamfer on 2048 x (512,512) clouds (second stream), fwd+bwd, eager", "ms_per_step": t * 1e3,
                                                            "scenes_per_s": b / t,
                                                            "roofline": {"bound": "mfma_f32", "achieved": gf / t / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                                                         "frac": gf / t / 1e12 / MFMA_F32_PEAK_TFLOPS, "kernels": "as configs[3]: the layers' flops over the whole leg"}}

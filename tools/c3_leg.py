@@ -14,12 +14,22 @@ pred0 = torch.randn(b * 256, 512, 3, device=dev, generator=gen)
 gt = torch.randn(b * 256, 512, 3, device=dev, generator=gen)
 mask = (torch.rand(b * 256, device=dev, generator=gen) > 0.2).float()
 col_g = col.clone().requires_grad_(True)
+import os
+SIDE = torch.cuda.Stream() if os.environ.get("C3_SIDE") == "1" else None
 def step():
     for p_ in tf_util.get_variable_store().parameters():
         p_.grad = None
     pred = pred0.clone().requires_grad_(True)
+    if SIDE is not None:                      # the Chamfer term on its own stream, beside the encoder (its backward follows it there)
+        SIDE.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(SIDE):
+            ch = chamfer_recons_loss(pred, gt, mask)
     _, new_points, _, _ = multi_encoding_net(xyz, col_g, 256, [0.5, 1.0, 1.5], [256, 256, 512], [[64, 128, 256]] * 3, [], True, 0.5, 'c3', use_xyz=True)
-    loss = new_points.mean() + chamfer_recons_loss(pred, gt, mask)
+    if SIDE is not None:
+        torch.cuda.current_stream().wait_stream(SIDE)
+    else:
+        ch = chamfer_recons_loss(pred, gt, mask)
+    loss = new_points.mean() + ch
     loss.backward()
     col_g.grad = None
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 6
