@@ -1203,21 +1203,38 @@ static int mlp_fwd_impl(long rows, int cin, int cout, const float* X, int ldx, c
         static const int lean_bn = env_int("GSPN_FWD_LEAN_BN", 0);          // (tuning hook)
         // (beyond ~0.75 M rows the eight 32-column blocks of a 256-column layer re-read X from beyond the L2s: 1 M x 128 -> 256 946 us against
         //  874 for the 128-column register-staged kernel, 1 M x 64 -> 128 274 against 259 for the streaming kernel; 0.5 M rows: 431 / 437, 137 / 151)
-        if (lean_on && !gsrc && rows <= 786432 && vec_ok(X, ldx) && vec_ok(W, cout) && !(rows & 127) && !(cin & 31) && !(cout & 31) && rows * (long)std::max(ldx, ldy) < (1L << 30) && (long)cin * cout < (1L << 30) &&
+        // Beyond that the layer runs as `nsplit` launches over row slabs of at most 0.75 M rows, each with its share of the partial-sum rows (r04: the
+        // configs[3] shard's 1 M x 128 -> 256 layer, 929 us on the register-staged kernel -> 2 x 431)
+        int nsplit = 1;
+        if (rows > 786432 && cout >= 256) {
+            nsplit = (int)((rows + 786431) / 786432);
+            const unsigned nb = fwd_blocks(rows, cout);
+            if (nb % nsplit || rows % ((long)nsplit * 128)) nsplit = 0;
+        } else if (rows > 786432) nsplit = 0;
+        if (lean_on && !gsrc && nsplit >= 1 && vec_ok(X, ldx) && vec_ok(W, cout) && !(rows & 127) && !(cin & 31) && !(cout & 31) && rows * (long)std::max(ldx, ldy) < (1L << 30) && (long)cin * cout < (1L << 30) &&
             (!po.vmax || !(rows & 31))) {
             // 32-column blocks: measured best on every layer shape of the benchmark and of the configs[3] shard (tools/fwd_ablate.py with
             // GSPN_FWD_LEAN_BN = 32 / 64): 131072 x 64 -> 128 35 us against 39 (and 44 for the LDS-DMA streaming kernel), 32768 x 128 -> 256 30 against 40
             int bn = 32;
             if (lean_bn && cout % lean_bn == 0 && lean_bn <= 64) bn = lean_bn;
-            const dim3 g(fwd_blocks(rows, cout), cout / bn);
+            const unsigned nbs = fwd_blocks(rows, cout) / nsplit;
+            const long srows = rows / nsplit;
+            const dim3 g(nbs, cout / bn);
             const size_t dyn = sizeof(float) * 2 * chan_pad(cin);
-#define FL_GO(NT_, A_, P_) hipLaunchKernelGGL((fwd_lean_kernel<NT_, A_, P_>), g, dim3(256), dyn, st, (int)rows, cin, cout, X, ldx, in_scale, in_shift, W, bias, Y, ldy, stats, po)
+            for (int sl = 0; sl < nsplit; ++sl) {
+                const float* Xs = X + (size_t)sl * srows * ldx;
+                float* Ys = Y + (size_t)sl * srows * ldy;
+                float* sts = stats ? stats + (size_t)sl * nbs * 2 * cout : nullptr;
+                PoolOut pos = po;
+                if (po.vmax) { pos.vmax = po.vmax + (size_t)sl * (srows / 32) * cout; pos.amax = po.amax + (size_t)sl * (srows / 32) * cout; }
+#define FL_GO(NT_, A_, P_) hipLaunchKernelGGL((fwd_lean_kernel<NT_, A_, P_>), g, dim3(256), dyn, st, (int)srows, cin, cout, Xs, ldx, in_scale, in_shift, W, bias, Ys, ldy, sts, pos)
 #define FL_P(NT_, A_) do { if (po.vmax) FL_GO(NT_, A_, true); else FL_GO(NT_, A_, false); } while (0)
 #define FL_A(NT_) do { if (in_scale) FL_P(NT_, true); else FL_P(NT_, false); } while (0)
-            if (bn == 64) FL_A(2); else FL_A(1);
+                if (bn == 64) FL_A(2); else FL_A(1);
 #undef FL_A
 #undef FL_P
 #undef FL_GO
+            }
             return gspn_launch_status();
         }
     }
