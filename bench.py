@@ -87,7 +87,10 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="enqueue the layers kernel by kernel instead of replaying a captured hipGraph")
     ap.add_argument("--sync-bn", action="store_true", help="optional SyncBN (global-batch statistics, SURVEY 8e): unfused layers + two small "
                     "all-reduces per layer, no hipGraph; NOT the headline configuration")
-    ap.add_argument("--no-extra", action="store_true", help="skip the post-run legs (per-kernel rooflines of the layers / ball query, other_configs)")
+    ap.add_argument("--detail", action="store_true", help="after the headline run, also run the post-run legs (ball-query / layer / per-op rooflines, "
+                    "the S and D cloud kinds, the other BASELINE configs, the reference's own harness shapes: several child processes, a few minutes) "
+                    "and put them into bench_detail.json.  The stdout line is the same compact object either way.")
+    ap.add_argument("--no-extra", action="store_true", help="(accepted for the tools/ scripts of earlier rounds: the default run has no post-run legs any more)")
     ap.add_argument("--legs-only", action="store_true", help="(internal) run the post-run legs alone and print their JSON: roofline_mlp, other_configs, "
                     "roofline_ops, reference_harness -- bench.py runs itself with this flag in a child process")
     ap.add_argument("--force-collective", action="store_true", help="issue the gradient all-reduce through RCCL even at world size 1 (one-rank "
@@ -459,7 +462,8 @@ def main():
     fps_avg_ms = float(np.mean(fps_ms)) if fps_ms else float("nan")
     achieved = alg_bytes / (fps_avg_ms * 1e-3) / 1e9
     traffic = None
-    pmc = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r04_fps_pmc.json", "r03_fps_pmc.json", "r02_fps_pmc.json", "r01_fps_pmc.json")) if os.path.exists(q)), None)
+    pmc = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r05_fps_pmc.json", "r04_fps_pmc.json", "r03_fps_pmc.json", "r02_fps_pmc.json", "r01_fps_pmc.json")) if os.path.exists(q)), None)
+    traffic_src = ("profiles/" + os.path.basename(pmc)) if pmc else None
     if pmc:
         try:
             pj = json.load(open(pmc))
@@ -495,8 +499,9 @@ def main():
             coll["difference_run_steps"] = nd
     if rank == 0:
         global_batch = SCENES_PER_GPU * world
+        concurrent = GROUP if (PAIRED and geo is not None) else 1
         res = {
-            "metric": "scenes/sec fwd+bwd set-abstraction, 32768 pts, 1/2/4/8 MI355X",
+            "metric": METRIC,
             "value": global_batch * args.steps / dt,
             "unit": "scenes/s",
             "n_gpus": world,
@@ -520,10 +525,12 @@ def main():
             # SURVEY 8(d)'s yardstick: `achieved` = ALGORITHMIC bytes (what the reference's kernel moves: 20 B per point per round) / time.
             # It is an effective rate, not measured bandwidth: the kernel keeps the scene on chip, `traffic` (PMC) is what really
             # crosses HBM, and what bounds the kernel is VALU issue + barrier latency -- hence us_per_pick beside it.
-            "roofline": {"bound": "hbm", "kernel": "fps_cell_kernel<32,true> (SA1: 8 x 32768 -> 2048; its sort pre-pass, 0.07 ms, is timed outside the bracket)", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
-                         "achieved_is": "effective rate = algorithmic bytes / time (the kernel is on-chip resident; see traffic)",
-                         "avg_launch_ms": fps_avg_ms, "us_per_pick": fps_avg_ms * 1e3 / m, "launches_timed": len(fps_ms)},
+            # concurrent_launches: the FPS launches of `concurrent` consecutive batches run side by side (8 CUs each, PAIRED above), so one
+            # launch may last longer than a step although every step contains exactly one.
+            "roofline": {"bound": "hbm", "kernel": "fps_cell_kernel<32,true> (SA1: 8 x 32768 -> 2048)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes,
+                         "achieved_is": "effective rate = algorithmic bytes / time (the kernel is on-chip resident; see traffic); its sort pre-pass, 0.07 ms, is timed outside the bracket",
+                         "avg_launch_ms": fps_avg_ms, "us_per_pick": fps_avg_ms * 1e3 / m, "launches_timed": len(fps_ms), "concurrent_launches": concurrent},
             "geometry_streams": None if geo is None else {"hw_queues_env": os.environ.get("GPU_MAX_HW_QUEUES"), "streams_tried": [g_.tried for g_ in geo],
                                                          "shares_a_queue": [g_.shares_queue for g_ in geo]},
             "host_enqueue_ms_per_step": t_host / args.steps * 1e3,
@@ -532,27 +539,99 @@ def main():
         }
         if coll is not None:
             res["collective"] = coll
-        if world == 1 and not LAYERS_ONLY and (not args.no_extra or args.kind_leg):
+        _stdout_discipline(rank)                                    # whatever the C side buffered so far comes out BEFORE the line
+        if world == 1 and not args.no_cpu_baseline and not args.kind_leg:
+            try:
+                res["cpu_baseline"] = cpu_baseline(xyz_np0, col_np0, full=args.detail)
+            except Exception as e:                                  # the CPU leg never takes the headline down with it
+                print("cpu_baseline failed: %r" % (e,), file=sys.stderr)
+        if world == 1 and not LAYERS_ONLY and (args.detail or args.kind_leg):
             torch.cuda.synchronize()
             try:
                 res["roofline_ball_query"] = ball_query_roofline(bq_prof, batches, G if use_graph else None)
             except Exception as e:                                  # the extra legs never take the headline line down with them
                 res["roofline_ball_query"] = {"error": repr(e)}
-        if world == 1 and not LAYERS_ONLY and not args.no_extra and not args.kind_leg:
+        if world == 1 and not LAYERS_ONLY and args.detail and not args.kind_leg:
             # the same step on the other cloud kinds of SURVEY 8(d) (north_star names ScanNet scenes): short runs in child processes
             res["data_kinds"] = data_kinds_legs(res)
             # The remaining legs (per-kernel rooflines of the layers and of the stand-alone ops, the other configs, the reference's own
             # harness shapes) run in a CHILD process: whatever happens there -- an exception, a crash, a hang -- the headline line above
             # is printed.  (r03: a graph capture inside one of these legs segfaulted and the run printed nothing at all.)
             res.update(run_legs_in_child(args))
-        if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(xyz_np0, col_np0)
-        _stdout_discipline(rank)                                    # whatever the C side buffered so far comes out BEFORE the line
-        print(json.dumps(res), flush=True)
+        if args.kind_leg:
+            print(json.dumps(res), flush=True)                      # (internal child of data_kinds_legs: the parent reads the full object)
+        else:
+            if not LAYERS_ONLY:
+                write_detail(res)
+            print(json.dumps(compact_line(res)), flush=True)
         _stdout_discipline(rank, done=True)                         # ... and nothing after it
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+
+
+METRIC = "scenes/sec fwd+bwd set-abstraction, 32768 pts, 1/2/4/8 MI355X"
+DETAIL_FILE = "bench_detail.json"
+# the keys of the stdout line: everything else lives in bench_detail.json
+LINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "median_ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+             "dtype", "data", "config", "roofline", "cpu_baseline", "detail_file")
+CONFIG_KEYS = ("workload", "scenes_per_gpu", "global_batch", "npoints", "parallelism", "schedule")
+ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms", "launches_timed",
+                 "concurrent_launches")
+CPU_KEYS = ("value", "unit", "cores", "kind", "sample", "all_cores")
+LINE_LIMIT = 4096
+
+
+def _short(v, n):
+    return v if not isinstance(v, str) or len(v) <= n else v[:n - 3] + "..."
+
+
+def _num(v):
+    """six significant digits are plenty for the line (the detail file keeps full precision)"""
+    if isinstance(v, float) and v == v and abs(v) != float("inf"):
+        return float("%.6g" % v)
+    if isinstance(v, float):
+        return None                      # NaN / inf are not JSON
+    return v
+
+
+def compact_line(res):
+    """The ONE stdout line: a fixed key set, numbers at six digits, strings capped, strict JSON, < 4 KB whatever the full result holds."""
+    out = {}
+    for k in LINE_KEYS:
+        if k == "config":
+            c = res.get("config") or {}
+            out[k] = {q: _short(_num(c.get(q)), 200) for q in CONFIG_KEYS}
+        elif k == "roofline":
+            r = res.get("roofline") or {}
+            out[k] = {q: _short(_num(r.get(q)), 120) for q in ROOFLINE_KEYS}
+        elif k == "cpu_baseline":
+            c = res.get("cpu_baseline")
+            if c is None:
+                out[k] = None
+            else:
+                o = {q: _short(_num(c.get(q)), 200) for q in CPU_KEYS if q != "all_cores"}
+                a = c.get("all_cores")
+                o["all_cores"] = None if not a else {"value": _num(a.get("value")), "cores": a.get("cores")}
+                out[k] = o
+        elif k == "detail_file":
+            out[k] = DETAIL_FILE
+        else:
+            out[k] = _short(_num(res.get(k)), 200)
+    line = json.dumps(out, allow_nan=False)
+    assert len(line) < LINE_LIMIT, "bench line grew to %d bytes" % len(line)
+    return out
+
+
+def write_detail(res):
+    """everything the run knows (full precision, prose, the legs of --detail) next to bench.py; a short digest to stderr"""
+    try:
+        with open(os.path.join(ROOT, DETAIL_FILE), "w") as f:
+            json.dump(res, f, indent=1, default=repr)
+    except OSError as e:
+        print("bench_detail.json not written: %r" % (e,), file=sys.stderr)
+    dig = {k: res.get(k) for k in ("host_enqueue_ms_per_step", "host_wait_ms_per_step", "host_replay_ms_per_step", "geometry_streams", "collective") if res.get(k) is not None}
+    print("bench detail (full object in %s): %s" % (DETAIL_FILE, json.dumps(dig, default=repr)), file=sys.stderr)
 
 
 def data_kinds_legs(res_u, kinds=("S", "D"), timeout=600):
@@ -761,7 +840,8 @@ def _ev_time(fn, warm=3, reps=20):
 def _pmc_ops():
     """memory-side bytes per launch of the stand-alone ops (tools/pmc_ops.sh -> profiles/r03_ops_pmc.json: separate --pmc FETCH_SIZE /
     WRITE_SIZE passes over tools/ops_only.py, FETCH_SIZE doubled per MI355X_MICROARCH.md), keyed like the entries below"""
-    q = next((f for f in (os.path.join(ROOT, "profiles", n_) for n_ in ("r04_ops_pmc.json", "r03_ops_pmc.json")) if os.path.exists(f)), None)
+    q = next((f for f in (os.path.join(ROOT, "profiles", n_) for n_ in ("r05_ops_pmc.json", "r04_ops_pmc.json", "r03_ops_pmc.json")) if os.path.exists(f)), None)
+    _pmc_ops.source = ("profiles/" + os.path.basename(q)) if q else None
     try:
         return json.load(open(q)).get("ops", {}) if q else {}
     except Exception:
@@ -872,7 +952,7 @@ def ops_roofline(xyz, geo, dev, timer=None):
     torch.set_grad_enabled(True)
     return {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
             "achieved_is": "effective rate = SURVEY 8(d) algorithmic bytes / stand-alone launch time (HIP events, 20 calls, idle chip); traffic = PMC "
-                           "memory-side bytes per launch (profiles/r03_ops_pmc.json) or null",
+                           "memory-side bytes per launch (%s) or null" % getattr(_pmc_ops, "source", None),
             "ops": out}
 
 
@@ -974,6 +1054,18 @@ def reference_harness(dev):
     return res
 
 
+def _latest_profiles(*suffixes):
+    """profiles/rNN_<suffix> of the newest round that has it (labels follow the file actually on disk)"""
+    out = []
+    for suf in suffixes:
+        for r in range(9, 0, -1):
+            q = os.path.join(ROOT, "profiles", "r%02d_%s" % (r, suf))
+            if os.path.exists(q):
+                out.append("profiles/" + os.path.basename(q))
+                break
+    return ", ".join(out)
+
+
 def _time_steps(fn, warm, reps):
     for _ in range(warm):
         fn()
@@ -1060,7 +1152,7 @@ def other_configs(xyz, col, dev):
                                            "roofline": {"bound": "mfma_f32", "kernels": "the three 6 -> 64 -> 128 -> 256 stacks (forward, pass A, pass B): 3 x 2 x rows x (6*64 + 64*128 + "
                                                         "128*256) flops over the WHOLE leg (geometry, pooling and Chamfer included in the time)",
                                                         "achieved": gf / t / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": gf / t / 1e12 / MFMA_F32_PEAK_TFLOPS,
-                                                        "per_kernel": "profiles/r03_c3_kernel_stats.csv, r03_c3_sq_pmc_by_kernel.txt, r03_c3_sq_insts_by_kernel.txt"}}
+                                                        "per_kernel": _latest_profiles("c3_kernel_stats.csv", "c3_sq_pmc_by_kernel.txt")}}
         # configs[4], one GPU's shard of the SA/FP part (8 of the 64 scenes): 65536-pt scenes through pn2_fea_extractor, fwd+bwd
         from gspn_amd.fea_extractor import pn2_fea_extractor
         tf_util.set_variable_store(tf_util.VariableStore(device=dev, seed=4))
@@ -1107,14 +1199,16 @@ def other_configs(xyz, col, dev):
     return out
 
 
-def cpu_baseline(xyz_np, col_np):
-    """the CPU port (oracle geometry + torch-CPU MLP stand-in) on a bounded sample of the same workload: one full fwd+bwd step on the
-    8 scenes of one batch, (i) on one thread -- how the reference's own CPU ops run (threenn_cpu / nnsearch are plain loops) -- and
-    (ii) on all cores: OpenMP over scene x query inside the oracle loops, torch intra-op threads for the MLP stand-in."""
+def cpu_baseline(xyz_np, col_np, full=False):
+    """the CPU port (oracle geometry + torch-CPU MLP stand-in) on a bounded sample of the same workload: one full fwd+bwd step,
+    (i) on one thread -- how the reference's own CPU ops run (threenn_cpu / nnsearch are plain loops) -- on `sample` scenes of one batch and
+    (ii) on all cores on the whole batch: OpenMP over scene x query inside the oracle loops, torch intra-op threads for the MLP stand-in.
+    Default: 2 scenes / median of 3 after 1 warm-up each (~15-20 s of CPU work, so that the whole default run stays under ~30 s);
+    full (--detail): SURVEY 8(d)'s 4 scenes / median of 5."""
     from oracle import cpu_pipeline
     nthr = torch.get_num_threads()
     cores = os.cpu_count() or 1
-    sample, reps = 4, 5                               # SURVEY 8(d): median of 5 after 1 warm-up; 4 of the batch's 8 scenes keep the single-thread leg near 20 s
+    sample, reps = (4, 5) if full else (2, 3)
     med = lambda f: float(np.median([f() for _ in range(reps + 1)][1:]))
     torch.set_num_threads(1)
     try:
@@ -1125,9 +1219,8 @@ def cpu_baseline(xyz_np, col_np):
     finally:
         torch.set_num_threads(nthr)
     return {"value": sample / t1, "unit": "scenes/s", "cores": 1, "kind": "port",
-            "sample": "one full fwd+bwd step on %d scenes of one batch (32768 pts each; scenes are independent on the CPU path), median of %d after 1 "
-                      "warm-up, single thread: C oracle for FPS/ball/group/3-NN/interp, torch-CPU fp32 stand-in for the TensorFlow MLP; %.1f s per "
-                      "step" % (sample, reps, t1),
+            "sample": "1 fwd+bwd step on %d of the batch's 8 scenes (32768 pts), median of %d after 1 warm-up, 1 thread: C oracle geometry + torch-CPU fp32 "
+                      "MLP stand-in; %.1f s/step" % (sample, reps, t1),
             "all_cores": {"value": xyz_np.shape[0] / tall, "cores": cores, "omp_threads": cores, "mlp_threads": mlp_threads,
                           "note": "the whole batch of %d scenes, median of %d after 1 warm-up: OpenMP over scenes (FPS, scatter-add gradients) and over "
                                   "scene x query (ball query, grouping, 3-NN, interpolation); torch intra-op threads for the MLP stand-in; %.2f s per "

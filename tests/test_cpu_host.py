@@ -175,3 +175,40 @@ def test_async_status_words_raise_at_the_next_check():
     with pytest.raises(_lib.GspnHipError, match="pending"):
         _lib.check_async(block=True)
     assert _lib._async_status == []
+
+
+def test_bench_line_is_compact_strict_json_with_the_contract_keys():
+    """VERDICT r04 item 1: the stdout line is ONE compact JSON object (< 4 KB, fixed key set, strict JSON) whatever the full result holds;
+    r04's 23 KB line was not parsed by the driver."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    long = "prose " * 2000
+    res = {"metric": bench.METRIC, "value": 4586.123456789, "unit": "scenes/s", "n_gpus": 1, "steps": 20, "warmup": 5, "ms_per_step": 1.7444456,
+           "median_ms_per_step": 1.718, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic (U: " + long + ")",
+           "config": {"workload": "BASELINE configs[2]: " + long, "scenes_per_gpu": 8, "global_batch": 8, "npoints": 32768, "parallelism": "dp1", "schedule": long,
+                      "another": long},
+           "roofline": {"bound": "hbm", "kernel": "fps_cell_kernel<32,true>", "achieved": float("nan"), "peak": 8000.0, "unit": "GB/s", "frac": float("inf"),
+                        "traffic": 4.39e6, "algorithmic_bytes_per_launch": 1.0732e10, "avg_launch_ms": 1.793, "launches_timed": 24, "concurrent_launches": 2,
+                        "achieved_is": long, "us_per_pick": 0.9},
+           "roofline_ops": {"ops": [{"op": long, "bound_by": long}] * 40}, "data_kinds": {"S": long}, "reference_harness": long, "other_configs": {"x": long},
+           "cpu_baseline": {"value": 1.317, "unit": "scenes/s", "cores": 1, "kind": "port", "sample": long,
+                            "all_cores": {"value": 3.07, "cores": 256, "omp_threads": 256, "note": long}}}
+    out = bench.compact_line(res)
+    line = json.dumps(out, allow_nan=False)                   # strict: NaN / Infinity would raise
+    assert "\n" not in line and len(line) < 4096
+    back = json.loads(line, parse_constant=lambda c: (_ for _ in ()).throw(ValueError(c)))
+    assert set(back) == set(bench.LINE_KEYS)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline"):
+        assert k in back
+    assert set(back["config"]) == set(bench.CONFIG_KEYS) and "model" not in back["config"]
+    assert set(back["roofline"]) == set(bench.ROOFLINE_KEYS)
+    assert set(back["cpu_baseline"]) == set(bench.CPU_KEYS) and set(back["cpu_baseline"]["all_cores"]) == {"value", "cores"}
+    assert back["roofline"]["achieved"] is None and back["roofline"]["frac"] is None       # non-finite numbers become null, not NaN
+    assert back["value"] == pytest.approx(4586.12, rel=1e-5) and back["detail_file"] == "bench_detail.json"
+    # no CPU baseline (N > 1 runs): the key is there, null
+    res.pop("cpu_baseline")
+    assert bench.compact_line(res)["cpu_baseline"] is None

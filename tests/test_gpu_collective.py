@@ -155,7 +155,9 @@ def test_two_ranks_rehearsal_on_one_gpu_over_gloo():
     line = json.loads(lines[-1])                        # the line is the last thing on stdout
     assert line["n_gpus"] == 2 and line["steps"] == 6 and line["scaling"] == "weak"
     assert line["config"]["global_batch"] == 16 and line["value"] > 0
-    assert line["collective"]["world"] == 2
+    assert len(lines[-1]) < 4096 and line["detail_file"] == "bench_detail.json"      # the compact line; everything else is in the detail file
+    detail = json.load(open(os.path.join(ROOT, line["detail_file"])))
+    assert detail["collective"]["world"] == 2 and detail["n_gpus"] == 2
 
 
 SYNC_CHILD = r'''
