@@ -24,6 +24,10 @@ __device__ __forceinline__ float dist2_cuda(float a, float b, float c) {
     return __builtin_fmaf(c, c, __builtin_fmaf(a, a, b * b));
 #elif GSPN_DIST_POLICY == 1
     return __builtin_fmaf(c, c, __builtin_fmaf(b, b, a * a));
+#elif GSPN_DIST_POLICY == 3
+    // what hipcc (default and -ffp-contract=fast) makes of the reference's expression on gfx950: the left multiply fused, then a plain
+    // add -- the form under which this library is BIT-EQUAL to the reference's own sources as compiled here (oracle/_ref, tests/test_gpu_policy3.py)
+    return __builtin_fmaf(a, a, b * b) + c * c;
 #else
     return (a * a + b * b) + c * c;
 #endif

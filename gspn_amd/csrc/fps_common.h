@@ -21,6 +21,10 @@ __device__ __forceinline__ v2f dist2_cuda_v2(v2f a, v2f b, v2f c) {
     v2f d = a * a;
     d = __builtin_elementwise_fma(b, b, d);
     return __builtin_elementwise_fma(c, c, d);
+#elif GSPN_DIST_POLICY == 3
+    v2f d = b * b;
+    d = __builtin_elementwise_fma(a, a, d);
+    return d + c * c;
 #else
     return (a * a + b * b) + c * c;
 #endif

@@ -21,7 +21,8 @@
  *       t = b*b;  t = fma(a,a,t);  t = fma(c,c,t)
  *   (LLVM DAGCombiner::visitFADD folds (fadd (fmul x y) z) -> fma(x,y,z) before the commuted
  *   form).  GSPN_DIST_POLICY selects:  2 = that form (default), 1 = fma(c,c,fma(b,b,a*a))
- *   (the form SURVEY.md guessed), 0 = unfused.  The HIP kernels use the same switch.
+ *   (the form SURVEY.md guessed), 0 = unfused, 3 = fma(a,a,b*b)+c*c (what hipcc makes of the reference's
+ *   expression: the form that is bit-equal to oracle/_ref's hipcc builds of the reference sources).  The HIP kernels use the same switch.
  *   Host-derived ops (three_nn, three_interpolate, nnsearch CPU twin) were built by g++ -O2
  *   without -mfma: unfused fp32, left to right.
  *
@@ -43,6 +44,8 @@ static inline float dist2_cuda(float a, float b, float c) {
     return fmaf(c, c, fmaf(a, a, b * b));
 #elif GSPN_DIST_POLICY == 1
     return fmaf(c, c, fmaf(b, b, a * a));
+#elif GSPN_DIST_POLICY == 3
+    return fmaf(a, a, b * b) + c * c;      /* hipcc's contraction of the reference expression on gfx950 (oracle/_ref builds) */
 #else
     return (a * a + b * b) + c * c;
 #endif
@@ -115,6 +118,12 @@ void oracle_farthest_point_sample(int b, int n, int m, const float *inp, int *ou
     float *temp = (float *)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1));
     for (int i = 0; i < b; i++) fps_one(n, m, inp + (size_t)i * n * 3, temp, out + (size_t)i * m);
     free(temp);
+}
+/* indices AND the reference's scratch: temp_out (b, n) = min squared distance of every point to the chosen set after the run -- what
+ * tf_sampling_g.cu:117-145 leaves in `temp + blockIdx.x*n` (compared with oracle/_ref's scratch in tests/test_gpu_policy3.py) */
+void oracle_farthest_point_sample_temp(int b, int n, int m, const float *inp, int *out, float *temp_out) {
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int i = 0; i < b; i++) fps_one(n, m, inp + (size_t)i * n * 3, temp_out + (size_t)i * n, out + (size_t)i * m);
 }
 /* same result, scenes spread over OpenMP threads (cpu_baseline "all cores") */
 void oracle_farthest_point_sample_mt(int b, int n, int m, const float *inp, int *out) {

@@ -37,7 +37,7 @@ def lib():
 
 
 class use_policy:
-    """context manager: the oracle built with GSPN_DIST_POLICY = policy (0 unfused, 1 fma(c,c,fma(b,b,a*a)), 2 = the default)
+    """context manager: the oracle built with GSPN_DIST_POLICY = policy (0 unfused, 1 fma(c,c,fma(b,b,a*a)), 2 = the default, 3 = fma(a,a,b*b)+c*c: hipcc's own contraction of the reference expression)
     behind every function of this module -- tests/test_gpu_policy.py"""
 
     def __init__(self, policy):
@@ -111,6 +111,16 @@ def dist2(p, q):
 
 
 # ---- tf_sampling -------------------------------------------------------------------------
+def farthest_point_sample_temp(npoint, inp):
+    """(idx, temp): the indices and the reference kernel's scratch after the run (min squared distance of every point to the chosen set)"""
+    inp = _f32(inp)
+    b, n, _ = inp.shape
+    out = np.zeros((b, npoint), np.int32)
+    temp = np.empty((b, n), np.float32)
+    lib().oracle_farthest_point_sample_temp(b, n, npoint, _fp(inp), _ip(out), _fp(temp))
+    return out, temp
+
+
 def farthest_point_sample(npoint, inp, mt=False):
     inp = _f32(inp)
     b, n, _ = inp.shape

@@ -68,7 +68,7 @@ def _fps_multi(h, xyz, m, G):
     return out.cpu().numpy()
 
 
-@pytest.mark.parametrize("policy", [0, 1, 2])
+@pytest.mark.parametrize("policy", [0, 1, 2, 3])
 def test_geometry_is_index_exact_under_every_contraction_policy(policy):
     h = _variant(policy)
     with O.use_policy(policy):
