@@ -4,8 +4,13 @@ The gradients of the stand-alone ops -- gather_point (tf_sampling_g.cu:183-192),
 (tf_interpolate.cpp:131-153) -- are scatter-adds in the reference.  Here they are GATHERS through the inverse lists of the index tensor
 (positions sorted by value, ties ascending): no atomics, a fixed summation order (ascending position: for three_interpolate exactly the
 order of the reference's sequential loop, so its gradient is bit-identical to the reference's own compiled code), and every gradient row
-is read once.  The lists depend on the indices only; they are built on first use and kept ON the index tensor object (`idx._gspn_inv`)
-together with the tensor's version counter, so a training loop that reuses its geometry pays for them once.
+is read once.  The lists depend on the indices only.  By DEFAULT they are rebuilt inside every backward call, on the stream that runs it (no state
+outlives the call -- like the atomic kernels they replace).  Keeping them across calls is OPT-IN (r05): a caller that KNOWS its
+index tensor is not rewritten behind torch's back passes the lists itself (SAGeometry / FPGeometry carry them: the bench path), or enables
+the per-tensor cache with `enable_cache()` / GSPN_INVLIST_CACHE=1.  The cache entry is keyed on (n, data_ptr, torch version counter,
+`generation`) -- kernels of this library, hipGraph replays into a static buffer and `.data` writes do NOT bump the version counter, so code that refills an
+index buffer that way must call `invalidate(idx)` (or `bump_generation()`) -- and it carries an event of the stream that built the lists, which a
+different consuming stream waits for.
 GSPN_ATOMIC_GRADS=1 restores the atomic scatter-add kernels (order-free sums, as in the reference's CUDA ops)."""
 import os
 
@@ -14,6 +19,26 @@ import torch
 from . import _lib as L
 
 ATOMIC_GRADS = os.environ.get("GSPN_ATOMIC_GRADS", "0") == "1"
+CACHE = os.environ.get("GSPN_INVLIST_CACHE", "0") == "1"
+_generation = [0]
+
+
+def enable_cache(on=True):
+    """opt in to (out of) keeping inverse lists on the index tensor across calls; returns the previous setting"""
+    global CACHE
+    prev, CACHE = CACHE, bool(on)
+    return prev
+
+
+def bump_generation():
+    """drop every cached list at once (call after refilling index buffers in place by means torch does not see: a graph replay, a raw kernel)"""
+    _generation[0] += 1
+
+
+def invalidate(idx):
+    """forget the lists cached on this index tensor"""
+    if getattr(idx, "_gspn_inv", None) is not None:
+        idx._gspn_inv.clear()
 
 
 def inverse_lists(idx2d, n):
@@ -30,23 +55,30 @@ def inverse_lists(idx2d, n):
 
 
 def cached_inverse_lists(idx, n):
-    """(order, offsets) of idx.reshape(b, -1) for values in [0, n), cached on the tensor object `idx` (keyed by n and the tensor's version
-    counter: an in-place write to idx invalidates the entry).  Under stream capture nothing is cached across captures that could
-    outlive its memory pool: the lists are rebuilt inside the capture."""
+    """(order, offsets) of idx.reshape(b, -1) for values in [0, n).  Cache off (default): built now, on the current stream.  Cache on: kept
+    on the tensor object `idx`, keyed by n, the tensor's data pointer, its version counter and the module's generation; an entry built on
+    another stream is waited for through its event.  Under stream capture nothing is cached: the lists are rebuilt inside the capture."""
     n = int(n)
-    capturing = torch.cuda.is_current_stream_capturing()
+    if not CACHE or torch.cuda.is_current_stream_capturing():
+        return inverse_lists(idx.reshape(idx.shape[0], -1), n)
     cache = getattr(idx, "_gspn_inv", None)
-    if cache is not None and not capturing:
+    key = (idx._version, idx.data_ptr(), _generation[0])
+    cur = torch.cuda.current_stream(idx.device)
+    if cache is not None:
         hit = cache.get(n)
-        if hit is not None and hit[0] == idx._version and hit[1].device == idx.device:
+        if hit is not None and hit[0] == key and hit[1].device == idx.device:
+            if hit[3] is not None and hit[4] != cur.cuda_stream:
+                cur.wait_event(hit[3])                       # built on another stream: order this stream after the build
             return hit[1], hit[2]
     order, offsets = inverse_lists(idx.reshape(idx.shape[0], -1), n)
-    if not capturing:
-        if cache is None:
-            cache = {}
-            try:
-                idx._gspn_inv = cache
-            except Exception:
-                return order, offsets
-        cache[n] = (idx._version, order, offsets)
+    if cache is None:
+        cache = {}
+        try:
+            idx._gspn_inv = cache
+        except Exception:
+            return order, offsets
+    ev = torch.cuda.Event()
+    ev.record(cur)
+    order.record_stream(cur)
+    cache[n] = (key, order, offsets, ev, cur.cuda_stream)
     return order, offsets

@@ -109,7 +109,7 @@ class _GroupPoint(torch.autograd.Function):
         with torch.cuda.device(points.device):
             L.check(L.lib().gspn_grouppoint(b, n, c, m, ns, L.ptr(points), L.ptr(idx), L.ptr(out), L.stream()), "group_point")
         ctx.save_for_backward(idx)
-        ctx.idx_obj = idx                    # the caller's tensor OBJECT: the inverse lists of the gradient are cached on it (invlists.py)
+        ctx.idx_obj = idx                    # the caller's tensor OBJECT: with the opt-in cache the inverse lists of the gradient are kept on it (invlists.py)
         ctx.n = n
         return out
 

@@ -41,7 +41,7 @@ class _ThreeInterpolate(torch.autograd.Function):
         with torch.cuda.device(points.device):
             L.check(L.lib().gspn_threeinterpolate(b, m, c, n, L.ptr(points), L.ptr(idx), L.ptr(weight), L.ptr(out), L.stream()), "three_interpolate")
         ctx.save_for_backward(idx, weight)
-        ctx.idx_obj = idx                    # the caller's tensor OBJECT: the inverse lists of the gradient are cached on it (invlists.py)
+        ctx.idx_obj = idx                    # the caller's tensor OBJECT: with the opt-in cache the inverse lists of the gradient are kept on it (invlists.py)
         ctx.m = m
         return out
 

@@ -139,7 +139,7 @@ class _GatherPoint(torch.autograd.Function):
         with torch.cuda.device(inp.device):
             L.check(L.lib().gspn_gatherpoint(b, n, m, L.ptr(inp), L.ptr(idx), L.ptr(out), L.stream()), "gather_point")
         ctx.save_for_backward(idx)
-        ctx.idx_obj = idx                    # the caller's tensor OBJECT: the inverse lists of the gradient are cached on it (invlists.py)
+        ctx.idx_obj = idx                    # the caller's tensor OBJECT: with the opt-in cache the inverse lists of the gradient are kept on it (invlists.py)
         ctx.n = n
         return out
 

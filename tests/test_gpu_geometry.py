@@ -244,11 +244,35 @@ def test_three_interpolate_grad_bit_exact_vs_reference_binary_at_the_fp_level_sh
     np.testing.assert_array_equal(p.grad.cpu().numpy(), O.three_interpolate_grad(pts, idx_np, w_np, go))
     if O.ref_lib() is not None:
         np.testing.assert_array_equal(p.grad.cpu().numpy(), O.ref_three_interpolate_grad(pts, idx_np, w_np, go))
-    # the lists are cached on the index tensor: a second backward through the same idx builds nothing and gives the same bits
-    assert g.idx._gspn_inv[2048][0] == g.idx._version
-    p2 = dev(pts).requires_grad_(True)
-    three_interpolate(p2, g.idx, g.weight).backward(dev(go))
-    assert torch.equal(p.grad, p2.grad)
+    # default (r05): nothing is kept on the index tensor between calls
+    assert getattr(g.idx, "_gspn_inv", None) is None
+    # opt-in cache: a second backward through the same idx builds nothing and gives the same bits; a refill of the buffer BEHIND torch's
+    # back (no version bump: what a graph replay or a raw kernel does) is caught by invalidate(), and consuming on another stream is ordered
+    from gspn_amd import invlists
+    prev = invlists.enable_cache(True)
+    try:
+        p2 = dev(pts).requires_grad_(True)
+        three_interpolate(p2, g.idx, g.weight).backward(dev(go))
+        assert torch.equal(p.grad, p2.grad)
+        ent = g.idx._gspn_inv[2048]
+        assert ent[0] == (g.idx._version, g.idx.data_ptr(), invlists._generation[0])
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            p3 = dev(pts).requires_grad_(True)
+            three_interpolate(p3, g.idx, g.weight).backward(dev(go))
+        torch.cuda.current_stream().wait_stream(side)
+        assert torch.equal(p.grad, p3.grad) and g.idx._gspn_inv[2048] is ent          # a hit, served across streams
+        new_idx = torch.roll(g.idx, 1, dims=1).contiguous()
+        v = g.idx._version
+        g.idx.data.copy_(new_idx)                                                     # .data: no version bump
+        assert g.idx._version == v
+        invlists.invalidate(g.idx)
+        p4 = dev(pts).requires_grad_(True)
+        three_interpolate(p4, g.idx, g.weight).backward(dev(go))
+        np.testing.assert_array_equal(p4.grad.cpu().numpy(), O.three_interpolate_grad(pts, new_idx.cpu().numpy(), w_np, go))
+    finally:
+        invlists.enable_cache(prev)
 
 
 def test_standalone_scatter_gradients_are_deterministic_gathers():
