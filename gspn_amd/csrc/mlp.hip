@@ -19,30 +19,18 @@
 //
 // MFMA 32x32x2 f32 fragment layout (wave64):  A: lane l holds A[i=l&31][k=l>>5];  B: lane l holds
 // B[k=l>>5][j=l&31];  C/D: 16 registers, reg r -> row (r&3)+8*(r>>2)+4*(l>>5), col l&31.
-#include "common.h"
+#include "mlp_common.h"
 #include <type_traits>
 #include <utility>
 #include <stdlib.h>
 #include <stdio.h>
 #include <algorithm>
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
 #define TM 128          // rows of C per workgroup (4 waves x 32)
 #define TK 32           // K chunk staged per iteration
 #define LDT 129         // pitch of a K-major LDS tile [TK][128]: == 1 (mod 32) -> transposing writes and column reads conflict-free
 
-__device__ __forceinline__ int c_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
-
-// THE ReLU mask of a batch-normalised element, the forward's own expression: relu(y*scale + shift) is open iff the two-rounding value
-// round(round(y*scale) + shift) is positive (-ffp-contract=off: no fused form).  Every backward kernel forms its mask with this, so the
-// BN reductions (r0, r1), the coefficients and dY are built from the same set of live elements as the forward's activations.
-// (round(t + shift) > 0  <=>  t > -shift exactly: a multiply and a compare, the cost of the fused form.)
-__device__ __forceinline__ bool relu_open(float y, float sc, float sh) { return y * sc > -sh; }
-__device__ __forceinline__ float act1(float v, bool act, float sc, float sh) {
-    if (act) { v = v * sc + sh; v = v > 0.f ? v : 0.f; }     // relu(x*scale+shift): two roundings, like tf.nn.batch_normalization
-    return v;
-}
+// (c_row, relu_open, act1, PoolOut, env_int, vec_ok: mlp_common.h)
 
 #define MAXCH GSPN_MLP_MAX_CHANNELS      // (1024) per-channel constants are staged in LDS for layers up to this many channels (the 4-level networks of
                         // model_rpointnet.py:109,181 feed fa_layer1 with 256 + 512 = 768 input channels)
@@ -155,8 +143,6 @@ __device__ __forceinline__ float4 dz4_resolve(const gspn_dy_args& a, const DzRaw
 // statistics are known a (groups x c) kernel (pool_select_kernel) finishes the pool, and the (rows x c) tensor is not read again
 // (134 MB for SA level 1 of the benchmark).  The first maximum wins ties (lowest row), like the stand-alone kernel.  Only the maximum
 // is kept: channels with a negative scale are finished from Y itself (pool_select_kernel).
-struct PoolOut { float* vmax; int* amax; };
-
 // acc: this lane's 16 accumulator values of one 32x32 tile (bias `bv` still to be added); lane l and l^32 hold the same column.
 // Writes the column's maximum over the tile's 32 rows and the row it is first reached in (lanes < 32).  VALU work is not hidden under
 // the MFMAs on this chip, so: one max3 tree for the value, then the first register that equals it (c_row ascends with the register
@@ -817,14 +803,16 @@ static inline int pick_bn(long rows, int cols, const char* env) {
 }
 // number of row-blocks (= partial-statistics rows) the forward launch of a (rows, cout) layer uses
 // (workgroups per CU = what the kernel's LDS footprint lets reside at once: a persistent grid larger than that runs a second wave)
-static inline int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 static inline int bwd_bpc_narrow() { static const int v = env_int("GSPN_BWD_BPC", 4); return v < 1 ? 1 : v; }
-static inline unsigned fwd_blocks(long rows, int cout) { return row_grid(rows, cout <= 64 ? 1 : (cout + 127) / 128, cout <= 64 ? 4 : env_int("GSPN_FWD_WIDE_BPC", 3)); }
+static inline bool fwd_short_rows(long rows) { static const int on = env_int("GSPN_FWD_SHORT", 1); return on && rows >= 64 && rows <= GSPN_SHORT_ROWS && !(rows & 63); }
+static inline unsigned fwd_blocks(long rows, int cout) {
+    if (fwd_short_rows(rows)) return (unsigned)short_fwd_parts(rows);      // short layers (mlp_short.hip): one partial row per 32-row tile, at most 512
+    return row_grid(rows, cout <= 64 ? 1 : (cout + 127) / 128, cout <= 64 ? 4 : env_int("GSPN_FWD_WIDE_BPC", 3));
+}
 extern "C" long gspn_mlp_fwd_stats_bytes(long rows, int cout) {
     if (rows < 0 || cout <= 0) return GSPN_ERR_ARG;
     return (long)sizeof(float) * 2 * cout * (long)fwd_blocks(rows > 0 ? rows : 1, cout);
 }
-static inline bool vec_ok(const void* p, int ld) { return (ld % 4 == 0) && (((uintptr_t)p) % 16 == 0); }
 
 // ---- MFMA operand streams from LDS with explicit immediates and explicit waits ------------------------------------------------------
 // hipcc pairs the unrolled operand reads of a k loop into ds_read2_b32 whose 8-bit offsets do not reach across k steps of a transposed
@@ -1199,6 +1187,9 @@ static int mlp_fwd_impl(long rows, int cin, int cout, const float* X, int ldx, c
     hipStream_t st = (hipStream_t)stream;
     {
         if (!gsrc && (!po.vmax || !(rows & 31)) && fwd_split_go(rows, cin, cout, X, ldx, in_scale, in_shift, W, bias, Y, ldy, stats, po, st)) return gspn_launch_status();
+        // short layers (<= 32768 rows): split-K over the waves of a workgroup, operands straight from global memory (mlp_short.hip, r05)
+        if (!gsrc && fwd_short_rows(rows) && gspn_fwd_short_go(rows, cin, cout, X, ldx, in_scale, in_shift, W, bias, Y, ldy, stats, fwd_blocks(rows, cout), po, st))
+            return gspn_launch_status();
         static const int lean_on = env_int("GSPN_FWD_LEAN", 1);             // (A/B hook)
         static const int lean_bn = env_int("GSPN_FWD_LEAN_BN", 0);          // (tuning hook)
         // (beyond ~0.75 M rows the eight 32-column blocks of a 256-column layer re-read X from beyond the L2s: 1 M x 128 -> 256 946 us against
@@ -2206,6 +2197,9 @@ static WgradPlan wgrad_plan(long rows, int cin, int cout, bool generic = false, 
     if (floor_ch < 1) floor_ch = 1;
     if (chunks > by_size) chunks = by_size > floor_ch ? by_size : floor_ch;
     if (forced_chunks > 0) chunks = forced_chunks;
+    // short layers (r05, mlp_short.hip: wgrad_short_kernel): the chunking follows THAT kernel's 64 x 64 output blocks (the streaming kernels,
+    // which still run the two-product form of these shapes, take any chunk count)
+    if (!generic && forced_chunks <= 0 && gspn_wgrad_short_shape(rows, cin, cout)) chunks = gspn_wgrad_short_chunks(rows, cin, cout);
     long rpc = (rows + chunks - 1) / chunks;
     if (rpc < 4L * p.TKW) rpc = 4L * p.TKW;
     const long rq = p.TKW > 32 ? p.TKW : 32;              // (r03) whole stages of the lean kernel (32 rows) as well as of the streaming one (TKW)
@@ -2680,7 +2674,8 @@ static int wgrad_impl(long rows, int cin, int cout, const gspn_dy_args* a, const
     const float* vr = use_bn ? var : nullptr;
     if (use_stream) {
         int launched = 0;
-        if (known && !gsrc && wgrad_lean_try(rows, cin, cout, a, X, ldx, in_scale, in_shift, PP, p, st)) launched = 1;
+        if (known && !gsrc && !p.shared && gspn_wgrad_short_go(rows, cin, cout, a, X, ldx, in_scale, in_shift, PP, p.rpc, p.nch, st)) launched = 1;
+        if (!launched && known && !gsrc && wgrad_lean_try(rows, cin, cout, a, X, ldx, in_scale, in_shift, PP, p, st)) launched = 1;
         const dim3 grid((unsigned)((p.nch + 7) / 8 * 8 * p.nrow * p.ncol));
 #define WS_ARGS (int)rows, cin, cout, *a, X, ldx, in_scale, in_shift, mu, vr, eps, RP, GP, PP, (int)p.rpc, (int)p.nslots, p.shared, (int)p.nch, p.nrow, p.ncol
 #define WS_GO(MT_, NT_, TKW_, G_, P_) hipLaunchKernelGGL((wgrad_stream_kernel<MT_, NT_, TKW_, G_, P_>), grid, dim3(256), 0, st, WS_ARGS, GatherSrc{})
