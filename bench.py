@@ -898,7 +898,7 @@ def ops_roofline(xyz, geo, dev, timer=None):
         gp2 = torch.empty_like(p2)
         # the op API's gradient (tf_interpolate.py, r04): a gather through the inverse lists of idx (cached on the index tensor), sums in the
         # reference's own order, bit-exact vs oracle/_ref; the lists' one-off build is its own entry below
-        add("three_interpolate_grad (op API: gather over cached inverse lists)", "%dx%d->%d, c=%d" % (b, n, m, c2), 1.0 * b * n * (24 + 16 * c2),
+        add("three_interpolate_grad (op API: gather over inverse lists, built per call unless the cache is opted into)", "%dx%d->%d, c=%d" % (b, n, m, c2), 1.0 * b * n * (24 + 16 * c2),
             lambda: L.check(lib.gspn_fp_concat_grad_csr(b, n, m, c2, 0, c2, L.ptr(go), L.ptr(fpg.order), L.ptr(fpg.offsets), L.ptr(fpg.weight), L.ptr(gp2), None,
                                                         L.stream()), "three_interpolate_grad(csr)"),
             "dependent-load latency of the inverse-list walk (16 lanes per sparse point, 8 rows in flight)", "three_interpolate_grad_csr_%d" % n)
@@ -927,10 +927,13 @@ def ops_roofline(xyz, geo, dev, timer=None):
         go = torch.randn(b, m, ns, c, device=dev, generator=gen)
         gpts = torch.empty(b, n, c, device=dev)
         sord, soff = (sa.order, sa.offsets) if sa.order is not None else inverse_lists(sa.idx.reshape(b, m * ns), n)
-        add("group_point_grad (op API: gather over cached inverse lists)", "(%d,%d) -> %dx%d, c=%d" % (m, ns, b, n, c), 1.0 * b * m * ns * (4 + 8 * c),
+        from gspn_amd import invlists as _inv
+        add("group_point_grad (gather over inverse lists%s)" % ("; the op API's choice at this width" if not _inv.use_atomic(c) else "; GSPN_DETERMINISTIC_GRADS=1"),
+            "(%d,%d) -> %dx%d, c=%d" % (m, ns, b, n, c), 1.0 * b * m * ns * (4 + 8 * c),
             lambda: L.check(lib.gspn_sa_group_concat_grad_csr(b, n, c, m, ns, L.ptr(sord), L.ptr(soff), 0, c, L.ptr(go), L.ptr(gpts), L.stream()), "group_point_grad(csr)"),
             "dependent-load latency of the inverse-list walk; every gradient row read once", "group_point_grad_csr_%d" % n)
-        add("group_point_grad (C-ABI drop-in symbol: scatter-add, hardware fp32 atomics)", "(%d,%d) -> %dx%d, c=%d" % (m, ns, b, n, c), 1.0 * b * m * ns * (4 + 8 * c),
+        add("group_point_grad (C-ABI drop-in symbol: scatter-add, hardware fp32 atomics%s)" % ("; the op API's choice at this width" if _inv.use_atomic(c) else ""),
+            "(%d,%d) -> %dx%d, c=%d" % (m, ns, b, n, c), 1.0 * b * m * ns * (4 + 8 * c),
             lambda: L.check(lib.gspn_grouppoint_grad(b, n, c, m, ns, L.ptr(go), L.ptr(sa.idx), L.ptr(gpts), L.stream()), "group_point_grad"),
             "L2 atomic throughput", "group_point_grad_%d" % n)
     fidx = geo["sa"][0].idx[:, :, 0].contiguous()

@@ -171,7 +171,9 @@ def check(rc, what):
         # every launch through the binding is also a check point for the status words of earlier multi-CU FPS launches (the
         # consumers of a failed launch -- gather_point, the ball query, the layers -- used to run on its zero-filled output unnoticed
         # until the next farthest_point_sample call).  Free when nothing is pending; skipped inside a stream capture (no event queries there).
-        if _async_status and not torch.cuda.is_current_stream_capturing():
+        # ... nor while ANY capture of this process is open (CAPTURES_OPEN, kept by graph.CapturedStep): an event query from here is
+        # illegal for a capture running in global mode on another stream / thread
+        if _async_status and not CAPTURES_OPEN[0] and not torch.cuda.is_current_stream_capturing():
             check_async(block=len(_async_status) > 64)          # (and the list cannot grow without bound)
         return
     if rc == -1:
@@ -186,6 +188,7 @@ def check(rc, what):
 # check_async() raises for every registered word whose copy has completed with a non-zero value.  It is called by the op wrappers
 # before their next launch and by PendingGeometry.get() after its wait -- the next natural synchronisation points.
 _async_status = []
+CAPTURES_OPEN = [0]          # number of stream captures this process has open (graph.CapturedStep increments it around its capture)
 
 
 def register_async_status(host_word, event, what):

@@ -996,18 +996,25 @@ __global__ __launch_bounds__(256) void csr_sort_kernel(long nwaves, int L, int n
     int* bufB = dst;
     const int nbits = 32 - __builtin_clz((unsigned)(L > 1 ? L - 1 : 1));
     const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    // The phases below exchange data between lanes through bins[] (LDS) and the ping-pong buffers (global): every phase boundary is an explicit
+    // wave barrier + workgroup-scope fence (lockstep execution of a wave is an implementation detail a compiler may reschedule around).
+#define CSR_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
     for (int shift = 0; shift < nbits; shift += 6) {
         bins[lane] = 0;
+        CSR_WAVE_SYNC();
         for (int i0 = 0; i0 < cnt; i0 += 64) {
             const int i = i0 + lane;
             if (i < cnt) atomicAdd(&bins[(bufA[i] >> shift) & 63], 1);
         }
+        CSR_WAVE_SYNC();
         // exclusive scan of the 64 bins (one per lane)
         const int c = bins[lane];
         int incl = c;
 #pragma unroll
         for (int sft = 1; sft < 64; sft <<= 1) { const int u = __shfl_up(incl, sft, 64); if (lane >= sft) incl += u; }
+        CSR_WAVE_SYNC();
         bins[lane] = incl - c;
+        CSR_WAVE_SYNC();
         for (int i0 = 0; i0 < cnt; i0 += 64) {
             const int i = i0 + lane;
             const bool valid = i < cnt;
@@ -1019,16 +1026,21 @@ __global__ __launch_bounds__(256) void csr_sort_kernel(long nwaves, int L, int n
                 const unsigned long long m = __ballot((d >> bit) & 1);
                 eq &= ((d >> bit) & 1) ? m : ~m;
             }
+            int base = 0;
+            if (valid) base = bins[d];
+            CSR_WAVE_SYNC();                          // every lane has read its digit's cursor before the digit's highest lane moves it
             if (valid) {
-                const int base = bins[d];
                 const int rank = __builtin_popcountll(eq & lt);
                 bufB[base + rank] = v;
                 if ((eq >> lane) == 1ull) bins[d] = base + __builtin_popcountll(eq);      // the highest lane of the digit moves its cursor on
             }
+            CSR_WAVE_SYNC();
         }
         __threadfence_block();                        // this pass's stores are complete before other lanes of the wave read them back
+        CSR_WAVE_SYNC();
         int* t = bufA; bufA = bufB; bufB = t;
     }
+#undef CSR_WAVE_SYNC
     if (bufA != dst)                                                                      // (bufA holds the sorted group after the last swap)
         for (int i = lane; i < cnt; i += 64) dst[i] = bufA[i];
 }

@@ -338,8 +338,14 @@ __global__ __launch_bounds__(NNG_T) void three_nn_grid_kernel(int b, int n, int 
         for (int a = 0; a < 3; ++a) {
             c0[a] = max(c[a] - 1, 0);
             c1[a] = min(c[a] + 1, G - 1);
-            if (c0[a] > 0) bound = fminf(bound, qv[a] - (lo[a] + (float)c0[a] * h[a]));
-            if (c1[a] < G - 1) bound = fminf(bound, (lo[a] + (float)(c1[a] + 1) * h[a]) - qv[a]);
+            // box-relative: q - lo is the subtraction cell_of itself performs; lo + c*h would round at the scale of the ABSOLUTE
+            // coordinate (metres around 5e5 with a small extent: percent of h, far beyond the 0.999 shrink below).  A flat axis
+            // (inv == 0: every known point in cell 0, nothing behind any face) contributes no face.
+            const float rel = qv[a] - lo[a];
+            if (inv[a] > 0.f) {
+                if (c0[a] > 0) bound = fminf(bound, rel - (float)c0[a] * h[a]);
+                if (c1[a] < G - 1) bound = fminf(bound, (float)(c1[a] + 1) * h[a] - rel);
+            }
         }
         auto scan_block = [&]() {
             for (int cz = c0[2]; cz <= c1[2]; ++cz)
@@ -373,8 +379,9 @@ __global__ __launch_bounds__(NNG_T) void three_nn_grid_kernel(int b, int n, int 
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
                 if (r < INFINITY && inv[a] > 0.f) {
-                    c0[a] = min(max((int)floorf((qv[a] - r - lo[a]) * inv[a]) - 1, 0), G - 1);      // (one cell of slack on both sides)
-                    c1[a] = min(max((int)floorf((qv[a] + r - lo[a]) * inv[a]) + 1, 0), G - 1);
+                    const float rel = qv[a] - lo[a];                                                   // (box-relative, as above)
+                    c0[a] = min(max((int)floorf((rel - r) * inv[a]) - 1, 0), G - 1);                  // (one cell of slack on both sides)
+                    c1[a] = min(max((int)floorf((rel + r) * inv[a]) + 1, 0), G - 1);
                 } else { c0[a] = 0; c1[a] = G - 1; }
             }
             scan_block();

@@ -3253,8 +3253,11 @@ extern "C" int gspn_preagg_fwd(long rows, int cout, int T, const float* F, const
     const long fsrc_bytes = (long)(per_scene_rows > 0 ? ((rows + per_scene_rows - 1) / per_scene_rows) * (long)per_scene_src : 0) * cout * 4;
     if (rows16 && (cout == 64 || cout == 128 || cout == 256) && fsrc_bytes < (1L << 31) && (side_n == 0 || side_ld != 4 || ((uintptr_t)side % 16) == 0)
         && (per_scene_rows > 0 || true)) {
-        // (T = 1: idx are global source rows; their byte offsets must stay below 2^31 as well -- the caller's F has at most rows source rows)
-        if (per_scene_rows > 0 || rows * (long)cout * 4 < (1L << 31)) {
+        // (global idx, per_scene_rows == 0: the kernel forms 32-bit byte offsets into F.  per_scene_src then carries the TOTAL number of source rows
+        //  (r05, ADVICE r04: with m*nsample < n the source table is larger than `rows`); 0 = not given, the caller's F is taken to have at
+        //  most `rows` source rows, as round 4 assumed.  Beyond 2^31 bytes the general kernel below runs.)
+        const long src_rows = per_scene_src > 0 ? (long)per_scene_src : rows;
+        if (per_scene_rows > 0 || (src_rows * (long)cout * 4 < (1L << 31) && rows * (long)cout * 4 < (1L << 31))) {
 #define PA16_GO(T_, H_) hipLaunchKernelGGL((preagg_fwd16_kernel<T_, H_>), dim3(nb), dim3(256), sh, (hipStream_t)stream, rows, ps, Wside, bias, Y, stats)
             if (T == 1) { if (cout == 64) PA16_GO(1, 1); else if (cout == 128) PA16_GO(1, 2); else PA16_GO(1, 4); }
             else { if (cout == 64) PA16_GO(3, 1); else if (cout == 128) PA16_GO(3, 2); else PA16_GO(3, 4); }

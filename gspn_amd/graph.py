@@ -32,8 +32,13 @@ class CapturedStep:
         # of torch.distributed polls the events of earlier collectives from its own thread: with RCCL initialised the capture of the
         # step killed the process about once in thirty runs ("operation not permitted when stream is capturing" out of
         # ProcessGroupNCCL::Watchdog; tests/test_gpu_collective.py, r03).
-        with torch.cuda.graph(self.graph, pool=pool, capture_error_mode="thread_local"):
-            self.result = fn()
+        from . import _lib as L
+        L.CAPTURES_OPEN[0] += 1               # (no event polling from the binding's check points while a capture is open: _lib.check)
+        try:
+            with torch.cuda.graph(self.graph, pool=pool, capture_error_mode="thread_local"):
+                self.result = fn()
+        finally:
+            L.CAPTURES_OPEN[0] -= 1
 
     def pool(self):
         return self.graph.pool()

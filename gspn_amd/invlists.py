@@ -20,6 +20,18 @@ from . import _lib as L
 
 ATOMIC_GRADS = os.environ.get("GSPN_ATOMIC_GRADS", "0") == "1"
 CACHE = os.environ.get("GSPN_INVLIST_CACHE", "0") == "1"
+# Narrow rows (c < NARROW_C: the coordinate / colour gradients of group_point, every gather_point gradient) take the ATOMIC kernels by default
+# (r05): at c = 3 the list walk is one thread per point and waits for its longest list -- (2048, 32) -> 8 x 32768: 170 us + 89 us for the lists
+# against 43 us for the hardware fp32 atomics (bench_detail.json: roofline_ops), and the reference's own kernel is an atomicAdd with no order
+# either (tf_grouping_g.cu:66-83, tf_sampling_g.cu:183-192).  GSPN_DETERMINISTIC_GRADS=1 keeps the fixed-order gather at every width.
+NARROW_C = int(os.environ.get("GSPN_NARROW_GRAD_C", "16"))
+DETERMINISTIC = os.environ.get("GSPN_DETERMINISTIC_GRADS", "0") == "1"
+
+
+def use_atomic(c):
+    """the op wrappers' choice for a scatter-add gradient of row width c"""
+    return ATOMIC_GRADS or (c < NARROW_C and not DETERMINISTIC)
+
 _generation = [0]
 
 

@@ -168,9 +168,14 @@ class _MlpStack(torch.autograd.Function):
                         and not (li == 0 and (pre is not None or gather is not None))):      # (a one-layer stack with a gathered / pre-aggregated input has no plain forward)
                     g32 = rows // 32
                     pool = (torch.empty((g32, cout), dtype=torch.float32, device=dev), torch.empty((g32, cout), dtype=torch.int32, device=dev))
-                    L.check(lib.gspn_mlp_fwd_pool32(rows, cin, cout, L.ptr(cur), cur_ld, L.ptr(in_scale), L.ptr(in_shift), L.ptr(lp.weights),
-                                                    L.ptr(lp.biases), L.ptr(y), cout, L.ptr(stats), L.ptr(pool[0]), L.ptr(pool[1]), st),
-                            "mlp_fwd_pool32")
+                    try:
+                        L.check(lib.gspn_mlp_fwd_pool32(rows, cin, cout, L.ptr(cur), cur_ld, L.ptr(in_scale), L.ptr(in_shift), L.ptr(lp.weights),
+                                                        L.ptr(lp.biases), L.ptr(y), cout, L.ptr(stats), L.ptr(pool[0]), L.ptr(pool[1]), st),
+                                "mlp_fwd_pool32")
+                    except NotImplementedError:          # a shape / alignment without a pool epilogue: plain forward, the stand-alone pool below
+                        pool = None
+                        L.check(lib.gspn_mlp_fwd(rows, cin, cout, L.ptr(cur), cur_ld, L.ptr(in_scale), L.ptr(in_shift),
+                                                 L.ptr(lp.weights), L.ptr(lp.biases), L.ptr(y), cout, L.ptr(stats), st), "mlp_fwd")
                 elif li == 0 and pre is not None:
                     # F = feat . W_feat on the source rows, then the output rows from F (+ side . W_side + bias) and their column sums
                     wf = lp.weights[pre["wf0"]:pre["wf0"] + pre["c"]]
@@ -222,15 +227,24 @@ class _MlpStack(torch.autograd.Function):
                 groups = rows // pool_ns
                 out = torch.empty((groups, cl), dtype=torch.float32, device=dev)
                 arg = torch.empty((groups, cl), dtype=torch.int32, device=dev)
+                done = False
                 if pool is not None and pool_ns == 32:             # the group extrema came out of the last forward launch: finish on (groups, c) elements
-                    L.check(lib.gspn_pool32_select(groups, cl, L.ptr(pool[0]), L.ptr(pool[1]), L.ptr(cur), cur_ld,
-                                                   L.ptr(in_scale), L.ptr(in_shift), L.ptr(out), L.ptr(arg), st), "pool32_select")
+                    try:
+                        L.check(lib.gspn_pool32_select(groups, cl, L.ptr(pool[0]), L.ptr(pool[1]), L.ptr(cur), cur_ld,
+                                                       L.ptr(in_scale), L.ptr(in_shift), L.ptr(out), L.ptr(arg), st), "pool32_select")
+                        done = True
+                    except NotImplementedError:
+                        pool = None
                 elif pool is not None:           # groups of 32 * sub rows: the first largest of the tile maxima
                     yarg = torch.empty((groups, cl), dtype=torch.float32, device=dev)
-                    L.check(lib.gspn_pool32_select_groups(groups, pool_ns // 32, cl, L.ptr(pool[0]), L.ptr(pool[1]), L.ptr(cur), cur_ld,
-                                                          L.ptr(in_scale), L.ptr(in_shift), L.ptr(out), L.ptr(arg), L.ptr(yarg), st), "pool32_select_groups")
-                    pool = (yarg, None)
-                else:
+                    try:
+                        L.check(lib.gspn_pool32_select_groups(groups, pool_ns // 32, cl, L.ptr(pool[0]), L.ptr(pool[1]), L.ptr(cur), cur_ld,
+                                                              L.ptr(in_scale), L.ptr(in_shift), L.ptr(out), L.ptr(arg), L.ptr(yarg), st), "pool32_select_groups")
+                        pool = (yarg, None)
+                        done = True
+                    except NotImplementedError:  # (the library declined the shape -- the header's contract is "the caller then runs gspn_bnrelu_maxpool")
+                        pool = None
+                if not done:
                     L.check(lib.gspn_bnrelu_maxpool(groups, pool_ns, cl, L.ptr(cur), cur_ld, L.ptr(in_scale), L.ptr(in_shift),
                                                     L.ptr(out), L.ptr(arg), st), "bnrelu_maxpool")
             else:

@@ -170,7 +170,7 @@ def _sa_stack_gathered(points, geometry, xyz_first, cin, layers, is_training, bn
                 L.check(L.lib().gspn_sa_group_concat_grad(b, n, cout, m, ns, L.ptr(idx), 0, cout, L.ptr(dy), L.ptr(gp), L.stream()), "sa_group_concat_grad")
             return gp.view(b * n, cout)
 
-        pre = {"rows": b * m * ns, "c": c, "T": 1, "idx": geometry.gidx, "w": None, "per_scene_rows": 0, "per_scene_src": 0,
+        pre = {"rows": b * m * ns, "c": c, "T": 1, "idx": geometry.gidx, "w": None, "per_scene_rows": 0, "per_scene_src": b * n,      # (global idx: per_scene_src = ALL source rows, the library's offset guard)
                "side": geometry.rel, "side_ld": 4, "side_n": 3, "wf0": 3 if xyz_first else 0, "ws0": 0 if xyz_first else c, "scatter": scatter}
         return mlp_stack(feat, cin, layers, bool(is_training), bn_decay, pool_ns=nsample, preagg=pre)
     g = {"rows": b * m * ns, "c": c, "xyz_first": xyz_first, "gidx": geometry.gidx, "rel": geometry.rel, "dims": (b, n, m, ns),

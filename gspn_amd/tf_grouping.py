@@ -122,7 +122,7 @@ class _GroupPoint(torch.autograd.Function):
         c = grad_out.shape[3]
         g = torch.empty((b, ctx.n, c), dtype=torch.float32, device=grad_out.device)
         with torch.cuda.device(grad_out.device):
-            if invlists.ATOMIC_GRADS or m * ns == 0:
+            if invlists.use_atomic(c) or m * ns == 0:
                 L.check(L.lib().gspn_grouppoint_grad(b, ctx.n, c, m, ns, L.ptr(grad_out), L.ptr(idx), L.ptr(g), L.stream()), "group_point_grad")
             else:
                 # a gather through the inverse lists of idx (fixed order: ascending grouped position; the reference's atomicAdd,

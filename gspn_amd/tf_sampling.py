@@ -151,7 +151,7 @@ class _GatherPoint(torch.autograd.Function):
         b, m = idx.shape
         inp_g = torch.empty((b, ctx.n, 3), dtype=torch.float32, device=out_g.device)
         with torch.cuda.device(out_g.device):
-            if invlists.ATOMIC_GRADS or m == 0:
+            if invlists.use_atomic(3) or m == 0:
                 L.check(L.lib().gspn_scatteraddpoint(b, ctx.n, m, L.ptr(out_g), L.ptr(idx), L.ptr(inp_g), L.stream()), "gather_point_grad")
             else:
                 # gather through the inverse lists of idx (ascending sample position): deterministic also when a point was sampled

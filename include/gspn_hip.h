@@ -411,7 +411,8 @@ int gspn_mlp_bwd_fused_coef(long rows, int cin, int cout, const gspn_dy_args* a,
 /* Pre-aggregated first layer of an SA / FP module (gspn_amd/csrc/mlp.hip, "Pre-aggregated first layer"): the layer is linear, so its
  * feature part is multiplied on the SOURCE points (F = feat.W_feat, a small GEMM through gspn_mlp_fwd) and the grouped / interpolated
  * rows are then formed from F:   Y[r] = sum_t w[r,t] * F[idx[r,t]] + side[r,:side_n] . Wside + bias,   T = 1 (grouping, w = NULL) or 3
- * (3-NN interpolation).  idx are global source rows, or scene-local ones when per_scene_rows > 0 (output rows / source rows per scene).
+ * (3-NN interpolation).  idx are global source rows, or scene-local ones when per_scene_rows > 0 (output rows / source rows per scene);
+ * with global idx (per_scene_rows == 0) per_scene_src is the total number of source rows of F (0: not given, taken as <= rows).
  * stats: the column sums of Y, gspn_preagg_fwd_parts(rows, cout) partial rows for gspn_bn_finalize_parts, or NULL.
  * cout must be 4 * 2^k (gspn_preagg_ok); F, Y 16-byte aligned.  Same result as the GEMM over materialised rows up to fp32 rounding
  * (a different order of additions). */

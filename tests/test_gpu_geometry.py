@@ -302,17 +302,38 @@ def test_standalone_scatter_gradients_are_deterministic_gathers():
     xyz = rng.standard_normal((b, n, 3)).astype(np.float32)
     gi = rng.integers(0, 5, size=(b, 300)).astype(np.int32)                # a point sampled many times (npoint > distinct points)
     g3 = rng.standard_normal((b, 300, 3)).astype(np.float32)
-    outs = []
-    for _ in range(3):
-        x = dev(xyz).requires_grad_(True)
-        gather_point(x, dev(gi)).backward(dev(g3))
-        outs.append(x.grad.clone())
-    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
     ref = np.zeros((b, n, 3), np.float32)
     for s in range(b):
         for j in range(300):
             ref[s, gi[s, j]] += g3[s, j]
-    np.testing.assert_array_equal(outs[0].cpu().numpy(), ref)
+    # narrow rows (c < 16) take the atomic kernel by default since r05 (order-free sums, like the reference's atomicAdd: 43 us against
+    # 170 + 89 us at the bench shape) ...
+    x = dev(xyz).requires_grad_(True)
+    gather_point(x, dev(gi)).backward(dev(g3))
+    np.testing.assert_allclose(x.grad.cpu().numpy(), ref, rtol=1e-5, atol=2e-5)
+    # ... and the fixed-order gather when determinism is asked for (GSPN_DETERMINISTIC_GRADS=1)
+    from gspn_amd import invlists
+    prev, invlists.DETERMINISTIC = invlists.DETERMINISTIC, True
+    try:
+        outs = []
+        for _ in range(3):
+            x = dev(xyz).requires_grad_(True)
+            gather_point(x, dev(gi)).backward(dev(g3))
+            outs.append(x.grad.clone())
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+        np.testing.assert_array_equal(outs[0].cpu().numpy(), ref)
+        p3 = dev(xyz).requires_grad_(True)                                   # group_point on 3 columns: the narrow list walk
+        i3 = rng.integers(0, 40, size=(b, m, ns)).astype(np.int32)
+        go3 = rng.standard_normal((b, m, ns, 3)).astype(np.float32)
+        group_point(p3, dev(i3)).backward(dev(go3))
+        r3 = np.zeros((b, n, 3), np.float32)
+        for s in range(b):
+            for j in range(m):
+                for k in range(ns):
+                    r3[s, i3[s, j, k]] += go3[s, j, k]
+        np.testing.assert_array_equal(p3.grad.cpu().numpy(), r3)
+    finally:
+        invlists.DETERMINISTIC = prev
 
 
 @pytest.mark.parametrize("b,n,m", [(4, 512, 512), (2, 1500, 700), (3, 100, 2500), (1, 1, 1), (2, 3000, 1500)])     # the last one: beyond the LDS kernel (global atomics)
@@ -497,7 +518,7 @@ def test_fps_prepass_voxel_order_is_a_permutation_in_voxel_order():
         assert (np.diff(along) >= 0).all()
 
 
-@pytest.mark.parametrize("case", ["lattice", "plane", "outside", "clusters", "duplicates", "m1025"])
+@pytest.mark.parametrize("case", ["lattice", "plane", "outside", "clusters", "duplicates", "m1025", "far_origin", "far_plane"])
 def test_three_nn_cell_grid_is_exact(case):
     """r04: known clouds of more than 1024 points go through three_nn_grid_kernel (the known points sorted into cells in LDS, the 3 x 3 x 3
     block around the query's cell, acceptance by the distance to the block's faces, a restart over the ball's cells otherwise).  Exact
@@ -528,6 +549,13 @@ def test_three_nn_cell_grid_is_exact(case):
         sparse = D.batch("D", b, 4096, 40)
         sparse[:, 2000:] = sparse[:, :2096]                                   # every point twice: each nearest neighbour is a tie
         dense = D.batch("U", b, n, 41)
+    elif case in ("far_origin", "far_plane"):
+        #  large ABSOLUTE coordinates with a small extent -- metres around 5e5, coordinates on a 1/16 m raster so that the inputs
+        # are exact: the acceptance bound must be formed relative to the box (q - lo), not as lo + c*h at the scale of the coordinates
+        sparse = (np.float32(5e5) + rng.integers(0, 64, size=(b, 3000, 3)).astype(np.float32) / 16).astype(np.float32)
+        dense = (np.float32(5e5) + rng.integers(-8, 72, size=(b, n, 3)).astype(np.float32) / 16).astype(np.float32)
+        if case == "far_plane":
+            sparse[..., 1] = np.float32(5e5 + 1.0)
     else:
         sparse = D.batch("U", b, 1025, 50)
         dense = D.batch("U", b, n, 51)
