@@ -82,6 +82,8 @@ def main():
                     "S ScanNet-like room surfaces at metre scale, D uniform with 10 %% duplicated points (dataset.py:100-105)")
     ap.add_argument("--kind-leg", action="store_true", help="(internal) a short run on --data whose line carries the ball-query leg only: the "
                     "default run spawns one per non-headline kind and folds the figures into `data_kinds`")
+    ap.add_argument("--shape", default=None, help="(internal, with --kind-leg) SCENES,POINTS per GPU instead of 8,32768: the reference's own operating point "
+                    "2,18000 (models/config.py:14-19) through the same schedule -- a detail leg, never the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="geometry inline on the main stream instead of prefetched on a side stream")
     ap.add_argument("--no-graph", action="store_true", help="enqueue the layers kernel by kernel instead of replaying a captured hipGraph")
@@ -99,8 +101,12 @@ def main():
                     "issuing it after the replay (diagnostic: the default placement is after the graph)")
     args = ap.parse_args()
 
-    global DATA_KIND
+    global DATA_KIND, SCENES_PER_GPU, NPOINTS
     DATA_KIND = args.data
+    if args.shape:
+        if not args.kind_leg:
+            raise SystemExit("--shape is a detail leg (use with --kind-leg): the headline workload is BASELINE configs[2]")
+        SCENES_PER_GPU, NPOINTS = (int(v) for v in args.shape.split(","))
     if args.legs_only:
         return legs_main(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -516,8 +522,9 @@ def main():
             "data": ("synthetic (%s)" % {"U": "U: xyz ~ U[0,1)^3, SURVEY 8(d)'s primary kind", "S": "S: ScanNet-like room surfaces, 8 x 6 x 3 m + 20 boxes, metre scale",
                                          "D": "D: uniform with the last 10 % of the points duplicates of earlier ones"}[DATA_KIND])
                     if not LAYERS_ONLY else "DIAGNOSTIC RUN, NOT A RESULT: geometry skipped (GSPN_BENCH_LAYERS_ONLY)",
-            "config": {"workload": "BASELINE configs[2]: batch 8 x 32768-pt scenes per GPU, 3-level SA + 3-level FP (three_nn/interpolate) fwd+bwd, "
-                                   "pn2_fea_extractor layer spec, BN training mode, Adam step", "scenes_per_gpu": SCENES_PER_GPU,
+            "config": {"workload": ("BASELINE configs[2]: " if (SCENES_PER_GPU, NPOINTS) == (8, 32768) else "DETAIL LEG (not the headline): ") +
+                                   "batch %d x %d-pt scenes per GPU, 3-level SA + 3-level FP (three_nn/interpolate) fwd+bwd, "
+                                   "pn2_fea_extractor layer spec, BN training mode, Adam step" % (SCENES_PER_GPU, NPOINTS), "scenes_per_gpu": SCENES_PER_GPU,
                        "schedule": "geometry inline" if args.no_overlap else (("geometry of batches k+2, k+3 submitted together every other step on two side streams under the layers of batches k, k+1"
                                                                                 if PAIRED else "geometry of batches k+1, k+2 on two side streams under the layers of batch k")
                                                                                + ("; fwd+bwd replayed from a hipGraph" if use_graph else "")),
@@ -558,6 +565,8 @@ def main():
             # harness shapes) run in a CHILD process: whatever happens there -- an exception, a crash, a hang -- the headline line above
             # is printed.  (r03: a graph capture inside one of these legs segfaulted and the run printed nothing at all.)
             res.update(run_legs_in_child(args))
+            if isinstance(res.get("reference_harness"), dict):
+                res["reference_harness"]["operating_point_captured"] = operating_point_captured()
         if args.kind_leg:
             print(json.dumps(res), flush=True)                      # (internal child of data_kinds_legs: the parent reads the full object)
         else:
@@ -657,6 +666,24 @@ def data_kinds_legs(res_u, kinds=("S", "D"), timeout=600):
         except Exception as e:
             out[k] = {"error": repr(e)}
     return out
+
+
+def operating_point_captured(timeout=600):
+    """the reference's own operating point (models/config.py:14-19, train.py:27-28: batch 2 x 18000 points) through the headline's schedule --
+    layers replayed from a hipGraph, geometry prefetched on the side streams -- in a child process"""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--shape", "2,18000", "--kind-leg", "--no-cpu-baseline", "--steps", "100", "--warmup", "10"]
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"error": "child exited with code %d" % r.returncode, "stderr_tail": r.stderr[-400:]}
+        d = json.loads(lines[-1])
+        return {"workload": d["config"]["workload"], "schedule": d["config"]["schedule"], "ms_per_step": d["ms_per_step"], "median_ms_per_step": d["median_ms_per_step"],
+                "scenes_per_s": d["value"], "steps": d["steps"], "fps_sa1": {k: d["roofline"].get(k) for k in ("avg_launch_ms", "us_per_pick")},
+                "host_enqueue_ms_per_step": d.get("host_enqueue_ms_per_step"), "host_wait_ms_per_step": d.get("host_wait_ms_per_step")}
+    except Exception as e:
+        return {"error": repr(e)}
 
 
 def run_legs_in_child(args, timeout=900):
