@@ -898,11 +898,18 @@ def ops_roofline(xyz, geo, dev, timer=None):
     if timer is None:
         timer = lambda key, fn: _ev_time(fn)       # (tools/ops_only.py passes one that brackets a single launch with marker kernels for the PMC passes)
 
-    def add(name, shape, alg_bytes, fn, bound_by, key=None):
+    # vector-issue yardstick for the ops that work out of LDS / registers (their HBM fraction says nothing: VERDICT r04): lane-instructions per
+    # second the chip can issue = 256 CUs x 4 SIMDs x 64 lanes x 2.4 GHz / 2.07 cycles per fp32 add/mul/fma (tools/valu_probe*.hip)
+    VALU_PEAK = 256 * 4 * 64 * 2.4e9 / 2.07
+
+    def add(name, shape, alg_bytes, fn, bound_by, key=None, lane_instr=None):
         ms = timer(key or name, fn)
         ach = alg_bytes / (ms * 1e-3) / 1e9
-        out.append({"op": name, "shape": shape, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": ms, "achieved": ach,
-                    "frac": ach / HBM_PEAK_GBS, "traffic": pmc.get(key or name), "bound_by": bound_by})
+        e = {"op": name, "shape": shape, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": ms, "achieved": ach,
+             "frac": ach / HBM_PEAK_GBS, "traffic": pmc.get(key or name), "bound_by": bound_by}
+        if lane_instr is not None:          # (pairs x vector instructions per pair) / time against the issue peak
+            e["valu_issue_frac"] = lane_instr / (ms * 1e-3) / VALU_PEAK
+        out.append(e)
 
     torch.set_grad_enabled(False)            # forward launches and direct C-ABI gradient launches only: nothing here records an autograd graph
     lv = [xyz, geo["sa"][0].new_xyz, geo["sa"][1].new_xyz, geo["sa"][2].new_xyz]
@@ -912,7 +919,7 @@ def ops_roofline(xyz, geo, dev, timer=None):
         order = geo["sa"][d].scan_order if d < 3 else None
         add("three_nn", "%dx%d<-%d%s" % (b, n, m, " (queries in the FPS pre-pass order)" if order is not None else ""), 12.0 * b * n * m + 36.0 * b * n, lambda: three_nn(lv[d], lv[s_], order=order),
             "VALU issue + LDS broadcast: 4 instructions per (query, candidate) pair, exact re-evaluation of the survivors; the known cloud (<= 24 KB per "
-            "scene) sits in LDS" if n >= 2048 else "launch latency (a few microseconds of work)", "three_nn_%d" % n)
+            "scene) sits in LDS" if n >= 2048 else "launch latency (a few microseconds of work)", "three_nn_%d" % n, lane_instr=4.0 * b * n * m)
     # three_interpolate (+grad) (tf_interpolate.cpp:107-153): b*n*(24 + 16*c), and the fused FP input used by the bench graph
     for (d, s_, c2, c1, k) in ((0, 1, 128, 3, 2), (1, 2, 256, 64, 1), (2, 3, 256, 128, 0)):
         n, m = lv[d].shape[1], lv[s_].shape[1]
@@ -970,7 +977,8 @@ def ops_roofline(xyz, geo, dev, timer=None):
         a = torch.randn(nb, n, 3, device=dev, generator=gen)
         c_ = torch.randn(nb, m, 3, device=dev, generator=gen)
         add("nn_distance", "%d clouds x (%d, %d)" % (nb, n, m), 12.0 * nb * 2 * n * m + 8.0 * nb * (n + m), lambda: nn_distance(a, c_),
-            "VALU issue: 7 instructions per point pair from LDS tiles (the clouds are on-chip; 38 MB of input for 2048 clouds)", "nn_distance_%d" % n)
+            "VALU issue: 7 instructions per point pair from LDS tiles (the clouds are on-chip; 38 MB of input for 2048 clouds)", "nn_distance_%d" % n,
+            lane_instr=7.0 * nb * 2 * n * m)
         with torch.no_grad():
             d1, i1, d2, i2 = nn_distance(a.detach(), c_.detach())
         g1, g2 = torch.randn_like(d1), torch.randn_like(d2)

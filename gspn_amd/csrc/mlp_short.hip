@@ -30,7 +30,7 @@
 #include <type_traits>
 #include <algorithm>
 
-namespace {
+namespace gspn_k {
 
 template <int N> struct VecF;
 template <> struct VecF<1> { typedef float type; };
@@ -347,7 +347,8 @@ __global__ __launch_bounds__(256) void wgrad_short_kernel(int rows, int cin, int
         }
 }
 
-}  // namespace
+}  // namespace gspn_k
+using namespace gspn_k;
 
 // launcher for wgrad_impl (mlp.hip): false when the shape is not one the kernel takes.  rpc / nch: the plan's chunking (wgrad_plan, short form)
 bool gspn_wgrad_short_go(long rows, int cin, int cout, const gspn_dy_args* a, const float* X, int ldx, const float* in_scale, const float* in_shift,
@@ -372,8 +373,6 @@ bool gspn_wgrad_short_go(long rows, int cin, int cout, const gspn_dy_args* a, co
     return true;
 }
 
-namespace {
-}  // namespace
 
 // Tile shape per layer shape: enough workgroups to give every SIMD several waves (>= ~4 x 224 CUs), MFMA tiles per k step as large as that
 // allows (an A value feeds NT MFMAs, a B vector MT).  GSPN_FWD_SHORT_MT / _NT force a shape (tools/short_sweep.py), GSPN_FWD_SHORT=0 turns

@@ -24,7 +24,7 @@
 #define FPS_AMAX 8
 #endif
 
-namespace {
+namespace gspn_k {
 
 constexpr int NC = 16;            // cells
 // LDS map (bytes)
@@ -314,7 +314,8 @@ __global__ __launch_bounds__(FPS_T) void fps_stripe_kernel(int n, int m, int csz
         for (int jj = j + t; jj < m; jj += FPS_T) o[jj] = termk - 1;
 }
 
-}  // namespace
+}  // namespace gspn_k
+using namespace gspn_k;
 
 // launcher (sampling.hip: gspn_fps_cells_strided): cells of 1025..2048 points, i.e. 16385 <= n <= 32768
 int gspn_fps_stripe_launch(int b, int n, int m, int csz, const float* sxyz, const int* perm, const float* inp0, int stride0, int* out, hipStream_t st) {
