@@ -29,8 +29,8 @@ static inline bool vec_ok(const void* p, int ld) { return (ld % 4 == 0) && (((ui
 // rows at or below which the FORWARD of a layer takes the split-K kernel of mlp_short.hip.  Measured (tools/r05_short_ab.sh, graph-timed,
 // us, round-4 kernel -> split-K): 4096 x 256 -> 128 9.9 -> 7.1, 4096 x 128 -> 128 6.0 -> 4.4, 4096 x 384 -> 256 13.4 -> 13.3; at 16384 rows
 // 12.4 -> 13.9 / 6.9 -> 7.4 and at 32768 rows 17.5 -> 19.3 / 32.4 -> 38.4: with K = 128 a 32-row tile is 16 MFMAs per wave behind a full
-// global-load round trip, and the LDS footprint (partials + staged A) keeps 4 workgroups per CU -- not enough to cover it.  (A launch in a
-// captured chain costs ~4.5-4.9 us whatever it does -- 16384 x 64 -> 64 reads 4.9 us -- so the 4096-row layers are now at launch cost + 0-3 us.)
+// global-load round trip, and the LDS footprint (partials + staged A) keeps 4 workgroups per CU -- not enough to cover it.  (A trivial
+// dependent node of the captured chain costs 1.6 us, tools/r05_launch_floor.py; 16384 x 64 -> 64 reads 4.9 us.)
 #ifndef GSPN_SHORT_ROWS
 #define GSPN_SHORT_ROWS 8192
 #endif
@@ -43,7 +43,7 @@ static inline long short_fwd_parts(long rows) { const long t = rows / 32; return
 // graph-timed incl. the dW sum launch, us streaming -> this): 4096 x 384^T x 256 25.2 -> 23.7, 16384 x 192^T x 128 30.0 -> 32.6,
 // 32768 x 128^T x 128 34.1 -> 32.5, 32768 x 128^T x 256 (pool) 56.2 -> 58.1, and its chunking costs the tiny products 3-4 us
 // (4096 x 128^T x 128 10.9 -> 14.4).  Two unrelated decompositions landing on the same times says what bounds these launches is not the
-// loop: dispatch (~4.5 us) + ramp + one global-memory round trip + drain, with <= 2 us of matrix work per wave (profiles/r05_experiments.txt).
+// loop: node cost (1.6 us) + ramp + cold global-memory round trips + drain, with <= 2 us of matrix work per wave (profiles/r05_experiments.txt).
 static inline bool gspn_wgrad_short_shape(long rows, int cin, int cout) {
     static const int on = env_int("GSPN_WGRAD_SHORT", 0);
     return on && rows >= 256 && rows <= 32768 && !(rows & 31) && !(cin & 63) && !(cout & 63);
