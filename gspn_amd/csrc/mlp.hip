@@ -1331,6 +1331,24 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
     v += dpp_f64<0xB1>(v);           // quad_perm [1,0,3,2]
     return v;
 }
+// sum over the partial rows p = t, t + 256, ... of src[p * ld + off] and src[p * ld + off2] in double, ascending p.  The loads of FOUR rows (eight
+// values) are issued before the first is consumed: the rows were written by other XCDs in the kernel before, so every dependent batch is a
+// round trip to the Infinity Cache -- a loop that adds as it loads pays one per iteration (r05: bn_finalize 4.8 us in the step, 1.6 of it the node).
+__device__ __forceinline__ void part_rows_sum2(const float* __restrict__ src, size_t ld, int off, int off2, int nparts, int t, double& a0, double& a1) {
+    for (int base = 0; base < nparts; base += 1024) {
+        float u0[4], u1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = base + t + 256 * u;
+            const int pc = p < nparts ? p : nparts - 1;              // clamped, unconditional: all eight loads in flight together
+            u0[u] = src[(size_t)pc * ld + off];
+            u1[u] = src[(size_t)pc * ld + off2];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (base + t + 256 * u < nparts) { a0 += (double)u0[u]; a1 += (double)u1[u]; }
+    }
+}
 // one WORKGROUP per channel: 256 threads stride over the forward's per-block partials (double accumulation), then finalise
 __global__ __launch_bounds__(256) void bn_finalize_kernel(long rows, int c, const float* __restrict__ stats, int nparts, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float eps, float decay, int is_training,
@@ -1354,7 +1372,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(long rows, int c, cons
     double mu, v;
     if (is_training) {
         double a0 = 0.0, a1 = 0.0;
-        for (int p = threadIdx.x; p < nparts; p += 256) { a0 += (double)stats[(size_t)p * 2 * c + j]; a1 += (double)stats[(size_t)p * 2 * c + c + j]; }
+        part_rows_sum2(stats, (size_t)2 * c, j, c + j, nparts, (int)threadIdx.x, a0, a1);
         a0 = wave_sum_f64(a0);
         a1 = wave_sum_f64(a1);
         if (lane == 0) { sh2[0][wv] = a0; sh2[1][wv] = a1; }
@@ -2919,7 +2937,7 @@ __device__ __forceinline__ void bwd_coef_block(const CoefJob& q, int n, double (
     float g0 = 1.f, v0 = 1.f, m0 = 0.f;                                // (asked for before the partial rows, see bn_finalize_kernel)
     if (t == 0) { if (gamma) g0 = gamma[n]; v0 = var[n]; m0 = mean[n]; }
     double a0 = 0.0, a1 = 0.0;
-    for (int p = t; p < nparts; p += 256) { a0 += (double)part[(size_t)p * 2 * c + n]; a1 += (double)part[(size_t)p * 2 * c + c + n]; }
+    part_rows_sum2(part, (size_t)2 * c, n, c + n, nparts, t, a0, a1);
     a0 = wave_sum_f64(a0); a1 = wave_sum_f64(a1);
     if (lane == 0) { sh[0][wave] = a0; sh[1][wave] = a1; }
     __syncthreads();
