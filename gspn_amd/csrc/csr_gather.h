@@ -34,8 +34,11 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
+// row loads issued together per 16-lane row (CPL = 1; halved / quartered for wider rows).  r04 measured 8 vs 16 on the uniform clouds (no
+// difference) and kept 8; on the room scenes (S: skewed list lengths, the longest lists ARE the kernel's time) 16 takes csr_gather16<1,true>
+// from 64 to ~50 us and the captured layers from 1.605 to 1.585 ms, U unchanged (tools/r05_csr_u.sh).
 #ifndef GSPN_CSR_U1
-#define GSPN_CSR_U1 8
+#define GSPN_CSR_U1 16
 #endif
 struct CsrCopy {                      // the skip-link columns of fp_concat's gradient are a plain slice of grad_out: trailing workgroups copy it
     const float* g; float* dst; int ld, c0, c1; long total;
