@@ -333,8 +333,16 @@ def main():
 
     if PAIRED and (DEPTH != GROUP or NB != 2 * GROUP):
         raise SystemExit("GSPN_BENCH_PAIRED needs GSPN_BENCH_DEPTH = GSPN_BENCH_GROUP and 2 x GROUP batch slots")
+    # Phase of the paired submissions (r05).  Pairs go out every GROUP-th step; which residue is free.  It is chosen from the run length so that
+    # the LAST step of the run is never a submitting one: a pair submitted by the final step has one step's time to run a 2.65 ms chain and the
+    # rest shows up after the last step as a drain (1.1-1.6 ms once per run: 3 % of the driver's 20-step form, nothing at 100 steps).  Every step
+    # still gets exactly one geometry pass and any K consecutive steps contain K passes' submissions -- only WHEN inside a pair of steps changes.
+    PHASE = ((args.warmup + args.steps) % GROUP) if (PAIRED and os.environ.get("GSPN_BENCH_PHASE", "auto") == "auto") else (int(os.environ.get("GSPN_BENCH_PHASE", "0")) % GROUP if PAIRED else 0)
+
+    def is_submit(i):
+        return (i - PHASE) % GROUP == 0
     if geo is not None and not LAYERS_ONLY:
-        for j in range(DEPTH):
+        for j in range(DEPTH + PHASE):                     # steps 0 .. GROUP + PHASE - 1: the first submitting step (PHASE) sends PHASE + GROUP ...
             submit_geometry(j)
 
     def step():
@@ -362,12 +370,12 @@ def main():
             # of slot (i+DEPTH) % NB = (i-1) % NB, which the layers of step i-1 read: the HOST waits for that step (step i is already
             # queued behind it, so the GPU never idles) instead of making the side stream wait on the layers' stream.
             # (only the step whose completion the host will wait for gets an event: the last of each group)
-            if not PAIRED or i % GROUP == GROUP - 1:
+            if not PAIRED or is_submit(i + 1):
                 done[i] = torch.cuda.current_stream().record_event()
             if PAIRED:
                 # every GROUP-th step submits the geometry of steps i+GROUP .. i+2*GROUP-1 at once (their slots were last read by steps
                 # i-GROUP .. i-1: the host waits for step i-1)
-                if i % GROUP == 0:
+                if is_submit(i):
                     if (i - 1) in done:
                         tw = time.perf_counter()
                         done.pop(i - 1).synchronize()
@@ -540,6 +548,7 @@ def main():
                          "avg_launch_ms": fps_avg_ms, "us_per_pick": fps_avg_ms * 1e3 / m, "launches_timed": len(fps_ms), "concurrent_launches": concurrent},
             "geometry_streams": None if geo is None else {"hw_queues_env": os.environ.get("GPU_MAX_HW_QUEUES"), "streams_tried": [g_.tried for g_ in geo],
                                                          "shares_a_queue": [g_.shares_queue for g_ in geo]},
+            "geometry_pair_phase": PHASE if (PAIRED and geo is not None) else None,      # pairs are submitted by the steps i with i % 2 == phase (chosen so that the run's last step submits none)
             "host_enqueue_ms_per_step": t_host / args.steps * 1e3,
             "host_wait_ms_per_step": state["t_wait"] / args.steps * 1e3,
             "host_replay_ms_per_step": state.get("t_replay", 0.0) / (args.steps + args.warmup) * 1e3,
