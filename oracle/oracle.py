@@ -24,7 +24,9 @@ def build(force=False):
     so = os.path.join(_HERE, "libgspn_oracle.so")
     src = os.path.join(_HERE, "gspn_oracle.c")
     stale = (not os.path.exists(so)) or os.path.getmtime(so) < os.path.getmtime(src)
-    if force or stale or (os.path.isdir("/root/reference") and not os.path.exists(os.path.join(_HERE, "_ref", "libinterp_ref.so"))):
+    ref_missing = os.path.isdir("/root/reference") and not all(
+        os.path.exists(os.path.join(_HERE, "_ref", f)) for f in ("libinterp_ref.so", "libslices_ref.so"))
+    if force or stale or ref_missing:
         subprocess.check_call(["make", "-C", _HERE, "all"], stdout=subprocess.DEVNULL)
     return so
 
@@ -72,6 +74,22 @@ def ref_lib():
         if os.path.exists(p):
             _REF = ctypes.CDLL(p)
     return _REF
+
+
+_SLICES = None
+
+
+def slices_lib():
+    """oracle/_ref/libslices_ref.so: the reference's own `threenn_cpu` (tf_interpolate.cpp:60-103) and `nnsearch`
+    (tf_nndistance.cpp:21-43), cut out of /root/reference at build time and compiled by g++ -O2 (oracle/Makefile: slices); or None."""
+    global _SLICES
+    if _SLICES is None:
+        p = os.path.join(_HERE, "_ref", "libslices_ref.so")
+        if not os.path.exists(p):
+            build()
+        if os.path.exists(p):
+            _SLICES = ctypes.CDLL(p)
+    return _SLICES
 
 
 def _fp(a):
@@ -285,6 +303,34 @@ def ref_three_interpolate_grad(points, idx, weight, grad_out):
     g = np.zeros((b, m, c), np.float32)  # caller memset, tf_interpolate.cpp:258
     getattr(r, "_Z20interpolate_grad_cpuiiiiPKfPKiS0_Pf")(b, n, c, m, _fp(grad_out), _ip(idx), _fp(weight), _fp(g))
     return g
+
+
+def ref_three_nn(xyz1, xyz2):
+    """the reference's compiled threenn_cpu (tf_interpolate.cpp:60-103) -> (dist (b,n,3) squared, idx (b,n,3))"""
+    r = slices_lib()
+    xyz1, xyz2 = _f32(xyz1), _f32(xyz2)
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    dist = np.empty((b, n, 3), np.float32)
+    idx = np.empty((b, n, 3), np.int32)
+    r.threenn_cpu(b, n, m, _fp(xyz1), _fp(xyz2), _fp(dist), _ip(idx))
+    return dist, idx
+
+
+def ref_nnsearch(xyz1, xyz2):
+    """the reference's compiled nnsearch (tf_nndistance.cpp:21-43), run in both directions as NnDistanceOp::Compute does
+    (tf_nndistance.cpp:79-80) -> (dist1, idx1, dist2, idx2)"""
+    r = slices_lib()
+    xyz1, xyz2 = _f32(xyz1), _f32(xyz2)
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    d1 = np.empty((b, n), np.float32)
+    i1 = np.empty((b, n), np.int32)
+    d2 = np.empty((b, m), np.float32)
+    i2 = np.empty((b, m), np.int32)
+    r.nnsearch_ref(b, n, m, _fp(xyz1), _fp(xyz2), _fp(d1), _ip(i1))
+    r.nnsearch_ref(b, m, n, _fp(xyz2), _fp(xyz1), _fp(d2), _ip(i2))
+    return d1, i1, d2, i2
 
 
 # ---- tf_nndistance -----------------------------------------------------------------------

@@ -40,6 +40,53 @@ def test_interpolate_restatement_matches_live_reference_build():
     np.testing.assert_array_equal(O.three_interpolate_grad(pts, idx, w, go), O.ref_three_interpolate_grad(pts, idx, w, go))
 
 
+# ---- the real reference code (threenn_cpu, nnsearch): free functions cut out of TF-dependent files at build time ----------
+THREENN_CASES = ["demo", "lattice", "dups", "m2", "m1", "fp_level", "grid"]
+NNSEARCH_CASES = ["demo", "lattice", "single", "ins"]
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+@pytest.mark.parametrize("case", THREENN_CASES)
+def test_three_nn_restatement_matches_reference_golden(case):
+    """oracle three_nn == vectors of the reference's compiled threenn_cpu (tf_interpolate.cpp:60-103): indices AND squared distances bit for bit
+    (inf tails where m < 3 included)"""
+    g = np.load(os.path.join(GOLD, "threenn_ref.npz"))
+    d, i = O.three_nn(g[case + "_xyz1"], g[case + "_xyz2"])
+    np.testing.assert_array_equal(i, g[case + "_idx"])
+    np.testing.assert_array_equal(_bits(d), _bits(g[case + "_dist"]))
+
+
+@pytest.mark.parametrize("case", NNSEARCH_CASES)
+def test_nn_distance_cpu_twin_matches_reference_golden(case):
+    """oracle nn_distance(cpu_twin=True) == vectors of the reference's compiled nnsearch (tf_nndistance.cpp:21-43, both directions :79-80) bit for bit;
+    the CUDA-derived form (policy-2 contraction) picks the same neighbours on these clouds and differs from it by at most one rounding of the distance"""
+    g = np.load(os.path.join(GOLD, "nnsearch_ref.npz"))
+    a, b = g[case + "_xyz1"], g[case + "_xyz2"]
+    for got, key in zip(O.nn_distance(a, b, cpu_twin=True), ("d1", "i1", "d2", "i2")):
+        np.testing.assert_array_equal(_bits(got), _bits(g[case + "_" + key]))
+    d1, i1, d2, i2 = O.nn_distance(a, b)
+    np.testing.assert_array_equal(i1, g[case + "_i1"])
+    np.testing.assert_array_equal(i2, g[case + "_i2"])
+    np.testing.assert_allclose(d1, g[case + "_d1"], rtol=2.5e-7, atol=0)
+    np.testing.assert_allclose(d2, g[case + "_d2"], rtol=2.5e-7, atol=0)
+
+
+def test_three_nn_and_nnsearch_restatements_match_live_reference_build():
+    if O.slices_lib() is None:
+        pytest.skip("oracle/_ref/libslices_ref.so not built (no /root/reference on this box)")
+    for seed, (b, n, m) in enumerate([(2, 700, 333), (1, 64, 3), (3, 129, 1000)]):
+        x1, x2 = D.batch("S", b, n, 50 + seed), D.batch("U", b, m, 60 + seed) * 3.0
+        d, i = O.three_nn(x1, x2)
+        rd, ri = O.ref_three_nn(x1, x2)
+        np.testing.assert_array_equal(i, ri)
+        np.testing.assert_array_equal(_bits(d), _bits(rd))
+        for got, want in zip(O.nn_distance(x1, x2, cpu_twin=True), O.ref_nnsearch(x1, x2)):
+            np.testing.assert_array_equal(_bits(got), _bits(want))
+
+
 # ---- committed oracle fixtures ------------------------------------------------------------------
 def test_oracle_fixture_config1():
     g = np.load(os.path.join(GOLD, "oracle_c1_fps_ball.npz"))

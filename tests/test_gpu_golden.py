@@ -5,7 +5,11 @@
    built by g++ -O2, tests/make_golden.py) on the shapes of tf_interpolate.py:39-48 and tf_interpolate_op_test.py:11-16 -- three_interpolate
    bit-exact; its gradient bit-exact through the op API (ordered sums) and 1e-5 through the drop-in atomic symbol.
  * oracle_c1_fps_ball.npz: BASELINE configs[0] (1 x 4096 -> 512, r 0.2, ns 32); oracle_dup_fps_ball.npz: duplicate-heavy clouds where the
-   (k mod 512, k) tie rule decides; oracle_nn.npz: nn_distance and 3-NN on the demo seeds -- indices and floats bit-exact."""
+   (k mod 512, k) tie rule decides; oracle_nn.npz: nn_distance and 3-NN on the demo seeds -- indices and floats bit-exact.
+ * threenn_ref.npz / nnsearch_ref.npz (r06): vectors of the REFERENCE'S OWN compiled `threenn_cpu` (tf_interpolate.cpp:60-103) and `nnsearch`
+   (tf_nndistance.cpp:21-43), cut out of the reference at build time by oracle/Makefile: slices.  three_nn: indices and squared distances bit-exact
+   through all three kernels (wave / cell grid / tiled); nn_distance: the product (CUDA-derived contraction, policy 2) picks the same neighbours and
+   its distances are within one rounding; the policy-0 (unfused, = what g++ -O2 emits for the CPU twin) variant library is bit-exact."""
 import ctypes
 import glob
 import os
@@ -26,7 +30,8 @@ def dev(a):
 
 def test_every_golden_file_is_consumed_here():
     names = sorted(os.path.basename(f) for f in glob.glob(os.path.join(GOLD, "*.npz")))
-    assert names == ["interp_ref_demo.npz", "interp_ref_optest.npz", "oracle_c1_fps_ball.npz", "oracle_dup_fps_ball.npz", "oracle_nn.npz"], names
+    assert names == ["interp_ref_demo.npz", "interp_ref_optest.npz", "nnsearch_ref.npz", "oracle_c1_fps_ball.npz", "oracle_dup_fps_ball.npz", "oracle_nn.npz",
+                     "threenn_ref.npz"], names
 
 
 @pytest.mark.parametrize("name", ["interp_ref_demo.npz", "interp_ref_optest.npz"])
@@ -96,3 +101,79 @@ def test_nn_distance_and_three_nn_equal_the_vectors():
     td, ti = three_nn(a, b)
     np.testing.assert_array_equal(td.cpu().numpy(), h["t_d"])
     np.testing.assert_array_equal(ti.cpu().numpy(), h["t_i"])
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+@pytest.mark.parametrize("case", ["demo", "lattice", "dups", "m2", "m1", "fp_level", "grid"])
+def test_three_nn_equals_the_reference_binary_vectors(case):
+    """HIP three_nn (op API and the drop-in symbol with threenn_cpu's argument order) == the reference's compiled threenn_cpu, bit for bit"""
+    from gspn_amd import _lib as L
+    from gspn_amd.tf_interpolate import three_nn
+    g = np.load(os.path.join(GOLD, "threenn_ref.npz"))
+    x1, x2 = dev(g[case + "_xyz1"]), dev(g[case + "_xyz2"])
+    d, i = three_nn(x1, x2)
+    np.testing.assert_array_equal(i.cpu().numpy(), g[case + "_idx"])
+    np.testing.assert_array_equal(_bits(d.cpu().numpy()), _bits(g[case + "_dist"]))
+    b, n, _ = x1.shape
+    m = x2.shape[1]
+    d2 = torch.full((b, n, 3), float("nan"), device="cuda")
+    i2 = torch.full((b, n, 3), -1, dtype=torch.int32, device="cuda")
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    assert L.lib().gspn_threenn(b, n, m, P(x1), P(x2), P(d2), P(i2), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(i2.cpu().numpy(), g[case + "_idx"])
+    np.testing.assert_array_equal(_bits(d2.cpu().numpy()), _bits(g[case + "_dist"]))
+
+
+def _nm(h, a, b):
+    bb, n, _ = a.shape
+    m = b.shape[1]
+    d1 = torch.empty((bb, n), device="cuda")
+    d2 = torch.empty((bb, m), device="cuda")
+    i1 = torch.empty((bb, n), dtype=torch.int32, device="cuda")
+    i2 = torch.empty((bb, m), dtype=torch.int32, device="cuda")
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    assert h.gspn_nmdistance(bb, n, P(a), m, P(b), P(d1), P(i1), P(d2), P(i2), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+    torch.cuda.synchronize()
+    return [t.cpu().numpy() for t in (d1, i1, d2, i2)]
+
+
+@pytest.mark.parametrize("case", ["demo", "lattice", "single", "ins"])
+def test_nn_distance_equals_the_reference_binary_vectors(case):
+    from gspn_amd import _lib as L
+    from tests.test_gpu_policy import _variant
+    g = np.load(os.path.join(GOLD, "nnsearch_ref.npz"))
+    a, b = dev(g[case + "_xyz1"]), dev(g[case + "_xyz2"])
+    want = [g[case + "_" + k] for k in ("d1", "i1", "d2", "i2")]
+    d1, i1, d2, i2 = _nm(L.lib(), a, b)                                  # the product: NmDistanceKernel's contraction (policy 2)
+    np.testing.assert_array_equal(i1, want[1])
+    np.testing.assert_array_equal(i2, want[3])
+    np.testing.assert_allclose(d1, want[0], rtol=2.5e-7, atol=0)
+    np.testing.assert_allclose(d2, want[2], rtol=2.5e-7, atol=0)
+    for got, w in zip(_nm(_variant(0), a, b), want):                     # unfused build == the CPU twin as g++ -O2 compiled it
+        np.testing.assert_array_equal(_bits(got), _bits(w))
+
+
+def test_three_nn_and_nn_distance_equal_the_live_reference_binary_at_the_model_shapes():
+    """oracle/_ref/libslices_ref.so travels with the snapshot (like every built .so): the dense FP level 32768 <- 2048 (cell-grid kernel) on one U and one S
+    scene, and the Chamfer shape 64 x (512, 512), against the reference's compiled loops run on this box's host"""
+    from oracle import oracle as O
+    from gspn_amd.tf_interpolate import three_nn
+    from tests.test_gpu_policy import _variant
+    if O.slices_lib() is None:
+        pytest.skip("oracle/_ref/libslices_ref.so absent")
+    from gspn_amd.tf_sampling import farthest_point_sample, gather_point
+    for kind in ("U", "S"):
+        x1 = dev(D.batch(kind, 1, 32768, 3))
+        x2 = gather_point(x1, farthest_point_sample(2048, x1))
+        d, i = three_nn(x1, x2)
+        rd, ri = O.ref_three_nn(x1.cpu().numpy(), x2.cpu().numpy())
+        np.testing.assert_array_equal(i.cpu().numpy(), ri)
+        np.testing.assert_array_equal(_bits(d.cpu().numpy()), _bits(rd))
+    a, b = D.batch("U", 64, 512, 100), D.batch("U", 64, 512, 300)
+    want = O.ref_nnsearch(a, b)
+    for got, w in zip(_nm(_variant(0), dev(a), dev(b)), want):
+        np.testing.assert_array_equal(_bits(got), _bits(w))
