@@ -235,6 +235,145 @@ def test_fea_extractor_full_size_forward_backward(scenes):
     assert err < 1e-5, err
 
 
+def _mlp_nodes(root):
+    """every _MlpStack autograd node reachable from `root`, keyed by the data_ptr of its first layer's weights"""
+    seen, todo, found = {}, [root], {}
+    while todo:
+        f = todo.pop()
+        if f is None or id(f) in seen:
+            continue
+        seen[id(f)] = f                                  # (keeps the wrapper alive: a collected wrapper's id would be reused)
+        if type(f).__name__.startswith("_MlpStack"):
+            found[f.spec["layers"][0].weights.data_ptr()] = f
+        todo.extend(nf for nf, _ in f.next_functions)
+    return found
+
+
+def test_fea_extractor_training_mode_values_and_gradients_at_full_size(scenes):
+    """BASELINE configs[2] in TRAINING mode -- 8 x 32768 points through all 16 layers with batch statistics over the whole batch --
+    against the float64 composition of oracle/mlp_ref.py evaluated on the device over the same (oracle-checked, test above) geometry.
+      (i)  every module (3 SA, 3 FP) on IDENTICAL INPUTS -- the float64 module fed the float32 tensors the GPU module was fed -- within 1e-5: north_star's bar;
+      (ii) the whole 16-layer composition chained in float64 from the raw inputs: the output differs by what six float32 modules compound to
+           (measured 2.0e-5 of max |out|; bound 5e-5 -- ANY float32 evaluation, the reference's included, sits this far from float64);
+           and EVERY parameter gradient of the module (weights, gamma, beta) under the upstream gradient the GPU backward handed that module within 1e-5,
+           nothing silenced: the float64 backward is routed by the ReLU masks / pool winners of the GPU forward's own float32 values
+           (tests/test_gpu_mlp.py: check_stack_routed), so what is compared is arithmetic;
+      (iii) the chained composition's 48 parameter gradients, through the grouping, pooling, interpolation and skip-link gradients between the stacks
+           (measured 6e-5; bound 2e-4: the forward difference of (ii) propagated)."""
+    from oracle import mlp_ref as R
+    from gspn_amd import tf_util
+    from gspn_amd.fea_extractor import PN2_SA_SPEC, pn2_geometry
+    from gspn_amd.pointnet_util import pointnet_fp_module, pointnet_sa_module
+    xyz, t = scenes
+    dev = t.device
+    col = torch.rand(B, N, 3, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+    geo = pn2_geometry(t)
+    store = tf_util.set_variable_store(tf_util.VariableStore(seed=21))
+    # pn2_fea_extractor's own body (fea_extractor.py / model_rpointnet.py:209-233), kept open so that the modules' outputs can be looked at
+    gpu_feats, cur_xyz, cur_pts = [col], t, col
+    with tf_util.variable_scope('fea'):
+        lx = [t]
+        for lvl, ((npoint, radius, ns), mlp) in enumerate(zip(PN2_SA_SPEC, ([32, 32, 64], [64, 64, 128], [128, 128, 256]))):
+            cur_xyz, cur_pts, _ = pointnet_sa_module(cur_xyz, cur_pts, npoint=npoint, radius=radius, nsample=ns, mlp=mlp, mlp2=None, group_all=False,
+                                                     is_training=True, bn_decay=0.5, scope='layer%d' % (lvl + 1), geometry=geo["sa"][lvl])
+            lx.append(cur_xyz)
+            gpu_feats.append(cur_pts)
+        gpu_up = [gpu_feats[3]]
+        for k, (dl, mlp) in enumerate([(2, [256, 128]), (1, [128, 64]), (0, [64, 64, 64])]):
+            gpu_up.append(pointnet_fp_module(lx[dl], lx[dl + 1], gpu_feats[dl], gpu_up[-1], mlp, True, 0.5, scope='fa_layer%d' % (k + 1), geometry=geo["fp"][k]))
+    out = gpu_up[-1]
+    nodes = _mlp_nodes(out.grad_fn)
+    assert len(nodes) == 6
+
+    for tns in gpu_feats[1:] + gpu_up[1:]:
+        tns.retain_grad()                                  # the upstream gradient every module receives in the GPU backward
+
+    def stack(scope, names, h, pool_ns, keep):
+        node = nodes[store.vars["%s/%s/weights" % (scope, names[0])].data_ptr()]
+        assert len(node.saved) == len(names)
+        for nm, sv in zip(names, node.saved):
+            y, scale, shift = sv[5], sv[8], sv[9]
+            g = lambda k: store.vars["%s/%s/%s" % (scope, nm, k)].detach().double()
+            w = g("weights")
+            q = {"w": w.view(w.shape[-2], w.shape[-1]).clone().requires_grad_(True), "b": g("biases").clone().requires_grad_(True),
+                 "gamma": g("bn/gamma").clone().requires_grad_(True), "beta": g("bn/beta").clone().requires_grad_(True)}
+            if keep is not None:
+                keep["%s/%s" % (scope, nm)] = q
+            z, _, _ = R.layer(h, q["w"], q["b"], q["gamma"], q["beta"], None, None, True, 0.5, True, relu=False)
+            h = z * ((y.double() * scale.double() + shift.double()) > 0)          # the GPU forward's own decision: sign of fma(y, scale, shift)
+        if pool_ns:
+            arg = node.arg.long()
+            h = h.view(-1, pool_ns, h.shape[1]).gather(1, arg[:, None, :]).squeeze(1)
+        return h
+
+    bidx = torch.arange(B, device=dev)[:, None, None]
+
+    def sa(lvl, pts_in, feat_in, keep):
+        npoint, radius, ns = PN2_SA_SPEC[lvl]
+        gi = geo["sa"][lvl].idx.long()                                              # (B, npoint, ns)
+        new = geo["sa"][lvl].new_xyz.double()
+        rows = torch.cat([pts_in[bidx, gi] - new[:, :, None, :], feat_in[bidx, gi]], -1).reshape(B * npoint * ns, -1)
+        return stack('fea/layer%d' % (lvl + 1), ['conv0', 'conv1', 'conv2'], rows, ns, keep).view(B, npoint, -1)
+
+    def fp(k, names, up_in, skip, keep):
+        fpg = geo["fp"][k]
+        interp = (up_in[bidx, fpg.idx.long()] * fpg.weight.double()[..., None]).sum(2)      # (B, n_dense, c)
+        h = stack('fea/fa_layer%d' % (k + 1), names, torch.cat([interp, skip], -1).reshape(-1, interp.shape[-1] + skip.shape[-1]), None, keep)
+        return h.view(B, -1, h.shape[-1])
+
+    def grad_errors(ref_p):
+        """per parameter tensor: max |GPU - float64| over the tensor's largest float64 element; a gradient that is ~0 by construction (the beta of a pooled
+        top layer whose winners all pass the ReLU shifts an input column of batch-normalised layers by a constant: no effect) is measured against the
+        largest gradient element of its own layer instead -- its float32 value is the rounding residue of sums of that size"""
+        e = {}
+        for key, q in ref_p.items():
+            layer_scale = max(float(q[k].grad.abs().max()) for k in ("w", "gamma", "beta"))
+            for k, name in (("w", "weights"), ("gamma", "bn/gamma"), ("beta", "bn/beta")):
+                got = store.vars["%s/%s" % (key, name)].grad.double().reshape(q[k].shape)
+                den = float(q[k].grad.abs().max())
+                e["%s/%s" % (key, name)] = float((got - q[k].grad).abs().max()) / (den if den > 1e-6 * layer_scale else layer_scale)
+        return e
+
+    rel = lambda a, b_: float((a.detach().double() - b_.detach()).abs().max() / b_.detach().abs().max())
+    fp_names = [['conv_0', 'conv_1'], ['conv_0', 'conv_1'], ['conv_0', 'conv_1', 'conv_2']]
+    go = torch.randn(out.shape, dtype=torch.float64, device=dev, generator=torch.Generator(device="cuda").manual_seed(9))
+    out.backward(go.float())
+    # (i) module by module on identical inputs: outputs, and parameter gradients under the upstream gradient the GPU backward handed the module
+    per_module, per_module_g = {}, {}
+    for lvl in range(3):
+        ref_p = {}
+        r = sa(lvl, lx[lvl].double(), gpu_feats[lvl].detach().double(), ref_p)
+        per_module["sa%d" % (lvl + 1)] = rel(gpu_feats[lvl + 1], r)
+        r.backward(gpu_feats[lvl + 1].grad.double())
+        per_module_g.update(grad_errors(ref_p))
+    for k, dl in enumerate((2, 1, 0)):
+        ref_p = {}
+        r = fp(k, fp_names[k], gpu_up[k].detach().double(), gpu_feats[dl].detach().double(), ref_p)
+        per_module["fp%d" % (k + 1)] = rel(gpu_up[k + 1], r)
+        r.backward(go if k == 2 else gpu_up[k + 1].grad.double())
+        per_module_g.update(grad_errors(ref_p))
+    worst_m = max(per_module_g.items(), key=lambda kv: kv[1])
+    print("training-mode full size, per module on identical inputs: outputs %s; worst of %d parameter gradients %s %.2e"
+          % ({k: "%.1e" % v for k, v in per_module.items()}, len(per_module_g), worst_m[0], worst_m[1]))
+    assert max(per_module.values()) < 1e-5, per_module
+    assert worst_m[1] < 1e-5, sorted(per_module_g.items(), key=lambda kv: -kv[1])[:5]
+    # (ii) + (iii) the chained composition
+    ref_p = {}
+    feats = [col.double()]
+    for lvl in range(3):
+        feats.append(sa(lvl, lx[lvl].double(), feats[lvl], ref_p))
+    up = feats[3]
+    for k, dl in enumerate((2, 1, 0)):
+        up = fp(k, fp_names[k], up, feats[dl], ref_p)
+    err = rel(out, up)
+    up.backward(go)
+    gerr = grad_errors(ref_p)
+    worst = max(gerr.items(), key=lambda kv: kv[1])
+    print("training-mode full size, chained in float64 from the raw inputs: output rel err %.2e; worst parameter gradient %s %.2e" % (err, worst[0], worst[1]))
+    assert err < 5e-5, err
+    assert worst[1] < 2e-4, sorted(gerr.items(), key=lambda kv: -kv[1])[:5]
+
+
 def test_config5_scene_size_through_the_extractor():
     """BASELINE configs[4]'s per-GPU shard: 8 scenes x 65536 points through pn2_fea_extractor, forward + backward.  FPS takes the
     multi-CU kernel (one scene no longer fits a CU); every index equals the oracle's; the step is finite and bit-reproducible."""

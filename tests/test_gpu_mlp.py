@@ -149,6 +149,80 @@ def check_stack(rows, ld, cin, chans, ns, training, ref_device="cpu", neg_gamma=
         assert float((lp.biases.grad.double().cpu() - p["b"].grad.cpu()).abs().max()) < tol * max(scale, float(p["b"].grad.abs().max()))
 
 
+def check_stack_routed(rows, ld, cin, chans, ns, ref_device="cuda", tol=1e-5):
+    """Gradients at north_star's 1e-5, NOTHING silenced.  check_stack above compares against a float64 evaluation that makes its
+    own ReLU / arg-max decisions and therefore has to zero the upstream gradient wherever float32 might decide differently.  Here the float64
+    backward is ROUTED by the decisions the GPU forward actually took: layer l's ReLU mask is sign(fma(y, scale, shift)) of the GPU's own float32
+    (y, scale, shift) -- the expression every kernel applies (csrc/mlp.hip) -- and the pool takes the row the GPU's arg-max names.  With the routing equal,
+    every remaining difference is float32 arithmetic, and all of dX (every row), dW, dgamma, dbeta, dbias are held to `tol` of their largest element.
+    (That the decisions themselves are right is what the forward comparison at 1e-5 and check_stack establish: a wrong mask away from the kink would show
+    there.)"""
+    from gspn_amd.mlp import mlp_stack
+    g = torch.Generator().manual_seed(rows + cin + 1)
+    x64 = torch.randn(rows, ld, generator=g, dtype=torch.float64)
+    x64[:, cin:] = 0
+    ps = make_params(chans, cin, seed=cin + 1)
+    layers = to_layers(ps)
+    x = x64.float().cuda().requires_grad_(True)
+    out = mlp_stack(x, cin, layers, True, 0.7, pool_ns=ns)
+    node = out.grad_fn                                    # the autograd node IS the ctx of _MlpStack.forward
+    masks = []
+    for (_, _, _, _, _, y, _, _, scale, shift) in node.saved:
+        masks.append(((y.double() * scale.double() + shift.double()) > 0).to(ref_device))      # y*scale exact in float64: the sign of the fma
+    arg = node.arg.long().to(ref_device) if ns else None
+    xr = x64[:, :cin].to(ref_device).clone().requires_grad_(True)
+    for p in ps:
+        for k in p:
+            if torch.is_tensor(p[k]):
+                p[k] = p[k].to(ref_device)
+        for k in ("w", "b", "gamma", "beta"):
+            p[k] = p[k].clone().requires_grad_(True)
+    h = xr
+    flips = 0
+    for p, mk in zip(ps, masks):
+        z, _, _ = R.layer(h, p["w"], p["b"], p["gamma"], p["beta"], p["moving_mean"], p["moving_var"], True, 0.7, True, relu=False)
+        flips += int(((z.detach() > 0) != mk).sum())
+        h = z * mk
+    ref = h
+    if ns:
+        groups = rows // ns
+        assert int(arg.min()) >= 0 and int(arg.max()) < ns
+        ref = ref.view(groups, ns, -1).gather(1, arg[:, None, :]).squeeze(1)
+    assert rel_err(out, ref) < 1e-5
+    go = torch.randn(ref.shape, generator=g, dtype=torch.float64).to(ref_device)
+    ref.backward(go)
+    out.backward(go.float().cuda())
+    errs = {"dX": rel_err(x.grad[:, :cin], xr.grad)}
+    for li, (lp, p) in enumerate(zip(layers, ps)):
+        errs["dW%d" % li] = rel_err(lp.weights.grad, p["w"].grad)
+        errs["dgamma%d" % li] = rel_err(lp.gamma.grad, p["gamma"].grad)
+        errs["dbeta%d" % li] = rel_err(lp.beta.grad, p["beta"].grad)
+        # the bias feeds a batch-normalised layer: its true gradient is 0 up to rounding; hold it to tol of the weight gradient's scale
+        scale = max(float(p["w"].grad.abs().max()), 1e-6)
+        errs["dbias%d" % li] = float((lp.biases.grad.double().cpu() - p["b"].grad.cpu()).abs().max()) / max(scale, float(p["b"].grad.abs().max()))
+    print("check_stack_routed rows=%d cin=%d chans=%s ns=%s: %d decisions where float64 alone would have differed; worst %s"
+          % (rows, cin, chans, ns, flips, max(errs.items(), key=lambda kv: kv[1])))
+    bad = {k: v for k, v in errs.items() if not v < tol}
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("rows,ld,cin,chans,ns", [
+    (4096, 6, 6, [32, 32, 64], 32),
+    (2048, 67, 67, [64, 64, 128], 32),
+    (1000, 67, 67, [64, 64, 64], None),
+    (768, 384, 384, [256, 128], None),
+    (524288, 8, 6, [32, 32, 64], 32),          # the seven stacks of test_mlp_stack_at_bench_sizes
+    (131072, 68, 67, [64, 64, 128], 32),
+    (32768, 132, 131, [128, 128, 256], 32),
+    (4096, 384, 384, [256, 128], None),
+    (16384, 192, 192, [128, 64], None),
+    (262144, 68, 67, [64, 64, 64], None),
+    (262144, 8, 6, [64, 64, 128], 32),
+])
+def test_mlp_stack_gradients_at_1e5_with_the_gpu_forward_s_own_routing(rows, ld, cin, chans, ns):
+    check_stack_routed(rows, ld, cin, chans, ns)
+
+
 @pytest.mark.parametrize("rows,ld,cin,chans,ns", [
     (4096, 6, 6, [32, 32, 64], 32),        # SA1-shaped
     (2048, 67, 67, [64, 64, 128], 32),     # SA2-shaped
