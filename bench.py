@@ -948,6 +948,11 @@ def ops_roofline(xyz, geo, dev, timer=None):
         add("three_interpolate_grad (C-ABI drop-in symbol: scatter-add, hardware fp32 atomics)", "%dx%d->%d, c=%d" % (b, n, m, c2), 1.0 * b * n * (24 + 16 * c2),
             lambda: L.check(lib.gspn_threeinterpolate_grad(b, n, c2, m, L.ptr(go), L.ptr(fpg.idx), L.ptr(fpg.weight), L.ptr(gp2), L.stream()), "three_interpolate_grad"),
             "L2 atomic throughput: 3*c atomic adds per dense point onto m*c addresses", "three_interpolate_grad_%d" % n)
+        ws3 = torch.empty(int(lib.gspn_threeinterpolate_grad_ws_bytes(b, n, c2, m)), dtype=torch.uint8, device=dev)
+        add("three_interpolate_grad (C-ABI drop-in symbol WITH a workspace, ABI 9: inverse lists built in the call + the ordered gather)", "%dx%d->%d, c=%d" % (b, n, m, c2),
+            1.0 * b * n * (24 + 16 * c2),
+            lambda: L.check(lib.gspn_threeinterpolate_grad_ws(b, n, c2, m, L.ptr(go), L.ptr(fpg.idx), L.ptr(fpg.weight), L.ptr(gp2), L.ptr(ws3), L.stream()), "three_interpolate_grad_ws"),
+            "the list build (one workgroup per scene) + the dependent-load latency of the walk", "three_interpolate_grad_ws_%d" % n)
         idx2d = fpg.idx.reshape(b, 3 * n)
         add("inverse_lists (once per index tensor)", "%d x %d positions -> %d lists" % (b, 3 * n, m), 1.0 * b * (3 * n * 12 + 4 * m),
             lambda: inverse_lists(idx2d, m), "one workgroup per scene (LDS histogram + cursors), then a per-list sort", "inverse_lists_%d" % n)
@@ -979,6 +984,11 @@ def ops_roofline(xyz, geo, dev, timer=None):
             "(%d,%d) -> %dx%d, c=%d" % (m, ns, b, n, c), 1.0 * b * m * ns * (4 + 8 * c),
             lambda: L.check(lib.gspn_grouppoint_grad(b, n, c, m, ns, L.ptr(go), L.ptr(sa.idx), L.ptr(gpts), L.stream()), "group_point_grad"),
             "L2 atomic throughput", "group_point_grad_%d" % n)
+        wsg = torch.empty(int(lib.gspn_grouppoint_grad_ws_bytes(b, n, c, m, ns)), dtype=torch.uint8, device=dev)
+        add("group_point_grad (C-ABI drop-in symbol WITH a workspace, ABI 9: inverse lists built in the call + the ordered gather)", "(%d,%d) -> %dx%d, c=%d" % (m, ns, b, n, c),
+            1.0 * b * m * ns * (4 + 8 * c),
+            lambda: L.check(lib.gspn_grouppoint_grad_ws(b, n, c, m, ns, L.ptr(go), L.ptr(sa.idx), L.ptr(gpts), L.ptr(wsg), L.stream()), "group_point_grad_ws"),
+            "the list build (one workgroup per scene) + the dependent-load latency of the walk", "group_point_grad_ws_%d" % n)
     fidx = geo["sa"][0].idx[:, :, 0].contiguous()
     add("gather_point", "%dx%d -> %d" % (b, xyz.shape[1], fidx.shape[1]), 1.0 * b * fidx.shape[1] * (4 + 24), lambda: gather_point(xyz, fidx), "launch latency (590 KB moved)", "gather_point")
     # nn_distance (+grad) (tf_nndistance_g.cu:5-151): 12*b*(2*n*m) + 8*b*(n+m); grad b*(n+m)*56
@@ -996,6 +1006,11 @@ def ops_roofline(xyz, geo, dev, timer=None):
             lambda: L.check(lib.gspn_nmdistance_grad(nb, n, L.ptr(a), m, L.ptr(c_), L.ptr(g1), L.ptr(i1), L.ptr(g2), L.ptr(i2), L.ptr(ga), L.ptr(gc), L.stream()),
                             "nn_distance_grad"),
             "L2 atomic throughput + two memsets", "nn_distance_grad_%d" % n)
+        wsn = torch.empty(int(lib.gspn_nmdistance_grad_ws_bytes(nb, n, m)), dtype=torch.uint8, device=dev)
+        add("nn_distance_grad (C-ABI drop-in symbol WITH a workspace, ABI 9: two list builds + the ordered gather)", "%d clouds x (%d, %d)" % (nb, n, m), 56.0 * nb * (n + m),
+            lambda: L.check(lib.gspn_nmdistance_grad_ws(nb, n, L.ptr(a), m, L.ptr(c_), L.ptr(g1), L.ptr(i1), L.ptr(g2), L.ptr(i2), L.ptr(ga), L.ptr(gc), L.ptr(wsn), L.stream()),
+                            "nn_distance_grad_ws"),
+            "the list builds (one workgroup per cloud) + the walk", "nn_distance_grad_ws_%d" % n)
     torch.set_grad_enabled(True)
     return {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
             "achieved_is": "effective rate = SURVEY 8(d) algorithmic bytes / stand-alone launch time (HIP events, 20 calls, idle chip); traffic = PMC "

@@ -49,7 +49,6 @@ SIGNATURES = {
     "gspn_probsample": [_I, _I, _I, _P, _P, _P, _P, _P],
     "gspn_queryballpoint": [_I, _I, _I, _F, _I, _P, _P, _P, _P, _P],
     "gspn_queryballpoint_ws": [_I, _I, _I, _F, _I, _P, _P, _P, _P, _P, _P],
-    "gspn_queryballpoint_lds": [_I, _I, _I, _F, _I, _P, _P, _P, _P, _P],
     "gspn_selectionsort": [_I, _I, _I, _I, _P, _P, _P, _P],
     "gspn_knn_point": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
     "gspn_grouppoint": [_I, _I, _I, _I, _I, _P, _P, _P, _P],
@@ -107,6 +106,10 @@ SIGNATURES = {
     "gspn_mlp_bwd_data_dw2": [_L, _I, _I, _c.POINTER(DyArgs), _P, _I, _I, _P, _I, _P, _I, _P, _P, _F, _I, _I, _P, _P, _P, _I, _I, _P, _P],
     "gspn_mlp_bwd_data_dw": [_L, _I, _I, _c.POINTER(DyArgs), _P, _I, _I, _P, _I, _P, _I, _P, _P, _F, _I, _I, _P, _P, _P],
     "gspn_inverse_lists": [_I, _I, _I, _P, _P, _P, _P, _P],
+    "gspn_grouppoint_grad_ws": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
+    "gspn_scatteraddpoint_ws": [_I, _I, _I, _P, _P, _P, _P, _P],
+    "gspn_threeinterpolate_grad_ws": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
+    "gspn_nmdistance_grad_ws": [_I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "gspn_multi_copy": [_I, _P, _P, _P, _P],
     "gspn_three_nn_weights": [_L, _P, _P, _P],
     "gspn_adam_flat": [_L, _P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _L, _P],
@@ -131,9 +134,13 @@ SPECIAL = {
     "gspn_inverse_lists_work_ints": ([_I, _I, _I], _L),
     "gspn_dot_work_floats": ([], _L),
     "gspn_ball_ws_bytes": ([_I, _I, _I], _L),
+    "gspn_grouppoint_grad_ws_bytes": ([_I, _I, _I, _I, _I], _L),
+    "gspn_scatteraddpoint_ws_bytes": ([_I, _I, _I], _L),
+    "gspn_threeinterpolate_grad_ws_bytes": ([_I, _I, _I, _I], _L),
+    "gspn_nmdistance_grad_ws_bytes": ([_I, _I, _I], _L),
 }
 
-ABI_VERSION = 8         # == GSPN_ABI_VERSION of include/gspn_hip.h this binding was written against
+ABI_VERSION = 9         # == GSPN_ABI_VERSION of include/gspn_hip.h this binding was written against
 
 _lib = None
 

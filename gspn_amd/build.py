@@ -37,7 +37,7 @@ def _newer(target, deps):
 
 
 # translation units whose arithmetic depends on GSPN_DIST_POLICY (common.h: dist2_cuda); a policy-variant library holds only these
-POLICY_SOURCES = ("sampling.hip", "sampling_stripe.hip", "sampling_multi.hip", "grouping.hip", "nndistance.hip")
+POLICY_SOURCES = ("sampling.hip", "sampling_multi.hip", "grouping.hip", "nndistance.hip")
 
 
 def policy_lib_path(policy):

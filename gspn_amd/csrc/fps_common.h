@@ -51,6 +51,3 @@ __host__ __device__ __forceinline__ int fps_tie_rank_inv(unsigned r) { return (i
 //   perm (b,n) i32: sorted position -> original index (the buffer doubles as the key scratch of the counting sort)
 //   sxyz (b,n,3) f32: coordinates in sorted order
 int gspn_fps_prepass_cells(int b, int n, int ncell, int csz, const float* inp, int* perm, float* sxyz, hipStream_t st, int* vorder = nullptr);
-
-// sampling_stripe.hip: the cell scheme with every cell striped over all 16 waves (cells of 1025..2048 points); same arguments as fps_cell_kernel's launcher
-int gspn_fps_stripe_launch(int b, int n, int m, int csz, const float* sxyz, const int* perm, const float* inp0, int stride0, int* out, hipStream_t st);

@@ -417,76 +417,9 @@ extern "C" long gspn_ball_ws_bytes(int b, int n, int m) {
     return (long)((size_t)b * bqg_scene_bytes(n) + (((size_t)b * m + 15) / 16) * 16);
 }
 
-// LDS-tiled variant (what BASELINE.json's north_star sketches: point tiles staged in LDS, shared by the queries of a workgroup).
-// 8 waves = 8 queries per workgroup walk the data cloud in tiles of BQL_TILE points; a wave stops testing once it has nsample hits,
-// the workgroup stops loading once all of its waves have.  Same output as ball_query_kernel.  Kept as a measured alternative, NOT
-// the default: the early exit makes the queries of a workgroup need very different prefixes of the cloud (1440 of 32768 points on
-// average at SA level 1 of the benchmark), so the cooperative tile loads run to the slowest query while the scene is L2-resident
-// anyway -- measured on MI355X (tools/ball_bench.py): see DESIGN.md 4.2.
-#define BQL_WAVES 8
-#define BQL_TILE 1024
-__global__ __launch_bounds__(BQL_WAVES * 64) void ball_query_lds_kernel(int b, int n, int m, float thresh, int nsample,
-                                                                        const float* __restrict__ xyz1, const float* __restrict__ xyz2,
-                                                                        int* __restrict__ idx, int* __restrict__ pts_cnt) {
-    __shared__ float tile[BQL_TILE * 3];
-    __shared__ int s_live;
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int scene = blockIdx.x % b;
-    const int j = (blockIdx.x / b) * BQL_WAVES + wave;
-    const bool active = j < m;
-    const float* data = xyz1 + (size_t)scene * n * 3;
-    float qx = 0.f, qy = 0.f, qz = 0.f;
-    int* row = nullptr;
-    if (active) {
-        const float* qp = xyz2 + ((size_t)scene * m + j) * 3;
-        qx = qp[0]; qy = qp[1]; qz = qp[2];
-        row = idx + ((size_t)scene * m + j) * nsample;
-    }
-    int cnt = 0, first = 0;
-    bool done = !active;
-    for (int base = 0; base < n; base += BQL_TILE) {
-        if (threadIdx.x == 0) s_live = 0;
-        __syncthreads();
-        if (!done && lane == 0) atomicAdd(&s_live, 1);
-        __syncthreads();
-        if (s_live == 0) break;                                   // every query of the workgroup is full
-        const int tcnt = min(BQL_TILE, n - base);
-        for (int i = threadIdx.x; i < tcnt * 3; i += BQL_WAVES * 64) tile[i] = data[(size_t)base * 3 + i];
-        __syncthreads();
-        if (!done) {
-            for (int c0 = 0; c0 < tcnt && cnt < nsample; c0 += 64) {
-                const int p = c0 + lane;
-                bool hit = false;
-                if (p < tcnt) hit = dist2_cuda(qx - tile[p * 3 + 0], qy - tile[p * 3 + 1], qz - tile[p * 3 + 2]) < thresh;     // :27
-                const unsigned long long mask = __ballot(hit);
-                if (mask != 0ull) {
-                    if (cnt == 0) first = base + c0 + __builtin_ctzll(mask);
-                    const int pos = cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                    if (hit && pos < nsample) row[pos] = base + p;
-                    cnt += __builtin_popcountll(mask);
-                }
-            }
-            done = cnt >= nsample;
-        }
-    }
-    if (active) {
-        cnt = cnt < nsample ? cnt : nsample;
-        for (int l = cnt + lane; l < nsample; l += 64) row[l] = first;
-        if (lane == 0) pts_cnt[(size_t)scene * m + j] = cnt;
-    }
-}
-extern "C" int gspn_queryballpoint_lds(int b, int n, int m, float radius, int nsample, const float* xyz1, const float* xyz2,
-                                       int* idx, int* pts_cnt, void* stream) {
-    if (!(radius > 0.0f) || nsample <= 0) return GSPN_ERR_ARG;
-    if (b < 0 || n <= 0 || m < 0) return GSPN_ERR_ARG;
-    if (b == 0 || m == 0) return 0;
-    const long long blocks = (long long)b * ((m + BQL_WAVES - 1) / BQL_WAVES);
-    if (blocks > 0x7FFFFFFFll || (long long)n * 3 > 0x7FFFFFFFll) return GSPN_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(ball_query_lds_kernel, dim3((unsigned)blocks), dim3(BQL_WAVES * 64), 0, (hipStream_t)stream,
-                       b, n, m, ball_threshold(radius), nsample, xyz1, xyz2, idx, pts_cnt);
-    return gspn_launch_status();
-}
+// (The LDS-tiled variant north_star sketches -- point tiles staged in LDS, shared by the 8 queries of a workgroup -- was built, is index-exact and
+// slower: with the reference's early exit the queries of a workgroup need very different prefixes of an L2-resident cloud.  DESIGN.md 4.2 has the
+// numbers; the kernel lives in tools/patches/r06_pruned_alternates.patch.)
 
 static int ball_query_impl(int b, int n, int m, float radius, int nsample, const float* xyz1, const float* xyz2, void* ws,
                            int* idx, int* pts_cnt, void* stream) {

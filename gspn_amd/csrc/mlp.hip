@@ -2215,9 +2215,6 @@ static WgradPlan wgrad_plan(long rows, int cin, int cout, bool generic = false, 
     if (floor_ch < 1) floor_ch = 1;
     if (chunks > by_size) chunks = by_size > floor_ch ? by_size : floor_ch;
     if (forced_chunks > 0) chunks = forced_chunks;
-    // short layers (r05, mlp_short.hip: wgrad_short_kernel): the chunking follows THAT kernel's 64 x 64 output blocks (the streaming kernels,
-    // which still run the two-product form of these shapes, take any chunk count)
-    if (!generic && forced_chunks <= 0 && gspn_wgrad_short_shape(rows, cin, cout)) chunks = gspn_wgrad_short_chunks(rows, cin, cout);
     long rpc = (rows + chunks - 1) / chunks;
     if (rpc < 4L * p.TKW) rpc = 4L * p.TKW;
     const long rq = p.TKW > 32 ? p.TKW : 32;              // (r03) whole stages of the lean kernel (32 rows) as well as of the streaming one (TKW)
@@ -2692,7 +2689,6 @@ static int wgrad_impl(long rows, int cin, int cout, const gspn_dy_args* a, const
     const float* vr = use_bn ? var : nullptr;
     if (use_stream) {
         int launched = 0;
-        if (known && !gsrc && !p.shared && gspn_wgrad_short_go(rows, cin, cout, a, X, ldx, in_scale, in_shift, PP, p.rpc, p.nch, st)) launched = 1;
         if (!launched && known && !gsrc && wgrad_lean_try(rows, cin, cout, a, X, ldx, in_scale, in_shift, PP, p, st)) launched = 1;
         const dim3 grid((unsigned)((p.nch + 7) / 8 * 8 * p.nrow * p.ncol));
 #define WS_ARGS (int)rows, cin, cout, *a, X, ldx, in_scale, in_shift, mu, vr, eps, RP, GP, PP, (int)p.rpc, (int)p.nslots, p.shared, (int)p.nch, p.nrow, p.ncol

@@ -37,30 +37,8 @@ static inline bool vec_ok(const void* p, int ld) { return (ld % 4 == 0) && (((ui
 // partial-statistics rows of a short layer's forward launch (one per 32-row tile, at most 512)
 static inline long short_fwd_parts(long rows) { const long t = rows / 32; return t < 512 ? t : 512; }
 
-// ---- pass A (known coefficients) of a short layer: wgrad_short_kernel (mlp_short.hip) --------------------------------------------------
-// shapes it takes: <= 32768 rows (a multiple of 32), channels multiples of 64 (2 x 2 blocks of 32x32 tiles per workgroup).
-// OFF by default (GSPN_WGRAD_SHORT=1 turns it on): measured a wash against the LDS-DMA streaming kernel (tools/r05_short_ab.sh wgrad,
-// graph-timed incl. the dW sum launch, us streaming -> this): 4096 x 384^T x 256 25.2 -> 23.7, 16384 x 192^T x 128 30.0 -> 32.6,
-// 32768 x 128^T x 128 34.1 -> 32.5, 32768 x 128^T x 256 (pool) 56.2 -> 58.1, and its chunking costs the tiny products 3-4 us
-// (4096 x 128^T x 128 10.9 -> 14.4).  Two unrelated decompositions landing on the same times says what bounds these launches is not the
-// loop: node cost (1.6 us) + ramp + cold global-memory round trips + drain, with <= 2 us of matrix work per wave (profiles/r05_experiments.txt).
-static inline bool gspn_wgrad_short_shape(long rows, int cin, int cout) {
-    static const int on = env_int("GSPN_WGRAD_SHORT", 0);
-    return on && rows >= 256 && rows <= 32768 && !(rows & 31) && !(cin & 63) && !(cout & 63);
-}
-// row chunks (= partial-tile slots) of such a layer: about GSPN_WGRAD_SHORT_WGS (default 448 = two per planned CU) workgroups of
-// (cin/64) x (cout/64) output blocks, chunks of at least 128 rows (32 per wave)
-static inline long gspn_wgrad_short_chunks(long rows, int cin, int cout) {
-    static const int target = env_int("GSPN_WGRAD_SHORT_WGS", 448);
-    const long groups = (long)(cin / 64) * (cout / 64);
-    long ch = target / groups;
-    if (ch > rows / 128) ch = rows / 128;
-    return ch < 1 ? 1 : ch;
-}
-struct gspn_dy_args;
-bool gspn_wgrad_short_go(long rows, int cin, int cout, const gspn_dy_args* a, const float* X, int ldx, const float* in_scale, const float* in_shift,
-                         float* PP, long rpc, long nch, hipStream_t st);
-
+// (r05 also measured a register-streaming pass A for these layers -- a wash against the LDS-DMA streaming kernel: profiles/r05_experiments.txt item 2;
+// the kernel lives in tools/patches/r06_pruned_alternates.patch)
 // mlp_short.hip: forward of a short layer (returns false when the shape is not one it takes: the caller goes on to the general kernels)
 bool gspn_fwd_short_go(long rows, int cin, int cout, const float* X, int ldx, const float* in_scale, const float* in_shift, const float* W, const float* bias,
                        float* Y, int ldy, float* stats, unsigned nparts, PoolOut po, hipStream_t st);

@@ -226,153 +226,8 @@ static void fwd_short_launch(dim3 g, hipStream_t st, int rows, int cin, int cout
 }
 
 
-// ============================================================================================
-// Pass A with known coefficients, short layers:  dW = act(X)^T . dY  over one row chunk per workgroup into the chunk's partial-tile slot
-// (the workspace layout of wgrad_stream_kernel / wgrad_lean_kernel: the reductions that follow do not care which kernel ran).
-// The contraction runs over ROWS, so both MFMA operands are already "k-major" in memory: lane (i = l & 31, slot = l >> 5) of the A operand
-// wants act(X)[row 2s + slot][m0 + i], of the B operand dY[row 2s + slot][n0 + i] -- plain coalesced dword loads (128 contiguous bytes per
-// half-wave), no transposition, no LDS, no barrier in the loop; a lane's column never changes, so its BN constants (scale, shift of the
-// input; scale, -shift, cA, cB, cC of the output) sit in registers.  The four waves of a workgroup take four quarters of the chunk's rows
-// for the same AM x BNW block of 32x32 tiles (every loaded X value feeds BNW MFMAs, every dY value AM) and meet once in LDS, tile by tile,
-// in the fixed order ((w0 + w1) + w2) + w3.  Loads run U k-steps ahead in a register ping-pong.
-// Round-4 form of these layers (wgrad_stream_kernel<1,1,64>): a 64-row LDS-DMA stage is 8 MFMAs per wave behind a barrier -- 17-22 us
-// whatever the shape (profiles/r04_mlp_layer_table.txt).
-// ============================================================================================
-template <int AM, int BNW, bool ACT, bool PK>
-__global__ __launch_bounds__(256) void wgrad_short_kernel(int rows, int cin, int cout, gspn_dy_args a, const float* __restrict__ X, int ldx,
-                                                          const float* __restrict__ in_scale, const float* __restrict__ in_shift, float* __restrict__ PP,
-                                                          int rpc, int nch, int nbm, int nbn, int pool_sh) {
-    constexpr int CM = 32 * AM, CN = 32 * BNW, U = 4;
-    __shared__ float sAcc[4 * 16 * 64];
-    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), l31 = lane & 31, kh = lane >> 5;
-    // block -> (chunk, output block): the blocks of one chunk are adjacent in launch order AND on the same XCD (id % 8), as in wgrad_lean_kernel
-    const int nblk = nbm * nbn;
-    const int bid = blockIdx.x, rest = bid >> 3;
-    const int blk = rest % nblk;
-    const int chunk = (rest / nblk) * 8 + (bid & 7);
-    if (chunk >= nch) return;
-    const int m0 = (blk % nbm) * CM, n0 = (blk / nbm) * CN;
-    const int r_begin = chunk * rpc;
-    const int cr = min(r_begin + rpc, rows) - r_begin;          // rows of this chunk (a multiple of 32)
-    const int rq = cr >> 2;                                     // rows of this wave (a multiple of 8)
-    const int rb = r_begin + wave * rq + kh;                    // this lane's first row; then every second one
-    const int nb = rq >> 3;                                     // batches of U = 4 k-steps (8 rows)
-    float xs[AM], xh[AM], ysc[BNW], yns[BNW], cA[BNW], cB[BNW], cC[BNW];
-#pragma unroll
-    for (int x = 0; x < AM; ++x) { xs[x] = ACT ? in_scale[m0 + 32 * x + l31] : 1.f; xh[x] = ACT ? in_shift[m0 + 32 * x + l31] : 0.f; }
-#pragma unroll
-    for (int y = 0; y < BNW; ++y) {
-        const int c = n0 + 32 * y + l31;
-        ysc[y] = a.scale[c]; yns[y] = -a.shift[c]; cA[y] = a.cA[c]; cB[y] = a.cB[c]; cC[y] = a.cC[c];
-    }
-    const float* xp = X + (size_t)rb * ldx + m0 + l31;
-    const float* yp = a.Y + (size_t)rb * a.ldy + n0 + l31;
-    const float* zp = PK ? nullptr : a.dZ + (size_t)rb * a.ldz + n0 + l31;
-    float xv[2][U][AM], yv[2][U][BNW], zv[2][U][BNW];
-    int av[2][U][PK ? BNW : 1];
-    auto fetch = [&](int bi, auto buf_) {
-        constexpr int buf = decltype(buf_)::value;
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int dr = (bi * U + u) * 2;                    // row offset from rb
-#pragma unroll
-            for (int x = 0; x < AM; ++x) xv[buf][u][x] = xp[(size_t)dr * ldx + 32 * x];
-#pragma unroll
-            for (int y = 0; y < BNW; ++y) yv[buf][u][y] = yp[(size_t)dr * a.ldy + 32 * y];
-            if constexpr (PK) {
-                const size_t g = (size_t)((rb + dr) >> pool_sh) * cout + n0 + l31;
-#pragma unroll
-                for (int y = 0; y < BNW; ++y) { zv[buf][u][y] = a.dPool[g + 32 * y]; av[buf][u][y] = a.pool_arg[g + 32 * y]; }
-            } else {
-#pragma unroll
-                for (int y = 0; y < BNW; ++y) zv[buf][u][y] = zp[(size_t)dr * a.ldz + 32 * y];
-            }
-        }
-    };
-    f32x16 acc[AM][BNW];
-#pragma unroll
-    for (int x = 0; x < AM; ++x)
-#pragma unroll
-        for (int y = 0; y < BNW; ++y)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
-    auto compute = [&](int bi, auto buf_) {
-        constexpr int buf = decltype(buf_)::value;
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            float ax[AM], by[BNW];
-#pragma unroll
-            for (int x = 0; x < AM; ++x) ax[x] = act1(xv[buf][u][x], ACT, xs[x], xh[x]);
-#pragma unroll
-            for (int y = 0; y < BNW; ++y) {
-                float dz = zv[buf][u][y];
-                if constexpr (PK) dz = av[buf][u][y] == ((rb + (bi * U + u) * 2) & ((1 << pool_sh) - 1)) ? dz : 0.f;
-                const float yy = yv[buf][u][y];
-                const float dyh = yy * ysc[y] > yns[y] ? dz : 0.f;
-                by[y] = __builtin_fmaf(cA[y], dyh, __builtin_fmaf(cB[y], yy, cC[y]));       // the streaming / lean kernels' own form of dY
-            }
-#pragma unroll
-            for (int x = 0; x < AM; ++x)
-#pragma unroll
-                for (int y = 0; y < BNW; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[x], by[y], acc[x][y], 0, 0, 0);
-        }
-    };
-    using B0 = std::integral_constant<int, 0>;
-    using B1 = std::integral_constant<int, 1>;
-    if (nb > 0) fetch(0, B0{});
-    for (int bi = 0; bi < nb; bi += 2) {
-        if (bi + 1 < nb) fetch(bi + 1, B1{});
-        compute(bi, B0{});
-        if (bi + 1 < nb) {
-            if (bi + 2 < nb) fetch(bi + 2, B0{});
-            compute(bi + 1, B1{});
-        }
-    }
-    // the four row quarters meet in LDS, one 32x32 tile at a time; wave q finishes accumulator registers 4q..4q+3 (rows 8q + j + 4 kh)
-    float* P1 = PP + (size_t)chunk * 2 * cin * cout;
-#pragma unroll
-    for (int x = 0; x < AM; ++x)
-#pragma unroll
-        for (int y = 0; y < BNW; ++y) {
-            if (x + y > 0) __syncthreads();
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sAcc[(wave * 16 + r) * 64 + lane] = acc[x][y][r];
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float* q = sAcc + (4 * wave + j) * 64 + lane;
-                const float v = ((q[0] + q[16 * 64]) + q[2 * 16 * 64]) + q[3 * 16 * 64];
-                P1[(size_t)(m0 + 32 * x + 8 * wave + j + 4 * kh) * cout + n0 + 32 * y + l31] = v;
-            }
-        }
-}
-
 }  // namespace gspn_k
 using namespace gspn_k;
-
-// launcher for wgrad_impl (mlp.hip): false when the shape is not one the kernel takes.  rpc / nch: the plan's chunking (wgrad_plan, short form)
-bool gspn_wgrad_short_go(long rows, int cin, int cout, const gspn_dy_args* a, const float* X, int ldx, const float* in_scale, const float* in_shift,
-                         float* PP, long rpc, long nch, hipStream_t st) {
-    if (!gspn_wgrad_short_shape(rows, cin, cout) || (rpc & 31)) return false;      // (GSPN_WGRAD_SHORT=1: off by default, see mlp_common.h)
-    const bool pooled = a->dZ == nullptr;
-    int pool_sh = 0;
-    if (pooled) {
-        if (a->ns < 2 || (a->ns & (a->ns - 1)) || rows % a->ns) return false;
-        pool_sh = __builtin_ctz(a->ns);
-    }
-    const long ldmax = std::max(std::max((long)ldx, (long)a->ldy), (long)(pooled ? 0 : a->ldz));
-    if (rows * ldmax >= (1L << 40)) return false;
-    const int nbm = cin / 64, nbn = cout / 64;
-    const dim3 g((unsigned)((nch + 7) / 8 * 8 * nbm * nbn));
-    const bool act = in_scale != nullptr;
-#define WSH_GO(A_, P_) hipLaunchKernelGGL((wgrad_short_kernel<2, 2, A_, P_>), g, dim3(256), 0, st, (int)rows, cin, cout, *a, X, ldx, in_scale, in_shift, PP, \
-                                          (int)rpc, (int)nch, nbm, nbn, pool_sh)
-    if (act) { if (pooled) WSH_GO(true, true); else WSH_GO(true, false); }
-    else     { if (pooled) WSH_GO(false, true); else WSH_GO(false, false); }
-#undef WSH_GO
-    return true;
-}
-
 
 // Tile shape per layer shape: enough workgroups to give every SIMD several waves (>= ~4 x 224 CUs), MFMA tiles per k step as large as that
 // allows (an A value feeds NT MFMAs, a B vector MT).  GSPN_FWD_SHORT_MT / _NT force a shape (tools/short_sweep.py), GSPN_FWD_SHORT=0 turns

@@ -734,13 +734,7 @@ static int gspn_fps_cells_strided(int b, int n, int m, int csz, const float* sxy
     if (csz <= 64 * 8) return launch_fps_cell<8, false>(b, n, m, csz, sxyz, perm, inp0, stride0, out, st);
     if (csz <= 64 * 16) return launch_fps_cell<16, false>(b, n, m, csz, sxyz, perm, inp0, stride0, out, st);
     if (csz <= 64 * 32) {
-        // r05: GSPN_FPS_STRIPE=1 takes the variant with every cell striped over all 16 waves (sampling_stripe.hip) -- identical indices, built
-        // to balance the apply segment as DESIGN 4.1 proposed, measured SLOWER (8 x 32768 -> 2048 incl. pre-pass: U 1845 -> 3015 us, S 2031 -> 3091,
-        // D 2040 -> 3191; tools/r05_fps_stripe.sh) and therefore opt-in: packed-fp32 / min / max issue at ~4.1 cycles per SIMD whichever wave
-        // they come from, so one busy wave already keeps its SIMD ~80 % busy -- spreading a cell over the four waves of every SIMD buys no
-        // issue slots, and every refresh becomes 16 wave reductions + a barrier instead of one wave's.
-        static const int stripe = getenv("GSPN_FPS_STRIPE") ? atoi(getenv("GSPN_FPS_STRIPE")) : 0;
-        if (stripe && csz > 64 * 16) return gspn_fps_stripe_launch(b, n, m, csz, sxyz, perm, inp0, stride0, out, st);
+        // (r05 measured the alternative -- every cell striped over all 16 waves -- 1.6x slower: tools/patches/r06_pruned_alternates.patch, profiles/r05_experiments.txt item 3)
         return launch_fps_cell<32, true>(b, n, m, csz, sxyz, perm, inp0, stride0, out, st);
     }
     return GSPN_ERR_UNSUPPORTED;

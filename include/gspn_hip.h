@@ -37,7 +37,7 @@ extern "C" {
  *   6: round 3 (gspn_fps_cells_prepass_order, gspn_bn_colsum / gspn_bn_apply_grad of tf_util's stand-alone batch norm).
  *   8: round 4 (gspn_pool32_select_groups).
  *   7: round 4 (gspn_nmdistance_grad_csr, gspn_bn_finalize_parts_pivot, gspn_mlp_bwd_fused_coef, gspn_dot, gspn_queryballpoint_ws; gspn_queryballpoint now launches a prefix scan + a continuation kernel -- same output). */
-#define GSPN_ABI_VERSION 8
+#define GSPN_ABI_VERSION 9
 int gspn_dist_policy(void);
 int gspn_abi_version(void);
 
@@ -111,11 +111,6 @@ int gspn_queryballpoint(int b, int n, int m, float radius, int nsample, const fl
 long gspn_ball_ws_bytes(int b, int n, int m);
 int gspn_queryballpoint_ws(int b, int n, int m, float radius, int nsample, const float* xyz1, const float* xyz2, void* ws,
                            int* idx, int* pts_cnt, void* stream);
-/* Same output through LDS-staged point tiles shared by the 8 queries of a workgroup (the shape BASELINE.json's north_star sketches).
- * A measured alternative, not what the Python surface calls: with the reference's early exit the queries of a workgroup need very
- * different prefixes of the cloud, and the scene is L2-resident anyway (DESIGN.md 4.2 has the numbers). */
-int gspn_queryballpoint_lds(int b, int n, int m, float radius, int nsample, const float* xyz1, const float* xyz2,
-                            int* idx, int* pts_cnt, void* stream);
 
 /* Host helper (no GPU work): the squared-distance threshold T the ball-query kernel compares against,
  * i.e. the smallest float with sqrtf(T) >= radius, so that  s < T  <=>  max(sqrtf(s),1e-20f) < radius
@@ -191,6 +186,29 @@ int gspn_nmdistance_grad(int b, int n, const float* xyz1, int m, const float* xy
 int gspn_nmdistance_grad_csr(int b, int n, const float* xyz1, int m, const float* xyz2, const float* grad_dist1, const int* idx1,
                              const float* grad_dist2, const int* idx2, const int* order1, const int* offsets1, const int* order2,
                              const int* offsets2, float* grad_xyz1, float* grad_xyz2, void* stream);
+
+/* ---------------- the four gradient launchers again, WITH a workspace (ABI 9) ----------------
+ * The reference's gradient launchers are scatter-adds whose signatures have no slot for scratch memory, so the symbols above that keep those
+ * signatures exactly can only scatter with hardware atomics (unordered sums, every gradient row read through an atomic).  The same launchers with
+ * ONE more argument before the stream -- `void* ws`, gspn_<op>_ws_bytes(...) bytes, 16-byte aligned (an OpKernel's allocate_temp) -- build the
+ * inverse lists of the index tensor in ws (gspn_inverse_lists) and GATHER: every gradient row is read once, sums are formed in a fixed order
+ * (ascending position of the flattened index tensor), no atomics, no memset.  Both steps run on the caller's stream; nothing is cached.
+ *   gspn_threeinterpolate_grad_ws : bit-identical to the reference's sequential loop (tf_interpolate.cpp:131-153) as compiled by g++
+ *   gspn_nmdistance_grad_ws       : terms in the order of the sequential CPU twin (tf_nndistance.cpp:126-163), any cloud size
+ *   gspn_grouppoint_grad_ws, gspn_scatteraddpoint_ws : one fixed order where the reference (atomicAdd, tf_grouping_g.cu:66-83,
+ *       tf_sampling_g.cu:183-192) defines none.  Rows narrower than 16 floats (coordinates, colours) are FASTER through the atomic symbols;
+ *       these are for callers that need run-to-run identical bits.
+ * Measured against the plain symbols: profiles/r06_dropin_ws.txt; INTEGRATION.md section B shows the OpKernel side. */
+long gspn_grouppoint_grad_ws_bytes(int b, int n, int c, int m, int nsample);
+int gspn_grouppoint_grad_ws(int b, int n, int c, int m, int nsample, const float* grad_out, const int* idx, float* grad_points, void* ws, void* stream);
+long gspn_scatteraddpoint_ws_bytes(int b, int n, int m);
+int gspn_scatteraddpoint_ws(int b, int n, int m, const float* out_g, const int* idx, float* inp_g, void* ws, void* stream);
+long gspn_threeinterpolate_grad_ws_bytes(int b, int n, int c, int m);
+int gspn_threeinterpolate_grad_ws(int b, int n, int c, int m, const float* grad_out, const int* idx, const float* weight, float* grad_points, void* ws,
+                                  void* stream);
+long gspn_nmdistance_grad_ws_bytes(int b, int n, int m);
+int gspn_nmdistance_grad_ws(int b, int n, const float* xyz1, int m, const float* xyz2, const float* grad_dist1, const int* idx1, const float* grad_dist2,
+                            const int* idx2, float* grad_xyz1, float* grad_xyz2, void* ws, void* stream);
 
 /* ---------------- utils/pointnet_util.py composition helpers --------------------------- */
 

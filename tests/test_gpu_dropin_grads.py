@@ -182,3 +182,102 @@ def test_groupmaxpool_grad_symbol():
     ref = O.group_maxpool_grad(pts, mi, go)
     scale = O.group_maxpool_grad(pts, mi, np.abs(go)).astype(np.float64)
     close(g.cpu().numpy(), ref, scale)
+
+
+# ---- ABI 9: the same launchers with a workspace -- fixed-order gathers through inverse lists built inside the call (csrc/dropin_ws.hip) -------------------
+def _ws(nbytes):
+    assert nbytes >= 0
+    return torch.randint(0, 255, (max(int(nbytes), 16),), dtype=torch.uint8, device="cuda")       # garbage: the call must not rely on its content
+
+
+@pytest.mark.parametrize("b,n,c,m,ns", [(2, 500, 3, 128, 32), (3, 2048, 64, 256, 32), (1, 64, 131, 40, 16), (2, 4096, 6, 512, 64), (8, 2048, 128, 512, 32)])
+def test_grouppoint_grad_ws_symbol_is_the_sequential_loop_bit_for_bit(b, n, c, m, ns):
+    """groupPointGradLauncher's arguments + `void* ws`: sums in ascending grouped position = the oracle's sequential loop, exactly, on contended indices"""
+    from gspn_amd import _lib as L
+    lib = L.lib()
+    rng = np.random.default_rng(b * 1000 + c)
+    idx = contended_group_idx(rng, b, n, m, ns) if b * m < 3000 else rng.integers(0, n, size=(b, m, ns)).astype(np.int32)
+    go = rng.standard_normal((b, m, ns, c)).astype(np.float32)
+    ref = O.group_point_grad(np.zeros((b, n, c), np.float32), idx, go)
+    tgo, tidx = dev(go), dev(idx)
+    for _ in range(2):
+        g, ws = garbage(b, n, c), _ws(lib.gspn_grouppoint_grad_ws_bytes(b, n, c, m, ns))
+        assert lib.gspn_grouppoint_grad_ws(b, n, c, m, ns, _p(tgo), _p(tidx), _p(g), _p(ws), _st()) == 0
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(g.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("b,n,m", [(2, 300, 1000), (8, 32768, 2048), (1, 5, 64)])
+def test_scatteraddpoint_ws_symbol_is_the_sequential_loop_bit_for_bit(b, n, m):
+    from gspn_amd import _lib as L
+    lib = L.lib()
+    rng = np.random.default_rng(n)
+    idx = rng.integers(0, n, size=(b, m)).astype(np.int32)
+    idx[:, : m // 4] = idx[:, :1]
+    og = rng.standard_normal((b, m, 3)).astype(np.float32)
+    g, ws = garbage(b, n, 3), _ws(lib.gspn_scatteraddpoint_ws_bytes(b, n, m))
+    assert lib.gspn_scatteraddpoint_ws(b, n, m, _p(dev(og)), _p(dev(idx)), _p(g), _p(ws), _st()) == 0
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(g.cpu().numpy(), O.gather_point_grad(np.zeros((b, n, 3), np.float32), idx, og))
+
+
+@pytest.mark.parametrize("b,n,c,m", [(2, 512, 64, 128), (1, 128, 16, 8), (3, 4096, 37, 50), (2, 2048, 256, 512), (8, 32768, 64, 2048)])
+def test_threeinterpolate_grad_ws_symbol_is_the_reference_loop_bit_for_bit(b, n, c, m):
+    """threeinterpolate_grad_cpu's arguments + `void* ws`: bit-identical to the reference's OWN compiled loop (g++ -O2 on interpolate.cpp, tf_interpolate.cpp:131-153)
+    where oracle/_ref has it, and to the restatement -- incl. the dense feature-propagation level 8 x 32768 -> 2048 at c = 64"""
+    from gspn_amd import _lib as L
+    lib = L.lib()
+    rng = np.random.default_rng(c)
+    idx = rng.integers(0, m, size=(b, n, 3)).astype(np.int32)
+    idx[:, ::7, :] = idx[:, :1, :1]
+    w = rng.random((b, n, 3)).astype(np.float32)
+    w /= w.sum(2, keepdims=True)
+    go = rng.standard_normal((b, n, c)).astype(np.float32)
+    g, ws = garbage(b, m, c), _ws(lib.gspn_threeinterpolate_grad_ws_bytes(b, n, c, m))
+    assert lib.gspn_threeinterpolate_grad_ws(b, n, c, m, _p(dev(go)), _p(dev(idx)), _p(dev(w)), _p(g), _p(ws), _st()) == 0
+    torch.cuda.synchronize()
+    got = g.cpu().numpy()
+    pts = np.zeros((b, m, c), np.float32)
+    np.testing.assert_array_equal(got, O.three_interpolate_grad(pts, idx, w, go))
+    if O.ref_lib() is not None:
+        np.testing.assert_array_equal(got, O.ref_three_interpolate_grad(pts, idx, w, go))
+
+
+@pytest.mark.parametrize("b,n,m", [(4, 512, 512), (2, 16384, 1024), (3, 100, 7)])
+def test_nmdistance_grad_ws_symbol_is_the_cpu_twin_s_order_bit_for_bit(b, n, m):
+    """NmDistanceGradKernelLauncher's arguments + `void* ws`: == gspn_nmdistance_grad_csr on lists built by the caller (what the op API runs beyond the LDS size,
+    bit-exact against the sequential CPU twin tf_nndistance.cpp:126-163), and within 1e-5 of the oracle's loop"""
+    from gspn_amd import _lib as L
+    from gspn_amd.invlists import inverse_lists
+    lib = L.lib()
+    rng = np.random.default_rng(m)
+    a = rng.standard_normal((b, n, 3)).astype(np.float32)
+    c = rng.standard_normal((b, m, 3)).astype(np.float32)
+    d1, i1, d2, i2 = O.nn_distance(a, c)
+    g1 = rng.standard_normal((b, n)).astype(np.float32)
+    g2 = rng.standard_normal((b, m)).astype(np.float32)
+    ta, tc, tg1, tg2, ti1, ti2 = dev(a), dev(c), dev(g1), dev(g2), dev(i1), dev(i2)
+    ga, gc, ws = garbage(b, n, 3), garbage(b, m, 3), _ws(lib.gspn_nmdistance_grad_ws_bytes(b, n, m))
+    assert lib.gspn_nmdistance_grad_ws(b, n, _p(ta), m, _p(tc), _p(tg1), _p(ti1), _p(tg2), _p(ti2), _p(ga), _p(gc), _p(ws), _st()) == 0
+    o1, f1 = inverse_lists(ti1, m)
+    o2, f2 = inverse_lists(ti2, n)
+    ha, hc = garbage(b, n, 3), garbage(b, m, 3)
+    assert lib.gspn_nmdistance_grad_csr(b, n, _p(ta), m, _p(tc), _p(tg1), _p(ti1), _p(tg2), _p(ti2), _p(o1), _p(f1), _p(o2), _p(f2), _p(ha), _p(hc), _st()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(ga, ha) and torch.equal(gc, hc)
+    r1, r2 = O.nn_distance_grad(a, c, g1, i1, g2, i2)
+    np.testing.assert_allclose(ga.cpu().numpy(), r1, rtol=1e-5, atol=1e-5 * float(np.abs(r1).max()))
+    np.testing.assert_allclose(gc.cpu().numpy(), r2, rtol=1e-5, atol=1e-5 * float(np.abs(r2).max()))
+
+
+def test_ws_symbols_reject_what_the_reference_ops_reject_and_size_their_workspace():
+    from gspn_amd import _lib as L
+    lib = L.lib()
+    assert lib.gspn_grouppoint_grad_ws_bytes(8, 2048, 64, 512, 32) == 4 * (8 * 512 * 32 + (8 * 2049 + 15) // 16 * 16 + (int(lib.gspn_inverse_lists_work_ints(8, 512 * 32, 2048)) + 15) // 16 * 16)
+    assert lib.gspn_grouppoint_grad_ws_bytes(1, 0, 3, 4, 4) == -1 and lib.gspn_threeinterpolate_grad_ws_bytes(1, 4, 3, 0) == -1 and lib.gspn_nmdistance_grad_ws_bytes(1, 0, 4) == -1
+    g = garbage(2, 10, 4)
+    assert lib.gspn_grouppoint_grad_ws(2, 10, 4, 5, 3, None, None, _p(g), None, _st()) == -1            # null pointers
+    assert lib.gspn_grouppoint_grad_ws(2, 10, 4, 0, 3, None, None, _p(g), None, _st()) == 0             # nothing grouped: zero gradient
+    torch.cuda.synchronize()
+    assert float(g.abs().max()) == 0.0
+    assert lib.gspn_grouppoint_grad_ws(0, 10, 4, 5, 3, None, None, None, None, _st()) == 0

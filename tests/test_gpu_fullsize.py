@@ -479,25 +479,3 @@ def test_ball_query_cell_grid_path_equals_the_reference_scan(radius, nsample):
     hit = rcnt > 0                                          # (rows without a hit are zero-filled here, uninitialised in the reference)
     np.testing.assert_array_equal(got[hit], ridx[hit])
     assert (got[~hit] == 0).all()
-
-
-def test_striped_fps_variant_is_index_exact_in_a_child_process():
-    """GSPN_FPS_STRIPE=1 (csrc/sampling_stripe.hip: every cell striped over the 16 waves -- the partition VERDICT r04 item 5 asked for; slower, opt-in):
-    the same indices as the oracle on U / S / D and on a lattice with ties everywhere, 16385 < n <= 32768.  The switch is read once: child process."""
-    import subprocess
-    import sys
-    code = r'''
-import sys, numpy as np, torch
-sys.path.insert(0, %r)
-from oracle import oracle as O
-from tests import data as D
-from gspn_amd.tf_sampling import farthest_point_sample
-for kind, b, n, m in (("U", 3, 32768, 1024), ("S", 2, 32768, 700), ("D", 2, 20000, 900), ("L", 2, 17000, 600)):
-    xyz = np.random.default_rng(5).integers(0, 9, size=(b, n, 3)).astype(np.float32) if kind == "L" else D.batch(kind, b, n, 7)
-    got = farthest_point_sample(m, torch.from_numpy(xyz).cuda()).cpu().numpy()
-    assert (got == O.farthest_point_sample(m, xyz, mt=True)).all(), kind
-print("STRIPE_OK")
-''' % ROOT
-    env = dict(os.environ, GSPN_FPS_STRIPE="1")
-    r = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
-    assert r.returncode == 0 and "STRIPE_OK" in r.stdout, r.stderr[-2000:]

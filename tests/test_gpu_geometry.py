@@ -461,21 +461,6 @@ def test_knn_dense_fallback_and_validation():
         knn_point(0, dev(x1), dev(x2))
 
 
-@pytest.mark.parametrize("kind,b,n,m,r,ns", [("U", 2, 8192, 300, 0.1, 32), ("D", 2, 4096, 77, 0.2, 64), ("U", 1, 1000, 9, 2.0, 512), ("S", 1, 6000, 256, 0.4, 32)])
-def test_ball_query_lds_variant_is_identical(kind, b, n, m, r, ns):
-    """gspn_queryballpoint_lds (LDS-staged point tiles shared by a workgroup: the measured alternative of DESIGN 4.2) == the default kernel == oracle"""
-    from gspn_amd import _lib as L
-    xyz = D.batch(kind, b, n)
-    q = O.gather_point(xyz, O.farthest_point_sample(m, xyz))
-    ridx, rcnt = O.query_ball_point(r, ns, xyz, q)
-    tx, tq = dev(xyz), dev(q)
-    idx = torch.empty(b, m, ns, dtype=torch.int32, device="cuda")
-    cnt = torch.empty(b, m, dtype=torch.int32, device="cuda")
-    L.check(L.lib().gspn_queryballpoint_lds(b, n, m, r, ns, L.ptr(tx), L.ptr(tq), L.ptr(idx), L.ptr(cnt), L.stream()), "ball lds")
-    np.testing.assert_array_equal(cnt.cpu().numpy(), rcnt)
-    np.testing.assert_array_equal(idx.cpu().numpy(), ridx)
-
-
 def test_knn_direct_random_shapes():
     """seeded sweep of knn_point (direct kernel) over sizes, k and tie-heavy lattices against the oracle's dense construction"""
     from gspn_amd.tf_grouping import knn_point

@@ -1,6 +1,6 @@
 """The split-K kernels of the short layers (csrc/mlp_short.hip, r05): the forward of layers with <= 8192 rows (default path) against an fp64
 product -- outputs, the per-workgroup partial column sums the batch norm is finalised from, the 32-row pool epilogue (maximum AND the first
-row that reaches it) -- and the opt-in pass-A kernel (GSPN_WGRAD_SHORT=1, a child process: the switch is read once).
+row that reaches it).
 utils/pointnet_util.py:109-113,165-169 (the FP1 / SA3 shapes of models/model_rpointnet.py:226-230)."""
 import ctypes
 import os
@@ -80,14 +80,3 @@ def test_short_forward_is_deterministic():
         outs.append((Y, stats))
     torch.cuda.synchronize()
     assert all(torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1]) for o in outs[1:])
-
-
-def test_opt_in_short_wgrad_against_fp64_in_a_child_process():
-    env = dict(os.environ, GSPN_WGRAD_SHORT="1")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "short_bench.py"), "wgrad"], env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                       text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
-    rows = [l.split() for l in r.stdout.splitlines() if "^T" in l and "(+dW" in l]
-    assert len(rows) >= 7
-    for l in rows:
-        assert float(l[-1]) < 1e-5, l

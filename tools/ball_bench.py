@@ -16,7 +16,7 @@ for kind in kinds:
         q = gather_point(cur, farthest_point_sample(m, cur))
         out = []
         ws = torch.empty(int(lib.gspn_ball_ws_bytes(8, n, m)), dtype=torch.uint8, device="cuda")
-        for name, fn in (("scan (prefix + continuation)", lib.gspn_queryballpoint), ("lds-tile", lib.gspn_queryballpoint_lds), ("cell grid + scan", None)):
+        for name, fn in (("scan (prefix + continuation)", lib.gspn_queryballpoint), ("cell grid + scan", None)):
             idx = torch.empty(8, m, ns, dtype=torch.int32, device="cuda"); cnt = torch.empty(8, m, dtype=torch.int32, device="cuda")
             if fn is None:
                 run = lambda: L.check(lib.gspn_queryballpoint_ws(8, n, m, r, ns, L.ptr(cur), L.ptr(q), L.ptr(ws), L.ptr(idx), L.ptr(cnt), L.stream()), name)
