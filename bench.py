@@ -476,7 +476,7 @@ def main():
     fps_avg_ms = float(np.mean(fps_ms)) if fps_ms else float("nan")
     achieved = alg_bytes / (fps_avg_ms * 1e-3) / 1e9
     traffic = None
-    pmc = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r05_fps_pmc.json", "r04_fps_pmc.json", "r03_fps_pmc.json", "r02_fps_pmc.json", "r01_fps_pmc.json")) if os.path.exists(q)), None)
+    pmc = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r06_fps_pmc.json", "r05_fps_pmc.json", "r04_fps_pmc.json", "r03_fps_pmc.json", "r02_fps_pmc.json", "r01_fps_pmc.json")) if os.path.exists(q)), None)
     traffic_src = ("profiles/" + os.path.basename(pmc)) if pmc else None
     if pmc:
         try:
@@ -536,6 +536,7 @@ def main():
                        "schedule": "geometry inline" if args.no_overlap else (("geometry of batches k+2, k+3 submitted together every other step on two side streams under the layers of batches k, k+1"
                                                                                 if PAIRED else "geometry of batches k+1, k+2 on two side streams under the layers of batch k")
                                                                                + ("; fwd+bwd replayed from a hipGraph" if use_graph else "")),
+                       "geometry_pair_phase": PHASE if (PAIRED and geo is not None) else None,      # pairs are submitted by the steps i with i % 2 == phase (the run's last step submits none)
                        "global_batch": global_batch, "npoints": NPOINTS, "parallelism": "dp%d (scenes sharded, one flat RCCL grad all-reduce)%s" % (world, "; SyncBN" if args.sync_bn else "")},
             # SURVEY 8(d)'s yardstick: `achieved` = ALGORITHMIC bytes (what the reference's kernel moves: 20 B per point per round) / time.
             # It is an effective rate, not measured bandwidth: the kernel keeps the scene on chip, `traffic` (PMC) is what really
@@ -554,6 +555,8 @@ def main():
             "host_replay_ms_per_step": state.get("t_replay", 0.0) / (args.steps + args.warmup) * 1e3,
         }
         if coll is not None:
+            if world > 1:
+                coll.update(n1_reference(res["value"], world))
             res["collective"] = coll
         _stdout_discipline(rank)                                    # whatever the C side buffered so far comes out BEFORE the line
         if world == 1 and not args.no_cpu_baseline and not args.kind_leg:
@@ -588,14 +591,30 @@ def main():
         dist.destroy_process_group()
 
 
+def n1_reference(value, world):
+    """whole-job value of this N-GPU run against the newest KEPT one-GPU line under profiles/ (weak scaling: efficiency = value / (N * value_1))"""
+    for f in ("r06_bench_line.json", "r05_bench_line.json", "r04_bench_line.json"):
+        q = os.path.join(ROOT, "profiles", f)
+        try:
+            v1 = float(json.load(open(q))["value"])
+            return {"n1_value": v1, "n1_source": "profiles/" + f + " (a kept line of another run and box)", "scaling_efficiency_vs_n1": value / (world * v1)}
+        except Exception:
+            continue
+    return {"n1_value": None, "n1_source": None, "scaling_efficiency_vs_n1": None}
+
+
 METRIC = "scenes/sec fwd+bwd set-abstraction, 32768 pts, 1/2/4/8 MI355X"
 DETAIL_FILE = "bench_detail.json"
 # the keys of the stdout line (VERDICT r04 item 1): everything else lives in bench_detail.json
 LINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "median_ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-             "dtype", "data", "config", "roofline", "cpu_baseline", "detail_file")
-CONFIG_KEYS = ("workload", "scenes_per_gpu", "global_batch", "npoints", "parallelism", "schedule")
-ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms", "launches_timed",
+             "dtype", "data", "config", "roofline", "cpu_baseline", "collective", "detail_file")
+CONFIG_KEYS = ("workload", "scenes_per_gpu", "global_batch", "npoints", "parallelism", "schedule", "geometry_pair_phase")
+# traffic is a KEPT counter figure (a --pmc pass cannot run inside the timed command): traffic_source names the file it was read from
+ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "algorithmic_bytes_per_launch", "avg_launch_ms", "launches_timed",
                  "concurrent_launches")
+# N > 1 only (null at N = 1): what the gradient all-reduce costs inside a step and the whole-job value against a KEPT one-GPU line (n1_source) --
+# so that the first multi-GPU record explains itself; the driver computes its own efficiency from its own N = 1 run
+COLLECTIVE_KEYS = ("allreduce_ms_in_step", "ms_per_step_without_collective", "bucket_bytes", "n1_value", "n1_source", "scaling_efficiency_vs_n1")
 CPU_KEYS = ("value", "unit", "cores", "kind", "sample", "all_cores")
 LINE_LIMIT = 4096
 
@@ -632,6 +651,9 @@ def compact_line(res):
                 a = c.get("all_cores")
                 o["all_cores"] = None if not a else {"value": _num(a.get("value")), "cores": a.get("cores")}
                 out[k] = o
+        elif k == "collective":
+            c = res.get("collective") if (res.get("n_gpus") or 1) > 1 else None
+            out[k] = None if not c else {q: _short(_num(c.get(q)), 120) for q in COLLECTIVE_KEYS}
         elif k == "detail_file":
             out[k] = DETAIL_FILE
         else:

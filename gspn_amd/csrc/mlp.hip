@@ -805,6 +805,10 @@ static inline int pick_bn(long rows, int cols, const char* env) {
 // (workgroups per CU = what the kernel's LDS footprint lets reside at once: a persistent grid larger than that runs a second wave)
 static inline int bwd_bpc_narrow() { static const int v = env_int("GSPN_BWD_BPC", 4); return v < 1 ? 1 : v; }
 static inline bool fwd_short_rows(long rows) { static const int on = env_int("GSPN_FWD_SHORT", 1); return on && rows >= 64 && rows <= GSPN_SHORT_ROWS && !(rows & 63); }
+// (the count depends on (rows, cout) only -- it sizes a caller-allocated buffer through gspn_mlp_fwd_stats_bytes, which has no cin / pointer
+//  arguments -- so a layer of <= 8192 rows that the split-K kernel then DECLINES (cin not one of its instances, an unaligned operand, a gathered source)
+//  still gets one partial row per 32 rows: the 128-row-tile kernels below are launched with up to 4x more workgroups than tiles; the extra ones write their
+//  zero statistics row and leave.  Correct, and bounded at 256 workgroups of a few hundred cycles on layers of <= 8192 rows.)
 static inline unsigned fwd_blocks(long rows, int cout) {
     if (fwd_short_rows(rows)) return (unsigned)short_fwd_parts(rows);      // short layers (mlp_short.hip): one partial row per 32-row tile, at most 512
     return row_grid(rows, cout <= 64 ? 1 : (cout + 127) / 128, cout <= 64 ? 4 : env_int("GSPN_FWD_WIDE_BPC", 3));
@@ -1187,7 +1191,7 @@ static int mlp_fwd_impl(long rows, int cin, int cout, const float* X, int ldx, c
     hipStream_t st = (hipStream_t)stream;
     {
         if (!gsrc && (!po.vmax || !(rows & 31)) && fwd_split_go(rows, cin, cout, X, ldx, in_scale, in_shift, W, bias, Y, ldy, stats, po, st)) return gspn_launch_status();
-        // short layers (<= 32768 rows): split-K over the waves of a workgroup, operands straight from global memory (mlp_short.hip, r05)
+        // short layers (<= GSPN_SHORT_ROWS = 8192 rows): split-K over the waves of a workgroup, operands straight from global memory (mlp_short.hip, r05)
         if (!gsrc && fwd_short_rows(rows) && gspn_fwd_short_go(rows, cin, cout, X, ldx, in_scale, in_shift, W, bias, Y, ldy, stats, fwd_blocks(rows, cout), po, st))
             return gspn_launch_status();
         static const int lean_on = env_int("GSPN_FWD_LEAN", 1);             // (A/B hook)

@@ -211,20 +211,27 @@ __global__ __launch_bounds__(256) void fwd_short_kernel(int rows, int cin, int c
     }
 }
 
+// false: the instance could not be configured on this device (the attribute call failed) -- nothing was launched, the caller goes on to the general kernels
 template <int KW, int MT, int NT, bool ACT, bool POOL>
-static void fwd_short_launch(dim3 g, hipStream_t st, int rows, int cin, int cout, const float* X, int ldx, const float* in_scale, const float* in_shift,
+static bool fwd_short_launch(dim3 g, hipStream_t st, int rows, int cin, int cout, const float* X, int ldx, const float* in_scale, const float* in_shift,
                              const float* W, const float* bias, float* Y, int ldy, float* stats, PoolOut po) {
     constexpr size_t dyn = sizeof(float) * (4 * MT * NT * 16 * 64 + 32 * MT * (4 * KW + 4) + 2 * 4 * KW);
     if constexpr (dyn > 48 * 1024) {
-        static bool done = false;
-        if (!done) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_short_kernel<KW, MT, NT, ACT, POOL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-            done = true;
+        // the attribute belongs to (function, DEVICE): one flag per device, not per process; a failure is reported, not swallowed
+        static bool done[64] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) dev = -1;
+        if (dev < 0 || dev >= 64 || !done[dev]) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_short_kernel<KW, MT, NT, ACT, POOL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) {
+                (void)hipGetLastError();
+                return false;
+            }
+            if (dev >= 0 && dev < 64) done[dev] = true;
         }
     }
     hipLaunchKernelGGL((fwd_short_kernel<KW, MT, NT, ACT, POOL>), g, dim3(256), dyn, st, rows, cin, cout, X, ldx, in_scale, in_shift, W, bias, Y, ldy, stats, po);
+    return true;
 }
-
 
 }  // namespace gspn_k
 using namespace gspn_k;
@@ -255,7 +262,8 @@ bool gspn_fwd_short_go(long rows, int cin, int cout, const float* X, int ldx, co
     if (mt == 2 && kw > 48) mt = 1;                                        // the staged A tile: 32 MT x (K + 4) floats of LDS
     const dim3 g(nparts, cout / (32 * nt));
     const int irows = (int)rows;
-#define FS_GO(KW_, MT_, NT_, A_, P_) fwd_short_launch<KW_, MT_, NT_, A_, P_>(g, st, irows, cin, cout, X, ldx, in_scale, in_shift, W, bias, Y, ldy, stats, po)
+    bool ok = true;
+#define FS_GO(KW_, MT_, NT_, A_, P_) ok = fwd_short_launch<KW_, MT_, NT_, A_, P_>(g, st, irows, cin, cout, X, ldx, in_scale, in_shift, W, bias, Y, ldy, stats, po)
 #define FS_P(KW_, MT_, NT_, A_) do { if (po.vmax) FS_GO(KW_, MT_, NT_, A_, true); else FS_GO(KW_, MT_, NT_, A_, false); } while (0)
 #define FS_A(KW_, MT_, NT_) do { if (in_scale) FS_P(KW_, MT_, NT_, true); else FS_P(KW_, MT_, NT_, false); } while (0)
 #define FS_T2(KW_) do { if (nt == 1) FS_A(KW_, 1, 1); else FS_A(KW_, 1, 2); } while (0)
@@ -274,5 +282,5 @@ bool gspn_fwd_short_go(long rows, int cin, int cout, const float* X, int ldx, co
 #undef FS_A
 #undef FS_P
 #undef FS_GO
-    return true;
+    return ok;
 }

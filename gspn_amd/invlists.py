@@ -80,7 +80,9 @@ def cached_inverse_lists(idx, n):
         hit = cache.get(n)
         if hit is not None and hit[0] == key and hit[1].device == idx.device:
             if hit[3] is not None and hit[4] != cur.cuda_stream:
-                cur.wait_event(hit[3])                       # built on another stream: order this stream after the build
+                cur.wait_event(hit[3])                       # built on another stream: order this stream after the build ...
+                hit[1].record_stream(cur)                    # ... and tell the caching allocator that THIS stream reads both tensors: an entry dropped
+                hit[2].record_stream(cur)                    # (invalidate / generation / key change) while the gather still runs must not be reused under it
             return hit[1], hit[2]
     order, offsets = inverse_lists(idx.reshape(idx.shape[0], -1), n)
     if cache is None:
@@ -91,6 +93,5 @@ def cached_inverse_lists(idx, n):
             return order, offsets
     ev = torch.cuda.Event()
     ev.record(cur)
-    order.record_stream(cur)
     cache[n] = (key, order, offsets, ev, cur.cuda_stream)
     return order, offsets

@@ -212,3 +212,11 @@ def test_bench_line_is_compact_strict_json_with_the_contract_keys():
     # no CPU baseline (N > 1 runs): the key is there, null
     res.pop("cpu_baseline")
     assert bench.compact_line(res)["cpu_baseline"] is None
+    assert back["collective"] is None and "traffic_source" in back["roofline"] and "geometry_pair_phase" in back["config"]
+    # N > 1: the collective's cost inside the step and the value against a kept one-GPU line ride on the line
+    res.update(n_gpus=4, value=4 * 4400.0, collective={"allreduce_ms_in_step": 0.031, "ms_per_step_without_collective": 1.75, "bucket_bytes": 1069056, "note": long})
+    res["collective"].update(bench.n1_reference(res["value"], 4))
+    c = bench.compact_line(res)["collective"]
+    assert set(c) == set(bench.COLLECTIVE_KEYS) and c["allreduce_ms_in_step"] == pytest.approx(0.031)
+    if c["n1_value"] is not None:
+        assert c["scaling_efficiency_vs_n1"] == pytest.approx(4 * 4400.0 / (4 * c["n1_value"]), rel=1e-5) and c["n1_source"].startswith("profiles/")

@@ -70,12 +70,14 @@ def test_ball_query_reference_source(kind, radius, ns):
     if kind != "lattice":                                   # r05: equality under the matching contraction instead of an escape clause
         from tests.test_gpu_policy import _variant
         from tests.test_gpu_policy3 import _ball
-        hit = rcnt > 0                                      # rows without a hit are uninitialised in the reference (zeros here and there)
+        # (rows without a hit are uninitialised in the reference, zeros here: compared where the reference counted a hit)
         for policy, nofma in ((3, False), (0, True)):
             i3, c3 = _ball(_variant(policy), dev(xyz), dev(q), radius, ns)
             ri, rc = R.query_ball_point(radius, ns, dev(xyz), dev(q), nofma=nofma)
             assert torch.equal(c3, rc) and torch.equal(i3[rc > 0], ri[rc > 0])
     else:
+        # lattice coordinates are small integers: every squared distance is exactly representable, so every contraction form -- the default policy-2
+        # product included -- gives the same bits.  A later non-integer "lattice" would make this branch fail for a reason that is not a bug.
         assert same and same_nofma
 
 
