@@ -209,6 +209,11 @@ def main():
             geo.append(GeometryStream(dev, priority=GEO_PRIO, beside=[torch.cuda.current_stream()] + [g_.stream for g_ in geo], probes=probes,
                                       agree=agree))
     use_graph = geo is not None and not args.no_graph
+    # r06, OPT-IN (GSPN_BENCH_ADAM_IN_GRAPH=1): where nothing has to run between the backward pass and the optimiser on the host's clock -- one rank without
+    # a forced collective, or the collective captured into the graph -- the Adam launch can be the graph's last node (gspn_adam_flat_dev: its step counter
+    # lives on the device).  Measured SLOWER than the eager launch behind every replay (captured layers 1.509 -> 1.523 ms, full step 1.731 -> 1.750: a graph
+    # that follows a graph directly starts later than one that follows an eager kernel; profiles/r06_experiments.txt item 4), so it stays off.
+    ADAM_IN_GRAPH = use_graph and os.environ.get("GSPN_BENCH_ADAM_IN_GRAPH", "0") == "1" and ((world == 1 and not FORCE_COLL) or COLL_IN_GRAPH)
     pend = {}                   # step index -> PendingGeometry
     done = {}                   # step index -> event after its layers + optimiser step
 
@@ -221,19 +226,22 @@ def main():
         if state["bucket"] is None:
             params = store.parameters()
             state["bucket"] = parallel.FlatGradBucket(params)
-            state["opt"] = parallel.FlatAdam(state["bucket"], lr=1e-3)       # one kernel for the whole update (parameters live in one flat buffer)
+            state["opt"] = parallel.FlatAdam(state["bucket"], lr=1e-3, device_step=ADAM_IN_GRAPH)       # one kernel for the whole update (parameters live in one flat buffer)
+            if os.environ.get("GSPN_BENCH_SINKS", "1") != "0":
+                state["bucket"].attach_sinks()                                   # from the next backward on the gradients are written straight into the bucket (no cat)
         state["bucket"].flatten()
         return loss.detach()          # (a live loss would keep the autograd graph -- and its AccumulateGrad nodes -- alive across captures)
 
     def finish(in_graph=False):
         if not in_graph and not state.get("skip_collective"):
             state["bucket"].all_reduce(average=False, force=FORCE_COLL)    # one flat RCCL all-reduce (SUM; no-op at world 1 unless --force-collective)
-        state["opt"].step(grad_scale=1.0 / world)    # the division by the world size rides in the Adam kernel
+        if not (ADAM_IN_GRAPH and use_graph):
+            state["opt"].step(grad_scale=1.0 / world)    # the division by the world size rides in the Adam kernel
 
     graphs = None
     if use_graph:
         # persistent geometry buffers per batch slot (the captured layers read these; the geometry stream refills them every step)
-        G = [pn2_geometry(batches[k][0]) for k in range(NB)]
+        G = [pn2_geometry(batches[k][0], points=batches[k][1]) for k in range(NB)]
         fwd_bwd(0, G[0])                             # creates the variables, the bucket and the optimiser
         finish()
         graphs = []
@@ -242,6 +250,8 @@ def main():
             r = fwd_bwd(k, G[k])
             if COLL_IN_GRAPH:
                 state["bucket"].all_reduce(average=False, force=FORCE_COLL)      # the collective as the captured step's last node (--collective-in-graph)
+            if ADAM_IN_GRAPH:
+                state["opt"].step(grad_scale=1.0 / world)                        # r06: the optimiser as the graph's last node (its step counter lives on the device)
             return r
         for k in range(NB):
             graphs.append(CapturedStep(lambda k=k: captured(k), pool=graphs[0].pool() if graphs else None))
@@ -264,9 +274,9 @@ def main():
         f0 = first_fps.pop(j, None)
         f0 = f0._value if f0 is not None else None          # (same stream, in order: no wait)
         if use_graph:
-            pend[j] = geo[j % DEPTH].submit(lambda x: copy_into(G[kj], pn2_geometry(x, fps0=f0)), batches[kj][0], after=AFTER)
+            pend[j] = geo[j % DEPTH].submit(lambda x, c: copy_into(G[kj], pn2_geometry(x, fps0=f0, points=c)), batches[kj][0], batches[kj][1], after=AFTER)
         else:
-            pend[j] = geo[j % DEPTH].submit(lambda x: pn2_geometry(x, fps0=f0), batches[kj][0], after=AFTER)
+            pend[j] = geo[j % DEPTH].submit(lambda x, c: pn2_geometry(x, fps0=f0, points=c), batches[kj][0], batches[kj][1], after=AFTER)
 
     # diagnostic only (the line it prints is NOT a benchmark result: the geometry of every step is skipped): layers graph alone
     LAYERS_ONLY = use_graph and os.environ.get("GSPN_BENCH_LAYERS_ONLY") == "1"

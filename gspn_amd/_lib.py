@@ -113,6 +113,7 @@ SIGNATURES = {
     "gspn_multi_copy": [_I, _P, _P, _P, _P],
     "gspn_three_nn_weights": [_L, _P, _P, _P],
     "gspn_adam_flat": [_L, _P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _L, _P],
+    "gspn_adam_flat_dev": [_L, _P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _P, _P],
     "gspn_dot": [_L, _P, _P, _P, _P, _P],
     "gspn_fill_zero": [_P, _L, _P],
 }

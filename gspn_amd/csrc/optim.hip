@@ -32,6 +32,48 @@ extern "C" int gspn_adam_flat(long n, float* p, const float* g, float* m, float*
     return gspn_launch_status();
 }
 
+// The same update with the step number kept ON THE DEVICE (r06): state[0] = number of updates done so far, state[1] = scratch (0 between launches).
+// A launch whose arguments never change can be a node of a captured hipGraph -- the optimiser then replays with the step instead of being enqueued
+// behind it by the host (an ~8 us bubble per step).  Every workgroup reads state[0] when it starts; a workgroup's last act is a ticket on state[1],
+// and the workgroup that draws the last ticket -- necessarily after every other one has read state[0] (its value has been USED by then) -- publishes
+// step + 1 and clears the tickets.  Relaxed device-scope atomics: nothing but these two words is communicated, and an acquire / release at agent scope
+// would write back and invalidate the L2 once per workgroup (measured: +30 us on a 4 us kernel); the next launch sees the words through the kernel boundary.
+// Bias corrections in double on the device (pow of a float base: same values as the host's computation in gspn_adam_flat).
+__global__ void adam_flat_dev_kernel(long n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                     float lr, float b1, float b2, float eps, float weight_decay, float grad_scale, unsigned long long* __restrict__ state) {
+    const unsigned long long step = __atomic_load_n(&state[0], __ATOMIC_RELAXED) + 1ull;
+    const float bc1 = (float)(1.0 - pow((double)b1, (double)step));
+    const float bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, (double)step));
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float gi = g[i] * grad_scale;
+        const float pi = p[i];
+        if (weight_decay != 0.f) gi = fmaf(weight_decay, pi, gi);
+        const float mi = fmaf(1.f - b1, gi - m[i], m[i]);
+        const float vi = fmaf(1.f - b2, gi * gi, b2 * v[i]);
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = pi - (lr / bc1) * (mi / denom);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long ticket = __hip_atomic_fetch_add(&state[1], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ticket == (unsigned long long)gridDim.x - 1ull) {
+            __hip_atomic_store(&state[1], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&state[0], step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+extern "C" int gspn_adam_flat_dev(long n, float* p, const float* g, float* m, float* v, float lr, float b1, float b2, float eps, float weight_decay,
+                                  float grad_scale, unsigned long long* state, void* stream) {
+    if (n < 0 || !state) return GSPN_ERR_ARG;
+    if (n == 0) return 0;
+    if (!p || !g || !m || !v || ((uintptr_t)state & 7)) return GSPN_ERR_ARG;
+    hipLaunchKernelGGL(adam_flat_dev_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, n, p, g, m, v, lr, b1, b2, eps, weight_decay,
+                       grad_scale, state);
+    return gspn_launch_status();
+}
+
 // <a, b> over n floats, deterministic: DOT_BLOCKS workgroups leave one partial each (per-thread sums in grid-stride order, wave shuffle tree,
 // one LDS hop), a second tiny launch adds the partials in index order, in double.  The loss of a training step as a product with a constant
 // tensor (bench.py) -- two streams at HBM rate instead of a library reduction.  work: DOT_BLOCKS floats.

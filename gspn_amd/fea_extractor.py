@@ -16,13 +16,16 @@ def pn2_first_fps(xyz):
     return farthest_point_sample(PN2_SA_SPEC[0][0], xyz.detach(), return_order=True)
 
 
-def pn2_geometry(xyz, fps0=None):
+def pn2_geometry(xyz, fps0=None, points=None):
     """Everything pn2_fea_extractor derives from coordinates alone: FPS + ball query of the three SA levels and the
     3-NN weights of the three FP levels.  Feed it to pn2_fea_extractor(..., geometry=...) -- typically computed for
-    the next batch on a GeometryStream (geometry.py) while the current batch trains.  fps0: pn2_first_fps(xyz), already enqueued."""
+    the next batch on a GeometryStream (geometry.py) while the current batch trains.  fps0: pn2_first_fps(xyz), already enqueued.
+    points: the batch's raw input features (colours), optional -- input-only data like the coordinates: their 16-byte-row copy for the first
+    gathering layer is then prepared here as well (the result is only valid for THESE features)."""
     sa, cur = [], xyz
     for level, (npoint, radius, nsample) in enumerate(PN2_SA_SPEC):
-        g = sa_geometry(cur, npoint, radius, nsample, inverse=level > 0, fps=fps0 if level == 0 else None)      # level 0 groups the raw colours: no gradient flows there
+        g = sa_geometry(cur, npoint, radius, nsample, inverse=level > 0, fps=fps0 if level == 0 else None,
+                        points=points if level == 0 else None)      # level 0 groups the raw colours: no gradient flows there
         sa.append(g)
         cur = g.new_xyz
     l1, l2, l3 = sa[0].new_xyz, sa[1].new_xyz, sa[2].new_xyz

@@ -27,18 +27,21 @@ from .tf_sampling import farthest_point_sample, gather_point
 class SAGeometry:
     """new_xyz (b,npoint,3), idx (b,npoint,nsample) int32, pts_cnt (b,npoint) int32 or None (knn), plus the inverse lists the gradient
     of the grouping gathers through: order (b, npoint*nsample) int32 = grouped positions sorted by data-point index, offsets (b, n+1)."""
-    __slots__ = ("new_xyz", "idx", "pts_cnt", "npoint", "nsample", "order", "offsets", "rel", "gidx", "scan_order")
+    __slots__ = ("new_xyz", "idx", "pts_cnt", "npoint", "nsample", "order", "offsets", "rel", "gidx", "scan_order", "feat4")
 
-    def __init__(self, new_xyz, idx, pts_cnt, npoint, nsample, order=None, offsets=None, rel=None, gidx=None, scan_order=None):
+    def __init__(self, new_xyz, idx, pts_cnt, npoint, nsample, order=None, offsets=None, rel=None, gidx=None, scan_order=None, feat4=None):
         self.new_xyz, self.idx, self.pts_cnt, self.npoint, self.nsample = new_xyz, idx, pts_cnt, npoint, nsample
         self.order, self.offsets = order, offsets
         # fused SA front end (gspn_sa_rel): per grouped row its centred coordinates (b*npoint*nsample, 4) and its source row (int32)
         self.rel, self.gidx = rel, gidx
         # spatial order of the INPUT cloud left behind by the FPS pre-pass ((b,n) int32 or None): fp_geometry scans in it
         self.scan_order = scan_order
+        # r06: the module's INPUT features padded to 16-byte rows ((b*n, 4*ceil(c/4)), what the gathering first layer reads) when the caller handed
+        # the raw features to sa_geometry(points=...): input-only data like the coordinates, so the pad runs ahead on the geometry stream too
+        self.feat4 = feat4
 
     def tensors(self):
-        return [t for t in (self.new_xyz, self.idx, self.pts_cnt, self.order, self.offsets, self.rel, self.gidx, self.scan_order) if t is not None]
+        return [t for t in (self.new_xyz, self.idx, self.pts_cnt, self.order, self.offsets, self.rel, self.gidx, self.scan_order, self.feat4) if t is not None]
 
 
 class FPGeometry:
@@ -71,10 +74,23 @@ def sa_front(xyz, new_xyz, idx, shift=None):
     return rel, gidx
 
 
-def sa_geometry(xyz, npoint, radius, nsample, knn=False, inverse=True, front=True, fps=None):
+def pad_features(points):
+    """(b, n, c) raw input features -> (b*n, 4*ceil(c/4)) with zero pad columns (gspn_pad_rows), or None when c is already a multiple of 4"""
+    b, n, c = points.shape
+    if c % 4 == 0:
+        return None
+    src = L.need(points.detach(), torch.float32, 3, "points").reshape(b * n, c)
+    out = torch.empty((b * n, (c + 3) // 4 * 4), dtype=torch.float32, device=src.device)
+    with torch.cuda.device(src.device):
+        L.check(L.lib().gspn_pad_rows(b * n, c, out.shape[1], L.ptr(src), L.ptr(out), L.stream()), "pad_rows")
+    return out
+
+
+def sa_geometry(xyz, npoint, radius, nsample, knn=False, inverse=True, front=True, fps=None, points=None):
     """pointnet_util.py:38-40: centres by FPS, neighbours by ball query (or kNN); front: also the coordinate half of the grouping.
     fps: (fps_idx, scan_order) of farthest_point_sample(npoint, xyz, return_order=True) when the caller has already enqueued it (on the
-    same stream) -- the long pole of a scene's geometry, worth starting before the host enqueues anything else"""
+    same stream) -- the long pole of a scene's geometry, worth starting before the host enqueues anything else.
+    points: the module's raw INPUT features (no gradient flows into them), optional: their 16-byte-row copy is prepared here (feat4)"""
     xyz = xyz.detach()
     fps_idx, scan_order = fps if fps is not None else farthest_point_sample(npoint, xyz, return_order=True)
     new_xyz = gather_point(xyz, fps_idx)
@@ -85,7 +101,8 @@ def sa_geometry(xyz, npoint, radius, nsample, knn=False, inverse=True, front=Tru
         idx, cnt = query_ball_point(radius, nsample, xyz, new_xyz)
     order, offsets = inverse_lists(idx.reshape(idx.shape[0], -1), xyz.shape[1]) if inverse else (None, None)
     rel, gidx = sa_front(xyz, new_xyz, idx) if front else (None, None)
-    return SAGeometry(new_xyz, idx, cnt, npoint, nsample, order, offsets, rel, gidx, scan_order)
+    feat4 = pad_features(points) if (points is not None and front) else None
+    return SAGeometry(new_xyz, idx, cnt, npoint, nsample, order, offsets, rel, gidx, scan_order, feat4)
 
 
 def fp_geometry(xyz1, xyz2, scan_order=None):

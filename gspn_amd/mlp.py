@@ -119,6 +119,39 @@ class LayerParams:
         return t
 
 
+# ---- gradient sinks (r06) ---------------------------------------------------------------------------------------------------------
+# A caller that keeps all parameter gradients in ONE flat buffer (parallel.FlatGradBucket: the operand of the gradient all-reduce and of the
+# one-launch Adam) can register, per parameter, the slice of that buffer its gradient belongs in (FlatGradBucket.attach_sinks()).  The backward
+# pass of a stack then lets its reduction kernels write dW / dbias / dbeta / dgamma STRAIGHT into those slices and returns None to autograd for
+# them: no per-step `cat` of ~60 gradient tensors into the bucket (the last library kernel inside the captured step but autograd's two gradient
+# accumulations).  Keyed by the parameter's data pointer (LayerParams.weights is a fresh VIEW of the stored kernel on every forward); an entry
+# holds a weak reference to the stored parameter and dies with it.  A parameter used by two stacks in one backward pass is written once, the
+# second gradient goes through autograd and FlatGradBucket.flatten() adds it.
+GRAD_SINKS = {}
+
+
+class _Sink:
+    __slots__ = ("bucket", "index", "view", "ref")
+
+    def __init__(self, bucket, index, view, ref):
+        self.bucket, self.index, self.view, self.ref = bucket, index, view, ref
+
+
+def _grad_buffer(param, sunk):
+    """where the gradient of `param` is to be written: its registered bucket slice (first gradient of this backward pass) or a fresh tensor"""
+    e = GRAD_SINKS.get(param.data_ptr())
+    if e is not None:
+        base = e.ref()
+        if base is None or base.data_ptr() != param.data_ptr() or base.numel() != param.numel():
+            GRAD_SINKS.pop(param.data_ptr(), None)                 # the parameter is gone (or moved): never write through a stale entry
+        elif e.index not in e.bucket._written and param.dtype == torch.float32 and param.is_contiguous():
+            e.bucket._written.add(e.index)
+            v = e.view.view(param.shape)
+            sunk.add(v.data_ptr())
+            return v
+    return torch.empty_like(param)
+
+
 def _zeros(n, dev, dtype=torch.float32):
     return torch.zeros(n, dtype=dtype, device=dev)
 
@@ -282,6 +315,7 @@ class _MlpStack(torch.autograd.Function):
         d_out = d_out.contiguous()
         dev = d_out.device
         grads = []
+        sunk = set()                             # data pointers of gradient buffers that ARE bucket slices (returned to autograd as None)
         dz = None if pool_ns else d_out          # dense upstream gradient of the current layer
         ldz = d_out.shape[1]
         dx0 = None
@@ -311,7 +345,7 @@ class _MlpStack(torch.autograd.Function):
                     L.check(lib.gspn_pool_rsum(rows // pool_ns, pool_ns, cout, L.ptr(d_out), L.ptr(ctx.arg), L.ptr(y if yarg is None else yarg),
                                                cout if yarg is None else 0, L.ptr(scale), L.ptr(shift),
                                                L.ptr(mean), L.ptr(var), BN_EPS, L.ptr(part), ctypes.byref(npart), st), "pool_rsum")
-                    coef[li] = _coef_from_parts(lib, rows, cout, npart.value, part, mean, var, lp, dev, st, sw)
+                    coef[li] = _coef_from_parts(lib, rows, cout, npart.value, part, mean, var, lp, dev, st, sw, sunk)
                 # ---- early coefficients of the top layer of a DENSE stack: one streaming pass over (d_out, Y); worth its launch on the long
                 #      layers only (the two-product pass A of a short layer costs less than the extra dependent kernels) ----
                 if (tr_all and (DENSE_TOP_RSUM or sw > 1) and lp.bn and dz is not None and li == len(layers) - 1 and li not in coef
@@ -321,7 +355,7 @@ class _MlpStack(torch.autograd.Function):
                     try:
                         L.check(lib.gspn_dense_rsum(rows, cout, L.ptr(dz), ldz, L.ptr(y), cout, L.ptr(scale), L.ptr(shift), L.ptr(mean), L.ptr(var),
                                                     BN_EPS, L.ptr(part), ctypes.byref(npart), st), "dense_rsum")
-                        coef[li] = _coef_from_parts(lib, rows, cout, npart.value, part, mean, var, lp, dev, st, sw)
+                        coef[li] = _coef_from_parts(lib, rows, cout, npart.value, part, mean, var, lp, dev, st, sw, sunk)
                     except NotImplementedError:
                         pass
                 known = coef.get(li)
@@ -333,15 +367,15 @@ class _MlpStack(torch.autograd.Function):
                     cA = torch.empty(cout, dtype=torch.float32, device=dev)
                     cB = torch.empty(cout, dtype=torch.float32, device=dev)
                     cC = torch.empty(cout, dtype=torch.float32, device=dev)
-                    dgamma = torch.empty(cout, dtype=torch.float32, device=dev) if lp.bn else None
-                    dbeta = torch.empty(cout, dtype=torch.float32, device=dev) if lp.bn else None
-                    dbias = torch.empty(cout, dtype=torch.float32, device=dev)
+                    dgamma = _grad_buffer(lp.gamma, sunk) if lp.bn else None
+                    dbeta = _grad_buffer(lp.beta, sunk) if lp.bn else None
+                    dbias = _grad_buffer(lp.biases, sunk)
                 a.cA, a.cB, a.cC = cA.data_ptr(), cB.data_ptr(), cC.data_ptr()
                 if li == 0 and ctx.pre is not None:
                     if known is None:
                         raise RuntimeError("mlp_stack(preagg=): the first layer's BN coefficients must be known before its backward (EARLY_R)")
                     ev = _tic()
-                    dW, dx0 = _preagg_backward(lib, ctx.pre, ctx.pre_x, lp, a, rows, cout, ctx.x_needs_grad, dev, st)
+                    dW, dx0 = _preagg_backward(lib, ctx.pre, ctx.pre_x, lp, a, rows, cout, ctx.x_needs_grad, dev, st, sunk)
                     # (the whole backward of the layer, both "passes": dW_feat and d(feat) on the source rows, dW_side on the output rows)
                     _toc(ev, "bwd", rows, cin, cout, 2.0 * cout * (ctx.pre_x.shape[0] * ctx.pre["c"] * (2 if ctx.x_needs_grad else 1) + rows * ctx.pre["side_n"]))
                     g = [dW, dbias]
@@ -350,7 +384,7 @@ class _MlpStack(torch.autograd.Function):
                     grads = g + grads
                     del a
                     continue
-                dW = torch.empty_like(lp.weights)
+                dW = _grad_buffer(lp.weights, sunk)
                 wcin = int(lib.gspn_mlp_gather_cin(ctypes.byref(ctx.gargs))) if gather0 is not None else cin
                 work = torch.empty(int(lib.gspn_mlp_bwd_work_bytes(rows, wcin, cout)) // 4 + 4, dtype=torch.float32, device=dev)
                 has_dx = li > 0 or ctx.x_needs_grad
@@ -369,7 +403,7 @@ class _MlpStack(torch.autograd.Function):
                         if want_rsum and sw == 1 and FUSED_COEF:
                             # the previous layer's coefficient kernel and this layer's dW reduction depend on the fused launch only: one launch
                             pc = [torch.empty(cin, dtype=torch.float32, device=dev) for _ in range(3)]
-                            pg = torch.empty((3, cin), dtype=torch.float32, device=dev)
+                            pg = [_grad_buffer(prev.gamma, sunk), _grad_buffer(prev.beta, sunk), _grad_buffer(prev.biases, sunk)]
                             L.check(lib.gspn_mlp_bwd_fused_coef(rows, cin, cout, ctypes.byref(a), L.ptr(lp.weights), L.ptr(xin), xld, L.ptr(in_scale),
                                                                 L.ptr(in_shift), L.ptr(dx), cin, L.ptr(work), L.ptr(dW), L.ptr(pmean), L.ptr(pvar), BN_EPS,
                                                                 L.ptr(part), ctypes.byref(npart), L.ptr(prev.gamma), L.ptr(pc[0]), L.ptr(pc[1]), L.ptr(pc[2]),
@@ -387,7 +421,7 @@ class _MlpStack(torch.autograd.Function):
                         if merged is not None:
                             coef[li - 1] = merged
                         elif want_rsum:
-                            coef[li - 1] = _coef_from_parts(lib, rows, cin, npart.value, part, pmean, pvar, prev, dev, st, sw)
+                            coef[li - 1] = _coef_from_parts(lib, rows, cin, npart.value, part, pmean, pvar, prev, dev, st, sw, sunk)
                         g = [dW, dbias]
                         if lp.bn:
                             g += [dbeta, dgamma]
@@ -494,7 +528,7 @@ class _MlpStack(torch.autograd.Function):
                                                          L.ptr(pY), cin, L.ptr(pscale), L.ptr(pshift), L.ptr(pmean), L.ptr(pvar), BN_EPS, L.ptr(part),
                                                          ctypes.byref(npart) if want_rsum else None, st), "mlp_bwd_data_ex")
                         if want_rsum:
-                            coef[li - 1] = _coef_from_parts(lib, rows, cin, npart.value, part, pmean, pvar, prev, dev, st, sw)
+                            coef[li - 1] = _coef_from_parts(lib, rows, cin, npart.value, part, pmean, pvar, prev, dev, st, sw, sunk)
                     else:
                         L.check(lib.gspn_mlp_bwd_data_cols(rows, cin, cout, ctypes.byref(a), L.ptr(lp.weights), int(gc[0]), int(gc[1]), L.ptr(dx),
                                                            dx.shape[1], st), "mlp_bwd_data_cols")
@@ -507,7 +541,8 @@ class _MlpStack(torch.autograd.Function):
             if side is not None:
                 main.wait_event(side.record_event())                # join: the gradients (and the workspaces) are complete past here
         del keep
-        return (dx0, None, None) + tuple(grads)
+        # gradients that were written straight into their bucket slices are not handed to autograd (it would re-assign / clone them)
+        return (dx0, None, None) + tuple(None if (g is not None and g.data_ptr() in sunk) else g for g in grads)
 
 
 _consts = {}
@@ -522,11 +557,13 @@ def _const_vectors(dev, c):
     return v
 
 
-def _preagg_backward(lib, pre, x, lp, a, rows, cout, need_dx, dev, st):
+def _preagg_backward(lib, pre, x, lp, a, rows, cout, need_dx, dev, st, sunk=None):
     """backward of a pre-aggregated first layer: dY written once (+ dW_side), its transpose-gather G onto the source rows, then
     dW_feat = feat^T . G and d(feat) = G . W_feat^T as small GEMMs without BN (always-open mask: scale 0, shift 1, dY = dz)"""
     c, side_n = pre["c"], pre["side_n"]
-    dW = torch.zeros_like(lp.weights) if pre["c"] + side_n < lp.weights.shape[0] else torch.empty_like(lp.weights)
+    dW = _grad_buffer(lp.weights, sunk if sunk is not None else set())
+    if pre["c"] + side_n < lp.weights.shape[0]:
+        dW.zero_()
     dy = torch.empty((rows, cout), dtype=torch.float32, device=dev)
     part = torch.empty(int(lib.gspn_preagg_part_floats(cout, max(side_n, 1))), dtype=torch.float32, device=dev)
     dws = dW[pre["ws0"]:pre["ws0"] + side_n]
@@ -561,7 +598,7 @@ def _preagg_backward(lib, pre, x, lp, a, rows, cout, need_dx, dev, st):
     return dW, dx
 
 
-def _coef_from_parts(lib, rows, c, nparts, part, mean, var, lp, dev, st, sw=1):
+def _coef_from_parts(lib, rows, c, nparts, part, mean, var, lp, dev, st, sw=1, sunk=None):
     """gspn_mlp_bwd_coef: partial sums [nparts][2][c] of (dyh, dyh*xhat) -> the layer's final BN-backward coefficients and its
     dgamma / dbeta / dbias, before its pass A runs.  sw > 1 (fused SyncBN): the partial rows are all-reduced first, the coefficients are
     those of the global batch (rows x sw), and dgamma / dbeta / dbias -- global sums then -- are divided by sw so that the gradient
@@ -569,8 +606,12 @@ def _coef_from_parts(lib, rows, c, nparts, part, mean, var, lp, dev, st, sw=1):
     cA = torch.empty(c, dtype=torch.float32, device=dev)
     cB = torch.empty(c, dtype=torch.float32, device=dev)
     cC = torch.empty(c, dtype=torch.float32, device=dev)
-    dgb = torch.empty((3, c), dtype=torch.float32, device=dev)
-    dgamma, dbeta, dbias = dgb[0], dgb[1], dgb[2]
+    if sunk is not None and sw == 1:
+        dgamma, dbeta, dbias = _grad_buffer(lp.gamma, sunk), _grad_buffer(lp.beta, sunk), _grad_buffer(lp.biases, sunk)
+        dgb = None
+    else:
+        dgb = torch.empty((3, c), dtype=torch.float32, device=dev)
+        dgamma, dbeta, dbias = dgb[0], dgb[1], dgb[2]
     if sw > 1:
         _allreduce_sum(part[:int(nparts) * 2 * c])
     L.check(lib.gspn_mlp_bwd_coef(rows * sw, c, int(nparts), L.ptr(part), L.ptr(mean), L.ptr(var), L.ptr(lp.gamma), BN_EPS,

@@ -118,10 +118,46 @@ class FlatGradBucket:
         for p, s in zip(self.params, self.sizes):
             self._views.append(self.flat[off:off + s].view_as(p))
             off += s
+        self._written = set()        # indices of the parameters whose gradient a backward pass wrote straight into its slice since the last flatten()
+        self.sinks = False
+
+    def attach_sinks(self):
+        """r06: register every parameter's slice with gspn_amd.mlp.GRAD_SINKS -- the shared-MLP backward then writes dW / dbias / dbeta / dgamma
+        straight into the bucket and flatten() has nothing left to gather (no `cat` kernel in the step).  Call AFTER anything that moves the
+        parameters' storage (FlatAdam re-attaches by itself).  Parameters whose gradient arrives through autograd as before (another op, a second
+        use of the same layer in one backward pass) are still folded in by flatten()."""
+        import weakref
+        from . import mlp
+        for k in [k for k, e in mlp.GRAD_SINKS.items() if e.bucket is self]:
+            del mlp.GRAD_SINKS[k]
+        for i, (p, v) in enumerate(zip(self.params, self._views)):
+            if p.dtype == torch.float32 and p.is_contiguous() and p.numel() > 0:
+                mlp.GRAD_SINKS[p.data_ptr()] = mlp._Sink(self, i, v.reshape(-1), weakref.ref(p))
+        self.sinks = True
+        return self
+
+    def _flatten_sunk(self):
+        """flatten() when (some) gradients already sit in their slices: only what autograd delivered separately is copied / added"""
+        with torch.no_grad():
+            for i, (p, v) in enumerate(zip(self.params, self._views)):
+                g = p.grad
+                fresh = g is not None and g.data_ptr() != v.data_ptr()
+                if i in self._written:
+                    if fresh:
+                        v.add_(g)                   # a second gradient of a parameter whose first one was written in place
+                elif fresh:
+                    v.copy_(g)
+                elif g is None:
+                    v.zero_()                       # no gradient this step
+                p.grad = v
+        self._written.clear()
+        return self.flat
 
     def flatten(self):
         if not self.params:
             return self.flat
+        if self._written:
+            return self._flatten_sunk()
         grads = []
         for p, v in zip(self.params, self._views):
             g = p.grad
@@ -156,7 +192,9 @@ class FlatAdam:
     it -- do this before anything captures their addresses), the gradients are the bucket's flat tensor, and step() is a single
     gspn_adam_flat launch (torch.optim.Adam's update rule; tested against it) instead of a multi-tensor launch per ~50 tensors."""
 
-    def __init__(self, bucket, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    def __init__(self, bucket, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, device_step=False):
+        """device_step=True (r06): the update count lives in device memory (gspn_adam_flat_dev), no argument of step() changes between calls --
+        step() can then be captured into a hipGraph together with the backward pass and replays correctly (`t` reads the counter back)"""
         self.bucket = bucket
         self.lr, self.betas, self.eps, self.weight_decay = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
         self.flat = torch.empty_like(bucket.flat)
@@ -167,9 +205,23 @@ class FlatAdam:
                 view.copy_(p)
                 p.data = view
                 off += s
+        if getattr(bucket, "sinks", False):
+            bucket.attach_sinks()                   # the parameters have just moved: the sinks are keyed by their data pointers
         self.m = torch.zeros_like(self.flat)
         self.v = torch.zeros_like(self.flat)
-        self.t = 0
+        self._t = 0
+        self._dev_state = torch.zeros(2, dtype=torch.int64, device=self.flat.device) if device_step else None
+
+    @property
+    def t(self):
+        """number of updates done (device_step: read back from the device -- a synchronisation)"""
+        return int(self._dev_state[0].item()) if self._dev_state is not None else self._t
+
+    @t.setter
+    def t(self, value):
+        self._t = int(value)
+        if self._dev_state is not None:
+            self._dev_state[0] = int(value)
 
     def zero_grad(self, set_to_none=True):
         for p in self.bucket.params:
@@ -180,10 +232,15 @@ class FlatAdam:
 
     def step(self, grad_scale=1.0):
         from . import _lib as L
-        self.t += 1
         with torch.cuda.device(self.flat.device):
+            if self._dev_state is not None:
+                L.check(L.lib().gspn_adam_flat_dev(self.flat.numel(), L.ptr(self.flat), L.ptr(self.bucket.flat), L.ptr(self.m), L.ptr(self.v), self.lr,
+                                                   self.betas[0], self.betas[1], self.eps, self.weight_decay, float(grad_scale), L.ptr(self._dev_state),
+                                                   L.stream()), "adam_flat_dev")
+                return
+            self._t += 1
             L.check(L.lib().gspn_adam_flat(self.flat.numel(), L.ptr(self.flat), L.ptr(self.bucket.flat), L.ptr(self.m), L.ptr(self.v), self.lr,
-                                           self.betas[0], self.betas[1], self.eps, self.weight_decay, float(grad_scale), self.t, L.stream()), "adam_flat")
+                                           self.betas[0], self.betas[1], self.eps, self.weight_decay, float(grad_scale), self._t, L.stream()), "adam_flat")
 
 
 def average_moving_statistics(tensors):

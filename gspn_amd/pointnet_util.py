@@ -156,7 +156,11 @@ def _sa_stack_gathered(points, geometry, xyz_first, cin, layers, is_training, bn
     m, ns = geometry.idx.shape[1], geometry.idx.shape[2]
     feat = L.need(points, torch.float32, 3, "points").reshape(b * n, c)
     if c % 4:
-        feat = _PadCols.apply(feat, (c + 3) // 4 * 4)                                      # 16-byte feature rows (the pad columns are ignored)
+        f4 = getattr(geometry, "feat4", None)
+        if f4 is not None and not points.requires_grad and tuple(f4.shape) == (b * n, (c + 3) // 4 * 4):
+            feat = f4                                                                        # padded ahead of time beside the coordinates (sa_geometry(points=...))
+        else:
+            feat = _PadCols.apply(feat, (c + 3) // 4 * 4)                                      # 16-byte feature rows (the pad columns are ignored)
     if preagg_ok(layers, bool(is_training), c):
         # the first layer's feature part on the b*n points instead of the b*m*ns grouped rows (mlp.py: PREAGG)
         order, offsets, idx = geometry.order, geometry.offsets, geometry.idx

@@ -500,6 +500,11 @@ int gspn_multi_copy(int n, const void* const* src, void* const* dst, const long*
 int gspn_adam_flat(long n, float* p, const float* g, float* m, float* v, float lr, float b1, float b2, float eps, float weight_decay,
                    float grad_scale, long step, void* stream);
 
+/* The same update with the step number kept on the DEVICE: state = two 8-byte words, zero-initialised once by the caller (state[0] = updates done so far,
+ * state[1] = scratch).  No argument changes from step to step, so the launch can be a node of a captured hipGraph (ABI 9). */
+int gspn_adam_flat_dev(long n, float* p, const float* g, float* m, float* v, float lr, float b1, float b2, float eps, float weight_decay,
+                       float grad_scale, unsigned long long* state, void* stream);
+
 /* out[0] = <a, b> over n floats, deterministic (1024 per-workgroup partials added in index order, in double).  work: gspn_dot_work_floats() floats. */
 long gspn_dot_work_floats(void);
 int gspn_dot(long n, const float* a, const float* b, float* work, float* out, void* stream);

@@ -452,6 +452,38 @@ def test_flat_adam_matches_torch_adam():
         assert rel_err(q_.detach(), p_.detach()) < 2e-6
 
 
+def test_flat_adam_with_the_step_counter_on_the_device_equals_the_host_counted_one_also_from_a_graph():
+    """FlatAdam(device_step=True) (gspn_adam_flat_dev): bit-identical parameters to the host-counted kernel over 7 updates -- eager, and replayed from
+    a hipGraph whose arguments never change (the last-ticket workgroup publishes step + 1) -- on a buffer of several hundred workgroups"""
+    from gspn_amd.parallel import FlatAdam, FlatGradBucket
+    g = torch.Generator().manual_seed(8)
+    shapes = [(300, 500), (64,), (1, 1, 131, 128)]
+    init = [torch.randn(*s_, generator=g) for s_ in shapes]
+    grads = [[torch.randn(*s_, generator=g).cuda() for s_ in shapes] for _ in range(7)]
+    outs = []
+    for mode in ("host", "device", "graph"):
+        ps = [torch.nn.Parameter(t.clone().cuda()) for t in init]
+        bucket = FlatGradBucket(ps)
+        opt = FlatAdam(bucket, lr=1e-2, weight_decay=1e-3, device_step=mode != "host")
+        graph = None
+        for step in range(7):
+            torch.cat([gr.reshape(-1) for gr in grads[step]], out=bucket.flat)
+            if mode == "graph" and step >= 2:
+                if graph is None:
+                    torch.cuda.synchronize()
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):
+                        opt.step(grad_scale=0.5)                  # (captured, not executed)
+                graph.replay()
+            else:
+                opt.step(grad_scale=0.5)
+        torch.cuda.synchronize()
+        assert opt.t == 7
+        outs.append(opt.flat.clone())
+    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(outs[0], outs[2])
+
+
 @pytest.mark.parametrize("n", [1, 3, 4096, 1_000_003, 16_777_216])
 def test_dot_kernel_is_deterministic_and_close_to_float64(n):
     """gspn_dot (r04: the bench's loss <out, g> on the library's own kernel instead of a library reduction): two launches, 1024 partials added
@@ -472,3 +504,80 @@ def test_dot_kernel_is_deterministic_and_close_to_float64(n):
     scale = (a.double() * b.double()).abs().sum() + 1e-30
     for o in outs:
         assert float((o.double() - ref).abs() / scale) < 1e-6
+
+
+def test_gradient_sinks_leave_the_bucket_bit_identical_and_capture_without_a_cat():
+    """r06 (parallel.FlatGradBucket.attach_sinks / mlp.GRAD_SINKS): the shared-MLP backward writes every parameter gradient straight into its slice of the
+    flat bucket -- same bits as gathering them with `cat`, p.grad re-pointed at the slices, also after FlatAdam has moved the parameters, also when the
+    step is replayed from a hipGraph; geometry carrying the pre-padded colours (sa_geometry(points=...)) gives the same result as padding inline."""
+    from gspn_amd import mlp, parallel
+    from gspn_amd.fea_extractor import pn2_fea_extractor, pn2_geometry
+    from gspn_amd.graph import CapturedStep
+    xyz = torch.from_numpy(D.batch("U", 2, 8192)).cuda()
+    col = torch.rand(2, 8192, 3, device="cuda")
+    go = torch.randn(2, 8192, 64, device="cuda")
+    geo_plain, geo_pad = pn2_geometry(xyz), pn2_geometry(xyz, points=col)
+    assert geo_plain["sa"][0].feat4 is None and tuple(geo_pad["sa"][0].feat4.shape) == (2 * 8192, 4)
+    flats = []
+    for sinks in (False, True):
+        store = fresh_store(11)
+        st = {}
+
+        def fwd_bwd():
+            for p in store.parameters():
+                p.grad = None
+            out = pn2_fea_extractor(xyz, col, 'fea', True, 0.5, geometry=geo_pad if sinks else geo_plain)
+            out.backward(go)
+            if "bucket" not in st:
+                st["bucket"] = parallel.FlatGradBucket(store.parameters())
+                st["opt"] = parallel.FlatAdam(st["bucket"], lr=0.0)          # moves the parameters into one flat buffer (lr 0: they keep their values)
+                if sinks:
+                    st["bucket"].attach_sinks()
+            elif sinks:
+                assert all(p.grad is None for p in store.parameters())      # nothing went through autograd: every gradient was written in place
+                assert len(st["bucket"]._written) == len(store.parameters())
+            st["bucket"].flatten()
+            return out.detach()
+
+        fwd_bwd()                                   # creates the variables, the bucket, the optimiser
+        st["bucket"].flat.fill_(float("nan"))
+        fwd_bwd()
+        torch.cuda.synchronize()
+        eager = st["bucket"].flat.clone()
+        assert torch.isfinite(eager).all()
+        assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(store.parameters(), st["bucket"]._views))
+        cap = CapturedStep(fwd_bwd)
+        st["bucket"].flat.fill_(float("nan"))
+        cap.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(st["bucket"].flat, eager)
+        flats.append(eager)
+        for k in [k for k, e in mlp.GRAD_SINKS.items() if e.bucket is st["bucket"]]:
+            del mlp.GRAD_SINKS[k]
+    assert torch.equal(flats[0], flats[1])
+
+
+def test_gradient_sinks_add_a_second_use_of_a_layer():
+    """a layer applied twice in one backward pass: the first gradient is written in place, the second arrives through autograd and flatten() adds it"""
+    from gspn_amd import mlp, parallel
+    g = torch.Generator().manual_seed(5)
+    x1 = torch.randn(512, 32, generator=g).cuda()
+    x2 = torch.randn(512, 32, generator=g).cuda()
+    res = []
+    for sinks in (False, True):
+        w = torch.nn.Parameter((torch.randn(32, 48, generator=torch.Generator().manual_seed(1)) * 0.1).cuda())
+        b = torch.nn.Parameter(torch.zeros(48).cuda())
+        beta = torch.nn.Parameter(torch.zeros(48).cuda())
+        gamma = torch.nn.Parameter(torch.ones(48).cuda())
+        lp = mlp.LayerParams(w, b, True, beta, gamma, torch.zeros(48).cuda(), torch.ones(48).cuda())
+        bucket = parallel.FlatGradBucket([w, b, beta, gamma])
+        if sinks:
+            bucket.attach_sinks()
+        out = mlp.mlp_stack(x1, 32, [lp], True, 0.5).sum() + 2.0 * mlp.mlp_stack(x2, 32, [lp], True, 0.5).square().sum()
+        out.backward()
+        bucket.flatten()
+        torch.cuda.synchronize()
+        res.append(bucket.flat.clone())
+        for k in [k for k, e in mlp.GRAD_SINKS.items() if e.bucket is bucket]:
+            del mlp.GRAD_SINKS[k]
+    assert torch.allclose(res[0], res[1], rtol=1e-6, atol=1e-6) and float(res[0].abs().max()) > 0

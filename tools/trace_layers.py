@@ -4,7 +4,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"] for r in rows]
 # a step ends with the optimiser kernel
-ends = [i for i, n in enumerate(names) if n.startswith("adam_flat_kernel")]
+ends = [i for i, n in enumerate(names) if n.startswith("adam_flat")]
 if len(ends) < 3:
     sys.exit("no steps found")
 lo, hi = ends[-2] + 1, ends[-1] + 1
