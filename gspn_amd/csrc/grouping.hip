@@ -895,6 +895,91 @@ __global__ __launch_bounds__(1024) void csr_build_lds_kernel(int L, int n, const
         tp[atomicAdd(&csr_cnt[k], 1)] = p;
     }
 }
+// ---- r06: the same build spread over G workgroups per scene (a counting sort by POSITION slices) ------------------------------------------
+// csr_build_lds_kernel walks a scene's L positions twice with ONE workgroup: 96 dependent (load, LDS atomic) rounds per pass at the dense
+// feature-propagation level (L = 3 x 32768), 80-100 us on 8 CUs -- the longest part of the drop-in gradient symbols with a workspace and of the
+// five list builds per batch.  Here workgroup (g, scene) owns the position slice [L g / G, L (g+1) / G):
+//   hist   its slice's histogram over the n keys (LDS atomics), written out as hist[scene][g][.]
+//   scan   per scene: offsets[k] = sum over keys < k of all slices' counts; hist[scene][g][k] becomes the first slot of slice g inside key k's
+//          group (slices in ascending g, so groups are position-ordered BETWEEN slices; within a slice the atomics' order is arbitrary)
+//   fill   its slice again: position -> tmp[slot++] (LDS cursors loaded from hist)
+// and the per-group sort (csr_sort_kernel) makes the order unique as before: identical output.  Taken when a scene has enough positions to share
+// out and the G x n histogram stays small against L (csr_slices).
+__global__ __launch_bounds__(1024) void csr_hist_kernel(int L, int n, int G, const int* __restrict__ idx, int* __restrict__ hist) {
+    extern __shared__ int csr_cnt[];                 // [n]
+    const int t = threadIdx.x, g = blockIdx.x, scene = blockIdx.y;
+    const int* ix = idx + (size_t)scene * L;
+    const int p0 = (int)((long)L * g / G), p1 = (int)((long)L * (g + 1) / G);
+    for (int k = t; k < n; k += 1024) csr_cnt[k] = 0;
+    __syncthreads();
+    for (int p = p0 + t; p < p1; p += 1024) {
+        const int k = ix[p];
+        if ((unsigned)k < (unsigned)n) atomicAdd(&csr_cnt[k], 1);
+    }
+    __syncthreads();
+    int* h = hist + ((size_t)scene * G + g) * n;
+    for (int k = t; k < n; k += 1024) h[k] = csr_cnt[k];
+}
+__global__ __launch_bounds__(1024) void csr_slice_scan_kernel(int n, int G, int* __restrict__ hist, int* __restrict__ offsets) {
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    int* h = hist + (size_t)blockIdx.x * G * n;
+    int* o = offsets + (size_t)blockIdx.x * (n + 1);
+    if (t == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int k = base + t;
+        int c[32];                                   // the G <= 32 slices' counts of key k: all loads in flight at once (coalesced over k for every g)
+#pragma unroll
+        for (int g = 0; g < 32; ++g) c[g] = (g < G && k < n) ? h[(size_t)g * n + k] : 0;
+        int v = 0;
+#pragma unroll
+        for (int g = 0; g < 32; ++g) v += c[g];
+        int incl = v;
+#pragma unroll
+        for (int s = 1; s < 64; s <<= 1) { const int u = __shfl_up(incl, s, 64); if (lane >= s) incl += u; }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int before = carry;
+        for (int w = 0; w < wave; ++w) before += wsum[w];
+        const int excl = before + incl - v;
+        if (k < n) {
+            o[k] = excl;
+            int run = excl;
+#pragma unroll
+            for (int g = 0; g < 32; ++g) if (g < G) { h[(size_t)g * n + k] = run; run += c[g]; }
+        }
+        __syncthreads();
+        if (t == 1023) carry = excl + v;
+        __syncthreads();
+    }
+    if (t == 0) o[n] = carry;
+}
+__global__ __launch_bounds__(1024) void csr_slice_fill_kernel(int L, int n, int G, const int* __restrict__ idx, const int* __restrict__ hist, int* __restrict__ tmp) {
+    extern __shared__ int csr_cnt[];                 // [n]: this slice's next free slot per key
+    const int t = threadIdx.x, g = blockIdx.x, scene = blockIdx.y;
+    const int* ix = idx + (size_t)scene * L;
+    int* tp = tmp + (size_t)scene * L;
+    const int* h = hist + ((size_t)scene * G + g) * n;
+    const int p0 = (int)((long)L * g / G), p1 = (int)((long)L * (g + 1) / G);
+    for (int k = t; k < n; k += 1024) csr_cnt[k] = h[k];
+    __syncthreads();
+    for (int p = p0 + t; p < p1; p += 1024) {
+        const int k = ix[p];
+        if ((unsigned)k >= (unsigned)n) continue;
+        tp[atomicAdd(&csr_cnt[k], 1)] = p;
+    }
+}
+// slices per scene of the spread-out build: about 4096 positions each, at most 32, and the G x n histogram no larger than 2 L ints; 1 = the one-workgroup kernel
+static inline int csr_slices(int L, int n) {
+    static const int on = getenv("GSPN_CSR_SLICES") ? atoi(getenv("GSPN_CSR_SLICES")) : -1;      // tuning hook: 0 / 1 = off, k > 1 = force k
+    if (on == 0 || on == 1) return 1;
+    long G = on > 1 ? on : L / 4096;
+    if (G > 32) G = 32;
+    while (G > 1 && G * (long)n > 2L * L) --G;
+    return G < 8 ? 1 : (int)G;                   // (a few slices do not pay for the two extra launches: measured 24.9 -> 24.0 us with 4 at SA level 2, 108 -> 122 at SA level 1 where n = 32768)
+}
 // one WAVE per value: rank sort of its group (the positions are distinct, so rank = number of smaller entries), tmp -> order.
 // Groups of up to 64 entries (the usual case: a handful to a few dozen) never touch memory again -- one entry per lane, compared through
 // v_readlane; longer groups count against the group re-read from L2.
@@ -977,10 +1062,11 @@ __global__ __launch_bounds__(256) void csr_sort_kernel(long nwaves, int L, int n
     if (bufA != dst)                                                                      // (bufA holds the sorted group after the last swap)
         for (int i = lane; i < cnt; i += 64) dst[i] = bufA[i];
 }
-// work: b*n ints (counts, then cursors) followed by b*L ints (the unsorted groups)
+// work: b*n ints (counts, then cursors) followed by b*L ints (the unsorted groups) followed by b*G*n ints (the slices' histograms, r06)
 extern "C" long gspn_inverse_lists_work_ints(int b, int L, int n) {
     if (b < 0 || L < 0 || n <= 0) return GSPN_ERR_ARG;
-    return (long)b * n + (long)b * L;
+    const int G = n <= CSR_LDS_MAX_N ? csr_slices(L, n) : 1;
+    return (long)b * n + (long)b * L + (G > 1 ? (long)b * G * n : 0L);
 }
 extern "C" int gspn_inverse_lists(int b, int L, int n, const int* idx, int* work, int* order, int* offsets, void* stream) {
     if (b < 0 || L < 0 || n <= 0) return GSPN_ERR_ARG;
@@ -999,6 +1085,23 @@ extern "C" int gspn_inverse_lists(int b, int L, int n, const int* idx, int* work
                                                 (int)(sizeof(int) * CSR_LDS_MAX_N));
             if (ea != hipSuccess) return (int)ea;
             attr_done = true;
+        }
+        const int G = csr_slices(L, n);
+        if (G > 1) {
+            int* hist = tmp + (size_t)b * L;
+            static bool attr2_done = false;
+            if (!attr2_done) {
+                hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&csr_hist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(int) * CSR_LDS_MAX_N));
+                hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&csr_slice_fill_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(int) * CSR_LDS_MAX_N));
+                if (e1 != hipSuccess) return (int)e1;
+                if (e2 != hipSuccess) return (int)e2;
+                attr2_done = true;
+            }
+            hipLaunchKernelGGL(csr_hist_kernel, dim3(G, b), dim3(1024), sizeof(int) * (size_t)n, st, L, n, G, idx, hist);
+            hipLaunchKernelGGL(csr_slice_scan_kernel, dim3(b), dim3(1024), 0, st, n, G, hist, offsets);
+            hipLaunchKernelGGL(csr_slice_fill_kernel, dim3(G, b), dim3(1024), sizeof(int) * (size_t)n, st, L, n, G, idx, hist, tmp);
+            if (total > 0) hipLaunchKernelGGL(csr_sort_kernel, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, st, nwaves, L, n, offsets, tmp, order);
+            return gspn_launch_status();
         }
         const size_t lds = gspn_claim_lds(4, reinterpret_cast<const void*>(&csr_build_lds_kernel), sizeof(int) * (size_t)n);
         hipLaunchKernelGGL(csr_build_lds_kernel, dim3(b), dim3(1024), lds, st, L, n, idx, offsets, tmp);
