@@ -665,6 +665,132 @@ __global__ __launch_bounds__(1024) void fps_bin_kernel(int n, const float* __res
     }
 }
 
+// ---- r06: K1 spread over G workgroups per scene (point slices) ----------------------------------------------------------------------------------
+// fps_bin_kernel walks a scene three times with ONE workgroup (bounding box, histogram, scatter: 3 x 32 dependent rounds at 32768 points): 74 us
+// stand-alone, 115 us beside the layers, on 8 CUs whose co-resident layer workgroups starve meanwhile (HISTORY 4.6).  The same counting sort by
+// slices of 4096 points: bbox partials -> per-slice voxel histograms -> per-scene scan (slices in ascending order inside a voxel) -> per-slice scatter.
+// Which points of a voxel end up where inside it is as arbitrary as before (LDS atomics), and as irrelevant: the sampling kernel is exact for every
+// assignment of points to cells, and fps_cellsort_kernel orders every cell by reference tie rank.
+struct FpsBox { float lo[3], hi[3]; };
+__global__ __launch_bounds__(1024) void fps_bbox_kernel(int n, int G, const float* __restrict__ inp, FpsBox* __restrict__ part) {
+    __shared__ float red[6][16];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, g = blockIdx.x, scene = blockIdx.y;
+    const float* xyz = inp + (size_t)scene * n * 3;
+    const int k0 = (int)((long)n * g / G), k1 = (int)((long)n * (g + 1) / G);
+    float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f};
+    for (int k = k0 + t; k < k1; k += 1024)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { const float v = xyz[k * 3 + a]; lo[a] = fminf(lo[a], v); hi[a] = fmaxf(hi[a], v); }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int s2 = 32; s2 >= 1; s2 >>= 1) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], s2, 64)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], s2, 64)); }
+        if (lane == 0) { red[a][wave] = lo[a]; red[3 + a][wave] = hi[a]; }
+    }
+    __syncthreads();
+    if (t < 3) {
+        float l = red[t][0], h = red[3 + t][0];
+        for (int w = 1; w < 16; ++w) { l = fminf(l, red[t][w]); h = fmaxf(h, red[3 + t][w]); }
+        part[(size_t)scene * G + g].lo[t] = l;
+        part[(size_t)scene * G + g].hi[t] = h;
+    }
+}
+// the scene's box from the G partial boxes (min / max are exact: the same box whatever the slicing), then this point's 12-bit Morton voxel
+struct FpsVoxelizer {
+    float lo[3], inv[3];
+    __device__ void init(const FpsBox* part, int G) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            float l = part[0].lo[a], h = part[0].hi[a];
+            for (int g = 1; g < G; ++g) { l = fminf(l, part[g].lo[a]); h = fmaxf(h, part[g].hi[a]); }
+            lo[a] = l;
+            inv[a] = (h > l) ? 16.0f / (h - l) : 0.0f;
+        }
+    }
+    __device__ unsigned operator()(const float* xyz, int k) const {
+        unsigned q[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            int v = (int)((xyz[k * 3 + a] - lo[a]) * inv[a]);
+            q[a] = (unsigned)(v < 0 ? 0 : (v > 15 ? 15 : v));
+        }
+        return spread4(q[0]) | (spread4(q[1]) << 1) | (spread4(q[2]) << 2);
+    }
+};
+__global__ __launch_bounds__(1024) void fps_vhist_kernel(int n, int G, const float* __restrict__ inp, const FpsBox* __restrict__ part, int* __restrict__ hist) {
+    __shared__ int h[4096];
+    const int t = threadIdx.x, g = blockIdx.x, scene = blockIdx.y;
+    const float* xyz = inp + (size_t)scene * n * 3;
+    FpsVoxelizer vox;
+    vox.init(part + (size_t)scene * G, G);
+    for (int i = t; i < 4096; i += 1024) h[i] = 0;
+    __syncthreads();
+    const int k0 = (int)((long)n * g / G), k1 = (int)((long)n * (g + 1) / G);
+    for (int k = k0 + t; k < k1; k += 1024) atomicAdd(&h[vox(xyz, k)], 1);
+    __syncthreads();
+    int* o = hist + ((size_t)scene * G + g) * 4096;
+    for (int i = t; i < 4096; i += 1024) o[i] = h[i];
+}
+// per scene: hist[g][v] <- first slot of slice g inside voxel v (voxels ascending, slices ascending inside a voxel); G <= 32
+__global__ __launch_bounds__(1024) void fps_vscan_kernel(int G, int* __restrict__ hist) {
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    int* h = hist + (size_t)blockIdx.x * G * 4096;
+    if (t == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < 4096; base += 1024) {
+        const int v = base + t;
+        int c[32];
+#pragma unroll
+        for (int g = 0; g < 32; ++g) c[g] = g < G ? h[(size_t)g * 4096 + v] : 0;
+        int tot = 0;
+#pragma unroll
+        for (int g = 0; g < 32; ++g) tot += c[g];
+        int incl = tot;
+#pragma unroll
+        for (int s2 = 1; s2 < 64; s2 <<= 1) { const int u = __shfl_up(incl, s2, 64); if (lane >= s2) incl += u; }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int before = carry;
+        for (int w = 0; w < wave; ++w) before += wsum[w];
+        int run = before + incl - tot;
+#pragma unroll
+        for (int g = 0; g < 32; ++g) if (g < G) { h[(size_t)g * 4096 + v] = run; run += c[g]; }
+        __syncthreads();
+        if (t == 1023) carry = run;
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(1024) void fps_vfill_kernel(int n, int G, const float* __restrict__ inp, const FpsBox* __restrict__ part, const int* __restrict__ hist,
+                                                         unsigned* __restrict__ keys, int* __restrict__ vorder) {
+    __shared__ int h[4096];
+    const int t = threadIdx.x, g = blockIdx.x, scene = blockIdx.y;
+    const float* xyz = inp + (size_t)scene * n * 3;
+    unsigned* out = keys + (size_t)scene * n;
+    FpsVoxelizer vox;
+    vox.init(part + (size_t)scene * G, G);
+    const int* hs = hist + ((size_t)scene * G + g) * 4096;
+    for (int i = t; i < 4096; i += 1024) h[i] = hs[i];
+    __syncthreads();
+    const int k0 = (int)((long)n * g / G), k1 = (int)((long)n * (g + 1) / G);
+    for (int k = k0 + t; k < k1; k += 1024) {
+        const int pos = atomicAdd(&h[vox(xyz, k)], 1);
+        out[pos] = fps_tie_rank(k);
+        if (vorder) vorder[(size_t)scene * n + pos] = k;
+    }
+}
+// slices per scene of the spread-out pre-pass (1 = fps_bin_kernel); scratch: G x (4096 ints + 6 floats) per scene, taken from the front of the scene's
+// slice of sxyz (n x 3 floats, written only by the cell sort that follows)
+static inline int fps_bin_slices(int n) {
+    static const int on = getenv("GSPN_FPS_BIN_SLICES") ? atoi(getenv("GSPN_FPS_BIN_SLICES")) : -1;      // tuning hook: 0 / 1 = off, k > 1 = force k
+    if (on == 0 || on == 1) return 1;
+    long G = on > 1 ? on : n / 4096;
+    if (G > 32) G = 32;
+    while (G > 1 && G * (4096L + 8) * 4 > (long)n * 12) --G;
+    return G < 4 ? 1 : (int)G;
+}
+
 template <int SZ>      // SZ = power of two >= csz, <= 2048; block = SZ/2 threads
 __global__ void fps_cellsort_kernel(int n, int csz, const float* __restrict__ inp, int* perm, float* __restrict__ sxyz) {
     __shared__ unsigned sk[SZ];
@@ -699,7 +825,19 @@ __global__ void fps_cellsort_kernel(int n, int csz, const float* __restrict__ in
 
 int gspn_fps_prepass_cells(int b, int n, int ncell, int csz, const float* inp, int* perm, float* sxyz, hipStream_t st, int* vorder) {
     if (csz > 2048 || (long long)ncell * csz < n || b > 65535) return GSPN_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(fps_bin_kernel, dim3(b), dim3(1024), 0, st, n, inp, reinterpret_cast<unsigned*>(perm), vorder);
+    const int G = fps_bin_slices(n);
+    if (G > 1) {
+        // scratch inside sxyz: every scene's own slice holds its G histograms, then its G partial boxes
+        // (stride n*3 floats per scene; the pointers below are per-scene bases folded into the kernels' scene * G indexing through a common layout)
+        int* hist = reinterpret_cast<int*>(sxyz);                                        // [b][G][4096] ints, packed from the front of sxyz
+        FpsBox* part = reinterpret_cast<FpsBox*>(hist + (size_t)b * G * 4096);           // [b][G] boxes behind them: b*G*(4096+6)*4 bytes <= b*n*12 (fps_bin_slices)
+        hipLaunchKernelGGL(fps_bbox_kernel, dim3(G, b), dim3(1024), 0, st, n, G, inp, part);
+        hipLaunchKernelGGL(fps_vhist_kernel, dim3(G, b), dim3(1024), 0, st, n, G, inp, part, hist);
+        hipLaunchKernelGGL(fps_vscan_kernel, dim3(b), dim3(1024), 0, st, G, hist);
+        hipLaunchKernelGGL(fps_vfill_kernel, dim3(G, b), dim3(1024), 0, st, n, G, inp, part, hist, reinterpret_cast<unsigned*>(perm), vorder);
+    } else {
+        hipLaunchKernelGGL(fps_bin_kernel, dim3(b), dim3(1024), 0, st, n, inp, reinterpret_cast<unsigned*>(perm), vorder);
+    }
     const dim3 g2(ncell, b);
     if (csz <= 128) hipLaunchKernelGGL(fps_cellsort_kernel<128>, g2, dim3(64), 0, st, n, csz, inp, perm, sxyz);
     else if (csz <= 256) hipLaunchKernelGGL(fps_cellsort_kernel<256>, g2, dim3(128), 0, st, n, csz, inp, perm, sxyz);
