@@ -280,6 +280,7 @@ def main():
 
     # diagnostic only (the line it prints is NOT a benchmark result: the geometry of every step is skipped): layers graph alone
     LAYERS_ONLY = use_graph and os.environ.get("GSPN_BENCH_LAYERS_ONLY") == "1"
+    GAP_EV = [] if os.environ.get("GSPN_BENCH_GAPS") == "1" else None        # diagnostic: two events around every replay
     SIDE = os.environ.get("GSPN_BENCH_SIDE", "") if LAYERS_ONLY else ""      # diagnostic: a chosen part of the geometry beside the layers
 
     tiny = torch.zeros(64, device=dev)
@@ -293,6 +294,11 @@ def main():
         def part(x):
             if "fps0" in SIDE:
                 tf_sampling.farthest_point_sample(2048, x)
+            if "fpsn:" in SIDE:                                # fpsn:<scenes>: FPS of SA level 1 for that many scenes in ONE launch every step (how does the tax scale with the CUs held?)
+                ns_ = int(SIDE.split("fpsn:")[1].split()[0])
+                if "xyzn" not in state:
+                    state["xyzn"] = torch.cat([batches[j % NB][0] for j in range(4)], 0).contiguous()
+                tf_sampling.farthest_point_sample(2048, state["xyzn"][:ns_].contiguous())
             if "fps32alt" in SIDE and i % 4 == 0:          # four batches' FPS in one launch every fourth step
                 if "xyz32" not in state:
                     state["xyz32"] = torch.cat([batches[0][0], batches[1][0], batches[2][0], batches[0][0]], 0).contiguous()
@@ -366,9 +372,17 @@ def main():
             tw = time.perf_counter()
             g = pend.pop(i).get(host_wait=True)               # geometry of THIS step (submitted DEPTH steps ago: long complete)
             state["t_wait"] += time.perf_counter() - tw
+            state["t_wait_geo"] = state.get("t_wait_geo", 0.0) + time.perf_counter() - tw      # (if this is not ~0 the layers' queue idled: the geometry was late)
         if use_graph:
             th = time.perf_counter()
-            graphs[k].replay()
+            if GAP_EV is not None and len(GAP_EV) < 400:
+                e_ = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                e_[0].record()                             # reached when the previous step's Adam is done
+                graphs[k].replay()
+                e_[1].record()                             # reached when this replay's last kernel is done
+                GAP_EV.append(e_)
+            else:
+                graphs[k].replay()
             state["t_replay"] = state.get("t_replay", 0.0) + time.perf_counter() - th
         else:
             if state["opt"] is not None:
@@ -438,6 +452,9 @@ def main():
     gc.collect()
     gc.freeze()
     state["t_wait"] = 0.0
+    state["t_wait_geo"] = 0.0
+    if GAP_EV is not None:
+        del GAP_EV[:]
     t0 = time.perf_counter()
     stamps = [] if os.environ.get("GSPN_BENCH_STEP_TIMES") == "1" else None      # (diagnostic: host clock after every step, the host trails the GPU by <= 2 steps)
     # SURVEY 8(d) asks for the MEDIAN step: one timing event per step on the layers' stream (created before the timed region; recording an
@@ -457,6 +474,10 @@ def main():
     t_host = time.perf_counter() - t0 - state["t_wait"]   # host time to enqueue the K steps, net of its waits on the GPU (launch-bound if close to dt)
     sync()
     dt = time.perf_counter() - t0
+    if GAP_EV and rank == 0:              # diagnostic (GSPN_BENCH_GAPS=1): from the end of the previous step's Adam to the end of this step's replay
+        sp = sorted(a.elapsed_time(b) for a, b in GAP_EV)
+        print("replay span incl. the idle time in front of it, ms: median %.4f mean %.4f p90 %.4f max %.4f over %d steps; host waited %.4f ms per step for geometry"
+              % (sp[len(sp) // 2], sum(sp) / len(sp), sp[int(len(sp) * 0.9)], sp[-1], len(sp), state.get("t_wait_geo", 0.0) / args.steps * 1e3), file=sys.stderr)
     if stamps is not None and rank == 0:
         w = 10
         print("ms/step by window of %d steps: %s" % (w, " ".join("%.2f" % ((stamps[min(j + w, len(stamps)) - 1] - (stamps[j - 1] if j else t0)) / (min(j + w, len(stamps)) - j) * 1e3)

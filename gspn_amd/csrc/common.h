@@ -126,6 +126,13 @@ static inline size_t gspn_claim_lds(int bit, const void* fn, size_t dyn) {
 // over, capped so very large problems loop instead of launching millions of tiny blocks
 static inline unsigned grid_for(long total, int block) {
     long g = (total + block - 1) / block;
+#ifdef GSPN_GRID_ROUND      // (r06 experiment) whole multiples of the planned CU count: no workgroup of an elementwise kernel is a 'fifth on a CU that was given four'
+    const long cap = (long)GSPN_PLAN_CUS * 16;
+    if (g > cap) g = cap;
+    if (g > GSPN_PLAN_CUS) g = g / GSPN_PLAN_CUS * GSPN_PLAN_CUS;
+    return (unsigned)(g < 1 ? 1 : g);
+#else
     const long cap = 256L * 16;
     return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
+#endif
 }

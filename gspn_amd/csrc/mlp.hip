@@ -2776,7 +2776,9 @@ extern "C" int gspn_mlp_bwd_wgrad(long rows, int cin, int cout, const gspn_dy_ar
 // ============================================================================================
 // every workgroup takes a slab of groups; thread (sub, col) walks the groups sub, sub + nsub, ... of the slab for its channel(s) in a
 // fixed order and the nsub partial sums of a channel meet in LDS, again in a fixed order: deterministic, one partial row per workgroup
+#ifndef RSUM_POOL_BLOCKS
 #define RSUM_POOL_BLOCKS 1024
+#endif
 __global__ __launch_bounds__(256) void pool_rsum_kernel(long groups, int ns, int c, const float* __restrict__ dPool, const int* __restrict__ arg,
                                                         const float* __restrict__ Y, int ldy, const float* __restrict__ scale,
                                                         const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ var,
@@ -3249,7 +3251,9 @@ __global__ __launch_bounds__(256) void preagg_fwd16_kernel(long rows, PreaggSrc 
 static bool preagg_shape_ok(int cout) { return cout >= 4 && cout <= 1024 && (cout & 3) == 0 && ((cout >> 2) & ((cout >> 2) - 1)) == 0; }
 extern "C" int gspn_preagg_ok(int cout) { return preagg_shape_ok(cout) ? 1 : 0; }
 // workgroups (= partial statistics rows) of gspn_preagg_fwd: every thread gets about four rows, 2048 workgroups at most
+#ifndef PREAGG_FWD_BLOCKS
 #define PREAGG_FWD_BLOCKS 2048
+#endif
 static unsigned preagg_fwd_blocks(long rows, int cout) {
     const long rpi = 256 / (cout >> 2);
     long nb = (rows + 4 * rpi - 1) / (4 * rpi);
@@ -3292,7 +3296,9 @@ extern "C" int gspn_preagg_fwd(long rows, int cout, int T, const float* F, const
 }
 // dY = cA * relu'(y*scale+shift) * dz + cB * y + cC, written out (rows, cout); per workgroup the partial side^T . dY (side_n x cout) into
 // part[workgroup][2][side_n*cout] (first half; the layout of the dW reduction's slots)
+#ifndef PREAGG_BWD_BLOCKS
 #define PREAGG_BWD_BLOCKS 1024
+#endif
 __global__ __launch_bounds__(256) void preagg_bwd_dy_kernel(long rows, int cout, gspn_dy_args a, const float* __restrict__ side, int side_ld, int side_n,
                                                             float* __restrict__ dY, float* __restrict__ part) {
     extern __shared__ float pa_sh[];                 // [rpi][side_n][cout]

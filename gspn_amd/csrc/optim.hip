@@ -77,7 +77,9 @@ extern "C" int gspn_adam_flat_dev(long n, float* p, const float* g, float* m, fl
 // <a, b> over n floats, deterministic: DOT_BLOCKS workgroups leave one partial each (per-thread sums in grid-stride order, wave shuffle tree,
 // one LDS hop), a second tiny launch adds the partials in index order, in double.  The loss of a training step as a product with a constant
 // tensor (bench.py) -- two streams at HBM rate instead of a library reduction.  work: DOT_BLOCKS floats.
+#ifndef DOT_BLOCKS
 #define DOT_BLOCKS 1024
+#endif
 __global__ __launch_bounds__(256) void dot_partial_kernel(long n4, long n, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ part) {
     __shared__ float sw[4];
     float s = 0.f;
