@@ -395,6 +395,28 @@ def test_inverse_lists_match_stable_sort(b, ln, n):
     assert torch.equal(order.cpu().long(), ref_order)
 
 
+@pytest.mark.parametrize("b,ln,n", [(3, 33001, 100), (2, 70001, 3000), (1, 131071, 777), (5, 40000, 1), (2, 98304, 2048)])
+def test_inverse_lists_spread_over_position_slices_with_dropped_positions(b, ln, n):
+    """r06 (csr_hist / csr_slice_scan / csr_slice_fill: several workgroups per scene for long index tensors): ragged slice boundaries (L not a multiple of the
+    slice count), key counts that are not multiples of the scan's 1024, one key for everything, and positions whose value lies OUTSIDE [0, n) -- dropped, as the
+    header promises (offsets[n] < L then) -- against a stable sort of the valid positions"""
+    from gspn_amd.geometry import inverse_lists
+    g = torch.Generator().manual_seed(ln * 7 + n)
+    idx = torch.randint(0, n, (b, ln), generator=g, dtype=torch.int32)
+    bad = torch.rand(b, ln, generator=g) < 0.07
+    idx[bad] = torch.where(torch.rand(int(bad.sum()), generator=g) < 0.5, torch.tensor(-1, dtype=torch.int32), torch.tensor(n + 5, dtype=torch.int32))
+    order, offsets = inverse_lists(idx.cuda(), n)
+    order, offsets = order.cpu().long(), offsets.cpu().long()
+    for s_ in range(b):
+        valid = (idx[s_] >= 0) & (idx[s_] < n)
+        pos = torch.nonzero(valid).squeeze(1)
+        keys, perm = torch.sort(idx[s_][valid].long(), stable=True)
+        nv = int(valid.sum())
+        assert int(offsets[s_, n]) == nv
+        assert torch.equal(order[s_, :nv], pos[perm])
+        assert torch.equal(offsets[s_], torch.searchsorted(keys.contiguous(), torch.arange(n + 1)))
+
+
 def test_copy_into_multi_copy():
     """graph.copy_into refills a nested structure of persistent buffers with one gspn_multi_copy launch: odd sizes, unaligned views, > 40 tensors"""
     from gspn_amd.graph import copy_into
