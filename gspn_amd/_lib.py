@@ -65,6 +65,7 @@ SIGNATURES = {
     "gspn_fp_concat": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P],
     "gspn_fp_concat_grad": [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "gspn_fp_concat_grad_csr": [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
+    "gspn_fp_concat_grad_csr_split": [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P],
     "gspn_nmdistance": [_I, _I, _P, _I, _P, _P, _P, _P, _P, _P],
     "gspn_nmdistance_grad": [_I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P],
     "gspn_nmdistance_grad_csr": [_I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],

@@ -44,11 +44,17 @@ struct CsrCopy {                      // the skip-link columns of fp_concat's gr
     const float* g; float* dst; int ld, c0, c1; long total;
 };
 
-template <int CPL, bool WEIGHTED>
+// SPLIT (r06; CPL = 1 only; callers whose summation order is NOT pinned to the reference's loop): a 16-lane row walks at most `split_t` entries of its list alone;
+// what lies beyond -- on clustered clouds one sparse point is the nearest neighbour of over a thousand dense points, and that one row used to BE the kernel's time
+// (63.8 us on the room scenes against 17.6 on uniform clouds) -- is then walked by all sixteen rows of the workgroup together (row r takes entries r, r + 16, ...),
+// the sixteen partial sums meet in LDS and are added to the owner's sum in row order.  A fixed order, so run-to-run identical bits; a DIFFERENT order from the
+// sequential one for lists longer than split_t, which is why the reference-pinned gradient (gspn_fp_concat_grad_csr: three_interpolate_grad) never takes it.
+template <int CPL, bool WEIGHTED, bool SPLIT = false>
 __global__ __launch_bounds__(256) void csr_gather16_kernel(int nt, int L, long src_scene_floats, int ld, int col0, const float* __restrict__ src,
                                                            const int* __restrict__ order, const int* __restrict__ offsets,
                                                            const float* __restrict__ weight, float* __restrict__ out, long ntot, long part,
-                                                           unsigned gather_blocks, CsrCopy cp, int chunks) {
+                                                           unsigned gather_blocks, CsrCopy cp, int chunks, int split_t = 0) {
+    static_assert(!SPLIT || CPL == 1, "the split walk is written for one float4 per lane");
     constexpr int U = CPL == 1 ? GSPN_CSR_U1 : (CPL == 2 ? GSPN_CSR_U1 / 2 : GSPN_CSR_U1 / 4);          // list entries whose row loads are issued together
     if (blockIdx.x >= gather_blocks) {
         const long nthreads = (long)(gridDim.x - gather_blocks) * 256;
@@ -63,13 +69,16 @@ __global__ __launch_bounds__(256) void csr_gather16_kernel(int nt, int L, long s
     // a work item = (target, chunk of 64 * CPL channels); `chunks` > 1 spreads a wide row over several 16-lane rows, each with its own
     // loads in flight (CPL = 1 then: 8 per lane) -- the walks are latency-bound, so more rows in flight beat fewer, fatter loads
     const long lt = (long)(blockIdx.x >> 3) * 16 + sub;
-    const long it = (long)(blockIdx.x & 7) * part + lt;
-    if (lt >= part || it >= ntot * chunks) return;               // (whole 16-lane rows leave together: the DPP moves below stay inside live rows)
+    const long it0 = (long)(blockIdx.x & 7) * part + lt;
+    const bool live = !(lt >= part || it0 >= ntot * chunks);
+    if (!SPLIT && !live) return;                                 // (whole 16-lane rows leave together: the DPP moves below stay inside live rows)
+    const long it = live ? it0 : 0;                              // (SPLIT: idle rows stay for the workgroup's barriers and help with the long lists)
     const long tg = it / chunks;
     const int ch = (int)(it - tg * chunks);
     const int s = (int)(tg / nt), j = (int)(tg - (long)s * nt);
     const int* off = offsets + (size_t)s * (nt + 1);
-    const int e0 = off[j], e1 = off[j + 1];
+    const int e0 = live ? off[j] : 0, e1_full = live ? off[j + 1] : 0;
+    const int e1 = (SPLIT && e1_full - e0 > split_t) ? e0 + split_t : e1_full;
     const int* ord = order + (size_t)s * L;
     const float* w = WEIGHTED ? weight + (size_t)s * L : nullptr;
     const char* gs = reinterpret_cast<const char*>(src + (size_t)s * src_scene_floats + col0 + 64 * CPL * ch + 4 * q);
@@ -127,6 +136,48 @@ __global__ __launch_bounds__(256) void csr_gather16_kernel(int nt, int L, long s
         ob = obn;
         wt = wtn;
     }
+    if constexpr (SPLIT) {
+        __shared__ int s_t0[16], s_t1[16], s_sc[16], s_chn[16];
+        __shared__ float4 s_part[16][16];
+        if (q == 0) { s_t0[sub] = e1; s_t1[sub] = e1_full; s_sc[sub] = s; s_chn[sub] = ch; }
+        __syncthreads();
+        for (int R = 0; R < 16; ++R) {
+            const int t0 = s_t0[R], t1 = s_t1[R];
+            if (t1 <= t0) continue;                              // (uniform over the workgroup: nearly every list ends inside split_t)
+            const int sc = s_sc[R];
+            const int* ordR = order + (size_t)sc * L;
+            const float* wR = WEIGHTED ? weight + (size_t)sc * L : nullptr;
+            const char* gR = reinterpret_cast<const char*>(src + (size_t)sc * src_scene_floats + col0 + 64 * s_chn[R] + 4 * q);
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int e = t0 + sub; e < t1; e += 64) {            // this row's entries e, e + 16, e + 32, e + 48 in flight together, added in ascending order
+                int pp[4];
+                float ww[4];
+                float4 vv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int ee = e + 16 * u;
+                    pp[u] = ee < t1 ? ordR[ee] : ordR[t0];
+                    ww[u] = WEIGHTED ? wR[pp[u]] : 1.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) vv[u] = *reinterpret_cast<const float4*>(gR + (size_t)(unsigned)((WEIGHTED ? pp[u] / 3 : pp[u]) * (ld * 4)));
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (e + 16 * u < t1) {
+                        if (WEIGHTED) { a.x += vv[u].x * ww[u]; a.y += vv[u].y * ww[u]; a.z += vv[u].z * ww[u]; a.w += vv[u].w * ww[u]; }
+                        else { a.x += vv[u].x; a.y += vv[u].y; a.z += vv[u].z; a.w += vv[u].w; }
+                    }
+            }
+            s_part[sub][q] = a;
+            __syncthreads();
+            if (sub == R) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { const float4 p4 = s_part[r][q]; acc[0].x += p4.x; acc[0].y += p4.y; acc[0].z += p4.z; acc[0].w += p4.w; }
+            }
+            __syncthreads();
+        }
+        if (!live) return;
+    }
     float* o = out + ((size_t)tg * chunks + ch) * (64 * CPL) + 4 * q;
 #pragma unroll
     for (int h = 0; h < CPL; ++h) *reinterpret_cast<float4*>(o + 64 * h) = acc[h];
@@ -135,7 +186,7 @@ __global__ __launch_bounds__(256) void csr_gather16_kernel(int nt, int L, long s
 // c == 64 * CPL, 16-byte aligned rows, byte offsets inside a scene's source below 2^31; returns GSPN_ERR_UNSUPPORTED otherwise (the caller
 // then takes the wave-per-target kernel)
 static int csr_gather16(bool weighted, int b, int nt, int L, long src_rows_per_scene, int c, int ld, int col0, const float* src, const int* order,
-                        const int* offsets, const float* weight, float* out, const CsrCopy& cp, hipStream_t st) {
+                        const int* offsets, const float* weight, float* out, const CsrCopy& cp, hipStream_t st, int split_t = 0) {
     static const bool off = getenv("GSPN_CSR_GATHER16") && atoi(getenv("GSPN_CSR_GATHER16")) == 0;      // comparison switch, read once
     if (off) return GSPN_ERR_UNSUPPORTED;
     if (c != 64 && c != 128 && c != 256) return GSPN_ERR_UNSUPPORTED;
@@ -155,6 +206,11 @@ static int csr_gather16(bool weighted, int b, int nt, int L, long src_rows_per_s
     const dim3 grid((unsigned)(gb + cb));
     const long ssf = src_rows_per_scene * (long)ld;
 #define CSR_GO(CPL_, W_) hipLaunchKernelGGL((csr_gather16_kernel<CPL_, W_>), grid, dim3(256), 0, st, nt, L, ssf, ld, col0, src, order, offsets, weight, out, ntot, part, (unsigned)gb, cp, chunks)
+    if (split_t > 0 && (c == 64 || chunks > 1)) {                // long lists shared out inside the workgroup (callers without a pinned summation order)
+        if (weighted) hipLaunchKernelGGL((csr_gather16_kernel<1, true, true>), grid, dim3(256), 0, st, nt, L, ssf, ld, col0, src, order, offsets, weight, out, ntot, part, (unsigned)gb, cp, chunks, split_t);
+        else hipLaunchKernelGGL((csr_gather16_kernel<1, false, true>), grid, dim3(256), 0, st, nt, L, ssf, ld, col0, src, order, offsets, weight, out, ntot, part, (unsigned)gb, cp, chunks, split_t);
+        return gspn_launch_status();
+    }
     if (weighted) { if (c == 64 || chunks > 1) CSR_GO(1, true); else if (c == 128) CSR_GO(2, true); else CSR_GO(4, true); }
     else { if (c == 64 || chunks > 1) CSR_GO(1, false); else if (c == 128) CSR_GO(2, false); else CSR_GO(4, false); }
 #undef CSR_GO

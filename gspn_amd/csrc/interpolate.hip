@@ -665,14 +665,14 @@ __global__ __launch_bounds__(256) void fp_concat_grad_csr_kernel(int n, int m, i
         }
     }
 }
-extern "C" int gspn_fp_concat_grad_csr(int b, int n, int m, int c2, int c1, int ld, const float* grad_out, const int* order, const int* offsets,
-                                       const float* weight, float* grad_points2, float* grad_points1, void* stream) {
-    if (b < 0 || n < 0 || m <= 0 || c2 <= 0 || c1 < 0 || ld < c2 + c1 || !order || !offsets || !weight) return GSPN_ERR_ARG;
+static int fp_concat_grad_csr_impl(int b, int n, int m, int c2, int c1, int ld, const float* grad_out, const int* order, const int* offsets,
+                                   const float* weight, float* grad_points2, float* grad_points1, int split_t, void* stream) {
+    if (b < 0 || n < 0 || m <= 0 || c2 <= 0 || c1 < 0 || ld < c2 + c1 || !order || !offsets || !weight || split_t < 0) return GSPN_ERR_ARG;
     if (b == 0 || n == 0) return 0;
     const long copy_total = grad_points1 ? (long)b * n * c1 : 0;
     if (grad_points2) {                                              // sixteen lanes per sparse point (csr_gather.h); same sums, same order
         const CsrCopy cp{grad_out, grad_points1, ld, c2, c1, copy_total};
-        const int rc = csr_gather16(true, b, m, 3 * n, n, c2, ld, 0, grad_out, order, offsets, weight, grad_points2, cp, (hipStream_t)stream);
+        const int rc = csr_gather16(true, b, m, 3 * n, n, c2, ld, 0, grad_out, order, offsets, weight, grad_points2, cp, (hipStream_t)stream, split_t);
         if (rc != GSPN_ERR_UNSUPPORTED) return rc;
     }
     const long nwaves2 = (long)b * m * ((c2 + 63) / 64);
@@ -683,6 +683,16 @@ extern "C" int gspn_fp_concat_grad_csr(int b, int n, int m, int c2, int c1, int 
     hipLaunchKernelGGL(fp_concat_grad_csr_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n, m, c2, c1, ld, grad_out, order, offsets,
                        weight, grad_points2, grad_points1, nwaves2, copy_total);
     return gspn_launch_status();
+}
+extern "C" int gspn_fp_concat_grad_csr(int b, int n, int m, int c2, int c1, int ld, const float* grad_out, const int* order, const int* offsets,
+                                       const float* weight, float* grad_points2, float* grad_points1, void* stream) {
+    return fp_concat_grad_csr_impl(b, n, m, c2, c1, ld, grad_out, order, offsets, weight, grad_points2, grad_points1, 0, stream);
+}
+// the same sums in a FIXED BUT DIFFERENT order for lists longer than split_t entries (csr_gather.h: SPLIT): for callers whose order is not the reference's
+// (the transposed aggregation of a pre-aggregated first layer); split_t = 0 is gspn_fp_concat_grad_csr
+extern "C" int gspn_fp_concat_grad_csr_split(int b, int n, int m, int c2, int c1, int ld, const float* grad_out, const int* order, const int* offsets,
+                                             const float* weight, float* grad_points2, float* grad_points1, int split_t, void* stream) {
+    return fp_concat_grad_csr_impl(b, n, m, c2, c1, ld, grad_out, order, offsets, weight, grad_points2, grad_points1, split_t, stream);
 }
 
 // ============================================================================================

@@ -130,6 +130,8 @@ def group_concat(xyz, new_xyz, points, idx, xyz_first=True, order=None, offsets=
 # fused SA front end: first conv2d straight from (b, n, c) features + 20 bytes per grouped row, no (b,m,ns,3+c) tensor
 FUSE_FP_FRONT = os.environ.get("GSPN_FUSE_FP_FRONT", "1") != "0"
 FUSE_SA_FRONT = os.environ.get("GSPN_FUSE_SA_FRONT", "1") != "0"
+# list length beyond which the transposed aggregation of a pre-aggregated FP layer shares a list out over the sixteen rows of a workgroup (0 = never)
+PREAGG_SPLIT_T = int(os.environ.get("GSPN_PREAGG_SPLIT_T", "128"))
 
 
 class _PadCols(torch.autograd.Function):
@@ -303,8 +305,10 @@ def _fp_stack_preagg(points2, points1, geometry, cin, layers, is_training, bn_de
     def scatter(dy, cout):
         g2 = torch.empty((b, m, cout), dtype=torch.float32, device=dy.device)
         if order is not None:
-            L.check(L.lib().gspn_fp_concat_grad_csr(b, n1, m, cout, 0, cout, L.ptr(dy), L.ptr(order), L.ptr(offsets), L.ptr(weight), L.ptr(g2), None,
-                                                    L.stream()), "fp_concat_grad_csr")
+            # (the order of THIS sum is the library's own -- the pre-aggregated layer is not the reference's arithmetic order anyway -- so lists longer than
+            #  PREAGG_SPLIT_T entries, the clustered clouds' case, are shared out over a workgroup's rows: csr_gather.h SPLIT)
+            L.check(L.lib().gspn_fp_concat_grad_csr_split(b, n1, m, cout, 0, cout, L.ptr(dy), L.ptr(order), L.ptr(offsets), L.ptr(weight), L.ptr(g2), None,
+                                                          PREAGG_SPLIT_T, L.stream()), "fp_concat_grad_csr_split")
         else:
             L.check(L.lib().gspn_fp_concat_grad(b, n1, m, cout, 0, cout, L.ptr(dy), L.ptr(idx), L.ptr(weight), L.ptr(g2), None, L.stream()), "fp_concat_grad")
         return g2.view(b * m, cout)

@@ -169,6 +169,11 @@ int gspn_fp_concat_grad(int b, int n, int m, int c2, int c1, int ld, const float
  * point in it -- coordinate-only data a caller builds once per batch (gspn_amd/geometry.py: fp_geometry). */
 int gspn_fp_concat_grad_csr(int b, int n, int m, int c2, int c1, int ld, const float* grad_out, const int* order, const int* offsets,
                             const float* weight, float* grad_points2, float* grad_points1, void* stream);
+/* The same sums with lists longer than split_t entries shared out over the sixteen rows of a workgroup (ABI 9): a fixed order -- run-to-run identical bits -- that
+ * DIFFERS from the reference loop's for those lists, so not for three_interpolate's gradient; for internal gathers whose order is this library's own (the transposed
+ * aggregation of a pre-aggregated first layer).  On clustered clouds one sparse point is the nearest neighbour of > 1000 dense points.  split_t = 0: as above. */
+int gspn_fp_concat_grad_csr_split(int b, int n, int m, int c2, int c1, int ld, const float* grad_out, const int* order, const int* offsets,
+                                  const float* weight, float* grad_points2, float* grad_points1, int split_t, void* stream);
 
 /* ---------------- tf_ops/nn_distance -------------------------------------------------- */
 

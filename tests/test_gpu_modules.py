@@ -603,3 +603,48 @@ def test_gradient_sinks_add_a_second_use_of_a_layer():
         for k in [k for k, e in mlp.GRAD_SINKS.items() if e.bucket is bucket]:
             del mlp.GRAD_SINKS[k]
     assert torch.allclose(res[0], res[1], rtol=1e-6, atol=1e-6) and float(res[0].abs().max()) > 0
+
+
+@pytest.mark.parametrize("c", [64, 128])
+def test_fp_concat_grad_csr_split_shares_long_lists_out_and_stays_reproducible(c):
+    """r06 (csr_gather.h SPLIT, gspn_fp_concat_grad_csr_split): lists longer than split_t walked by all sixteen rows of a workgroup -- same sums as the sequential walk
+    to float32 rounding (a different, FIXED order: bit-identical from run to run), identical BITS where no list is longer than split_t, on index tensors with one list of
+    5000 entries, a few of several hundred, many short ones, empty ones, and a target count that leaves idle rows in the last workgroup"""
+    import ctypes
+    from gspn_amd import _lib as L
+    from gspn_amd.geometry import inverse_lists
+    lib = L.lib()
+    b, n, m = 3, 9000, 1003
+    g = torch.Generator().manual_seed(c)
+    idx = torch.randint(7, m, (b, n, 3), generator=g, dtype=torch.int32)
+    idx[:, :1700, :] = 0                                  # one sparse point is the neighbour of 1700 dense points (5100 entries)
+    idx[:, 1700:1900, 0] = 1
+    idx[:, 1900:2300, 1] = 2
+    idx[1, 2300:2400, :] = 3
+    w = torch.rand(b, n, 3, generator=g)
+    go = torch.randn(b * n, c, generator=g)
+    idx, w, go = idx.cuda(), w.cuda(), go.cuda()
+    order, offsets = inverse_lists(idx.reshape(b, 3 * n), m)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def run(split_t):
+        out = torch.full((b, m, c), float("nan"), device="cuda")
+        assert lib.gspn_fp_concat_grad_csr_split(b, n, m, c, 0, c, P(go), P(order), P(offsets), P(w), P(out), None, split_t, st) == 0
+        torch.cuda.synchronize()
+        return out
+
+    seq = run(0)
+    ref = torch.zeros(b, m, c, dtype=torch.float64, device="cuda")
+    ref.view(b * m, c).index_add_(0, (idx.long() + torch.arange(b, device="cuda")[:, None, None] * m).reshape(-1),
+                                  (go.double().view(b, n, 1, c) * w.double().unsqueeze(-1)).reshape(-1, c))
+    scale = float(ref.abs().max())
+    assert float((seq.double() - ref).abs().max()) / scale < 1e-5
+    for t in (128, 64, 17):
+        a, a2 = run(t), run(t)
+        assert torch.equal(a, a2)                                               # a fixed order
+        assert float((a.double() - ref).abs().max()) / scale < 1e-5
+        lens = (offsets[:, 1:] - offsets[:, :-1])
+        short = (lens <= t)
+        assert torch.equal(a[short], seq[short])                                # lists inside split_t: the sequential walk, bit for bit
+    assert torch.equal(run(10 ** 6), seq)                                       # nothing is longer: identical everywhere
